@@ -1,0 +1,224 @@
+"""ctypes binding of the CPU oracle (oracle/liblbft_oracle.so).
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  The product package (librabft_simulator_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liblbft_oracle.so")
+
+
+class OracleConfig(C.Structure):
+    _fields_ = [
+        ("num_nodes", C.c_uint32),
+        ("delay_model", C.c_uint32),
+        ("mean", C.c_double),
+        ("variance", C.c_double),
+        ("uniform_lo", C.c_int64),
+        ("uniform_hi", C.c_int64),
+        ("commands_per_epoch", C.c_uint64),
+        ("target_commit_interval", C.c_int64),
+        ("delta", C.c_int64),
+        ("gamma", C.c_double),
+        ("lambda_", C.c_double),
+        ("quirks", C.c_uint32),
+        ("math_mode", C.c_uint32),
+        ("voting_rights", C.POINTER(C.c_uint64)),
+    ]
+
+
+class OracleCounters(C.Structure):
+    _fields_ = [
+        ("events", C.c_uint64 * 4),
+        ("rng_draws", C.c_uint64),
+        ("rounds", C.c_uint64),
+        ("commits", C.c_uint64),
+        ("response_inserts", C.c_uint64),
+        ("max_queue", C.c_uint64),
+        ("events_scheduled", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {
+            "events": list(self.events),
+            "rng_draws": self.rng_draws,
+            "rounds": self.rounds,
+            "commits": self.commits,
+            "response_inserts": self.response_inserts,
+            "max_queue": self.max_queue,
+            "events_scheduled": self.events_scheduled,
+        }
+
+
+COMMIT_DTYPE = np.dtype([("proposer", "<u8"), ("index", "<u8"), ("time", "<i8")])
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the oracle with g++ (Makefile in this directory)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        vp = C.c_void_p
+        L.lbft_oracle_create.argtypes = [C.POINTER(OracleConfig), C.c_uint64, C.POINTER(vp)]
+        L.lbft_oracle_create.restype = C.c_int
+        L.lbft_oracle_run_until.argtypes = [vp, C.c_int64]
+        L.lbft_oracle_run_until.restype = C.c_int
+        L.lbft_oracle_destroy.argtypes = [vp]
+        L.lbft_oracle_destroy.restype = None
+        L.lbft_oracle_commit_count.argtypes = [vp, C.c_uint32]
+        L.lbft_oracle_commit_count.restype = C.c_size_t
+        L.lbft_oracle_committed_history.argtypes = [vp, C.c_uint32, vp, C.c_size_t]
+        L.lbft_oracle_committed_history.restype = C.c_size_t
+        for name in ("last_committed_state", "active_round", "epoch"):
+            f = getattr(L, "lbft_oracle_" + name)
+            f.argtypes = [vp, C.c_uint32]
+            f.restype = C.c_uint64
+        L.lbft_oracle_startup_time.argtypes = [vp, C.c_uint32]
+        L.lbft_oracle_startup_time.restype = C.c_int64
+        L.lbft_oracle_counters_get.argtypes = [vp, C.POINTER(OracleCounters)]
+        L.lbft_oracle_counters_get.restype = None
+        L.lbft_oracle_last_error.argtypes = [vp]
+        L.lbft_oracle_last_error.restype = C.c_char_p
+        L.lbft_oracle_run_batch.argtypes = [
+            C.POINTER(OracleConfig), vp, C.c_size_t, C.c_int64, C.c_uint32, vp, vp, vp, vp, C.c_size_t,
+            C.POINTER(OracleCounters)]
+        L.lbft_oracle_run_batch.restype = C.c_int
+        L.lbft_oracle_siphash13.argtypes = [C.c_char_p, C.c_size_t]
+        L.lbft_oracle_siphash13.restype = C.c_uint64
+        L.lbft_oracle_xoshiro_first.argtypes = [C.c_uint64, vp, C.c_size_t]
+        L.lbft_oracle_xoshiro_first.restype = None
+        L.lbft_oracle_pick_author.argtypes = [vp, C.c_size_t, C.c_uint64]
+        L.lbft_oracle_pick_author.restype = C.c_uint64
+        L.lbft_oracle_leader.argtypes = [vp, C.c_size_t, C.c_uint64]
+        L.lbft_oracle_leader.restype = C.c_uint64
+        L.lbft_oracle_quorum_threshold.argtypes = [vp, C.c_size_t]
+        L.lbft_oracle_quorum_threshold.restype = C.c_uint64
+        L.lbft_oracle_sample_delays.argtypes = [C.POINTER(OracleConfig), C.c_uint64, vp, C.c_size_t]
+        L.lbft_oracle_sample_delays.restype = None
+        L.lbft_oracle_shuffle.argtypes = [C.c_uint64, vp, C.c_size_t]
+        L.lbft_oracle_shuffle.restype = None
+        L.lbft_oracle_exp_strict.argtypes = [C.c_double]
+        L.lbft_oracle_exp_strict.restype = C.c_double
+        L.lbft_oracle_log_strict.argtypes = [C.c_double]
+        L.lbft_oracle_log_strict.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def make_config(num_nodes=3, mean=10.0, variance=4.0, delay_model=0, uniform_lo=5, uniform_hi=15,
+                commands_per_epoch=30000, target_commit_interval=100000, delta=20, gamma=2.0,
+                lambda_=0.5, quirks=0, math_mode=0, voting_rights=None):
+    """Defaults = the reference CLI defaults (librabft-v2/src/main.rs:73-140)."""
+    cfg = OracleConfig()
+    cfg.num_nodes = num_nodes
+    cfg.delay_model = delay_model
+    cfg.mean = mean
+    cfg.variance = variance
+    cfg.uniform_lo = uniform_lo
+    cfg.uniform_hi = uniform_hi
+    cfg.commands_per_epoch = commands_per_epoch
+    cfg.target_commit_interval = target_commit_interval
+    cfg.delta = delta
+    cfg.gamma = gamma
+    cfg.lambda_ = lambda_
+    cfg.quirks = quirks
+    cfg.math_mode = math_mode
+    if voting_rights is not None:
+        arr = (C.c_uint64 * num_nodes)(*voting_rights)
+        cfg._keepalive = arr
+        cfg.voting_rights = C.cast(arr, C.POINTER(C.c_uint64))
+    return cfg
+
+
+class OracleSim:
+    """One simulated network: Simulator::new + loop_until (bft-lib/src/simulator.rs:200-250,380-475)."""
+
+    def __init__(self, cfg, seed):
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        rc = lib().lbft_oracle_create(C.byref(cfg), seed, C.byref(self.h))
+        if rc != 0:
+            raise RuntimeError("lbft_oracle_create failed: %d" % rc)
+
+    def run_until(self, max_clock):
+        rc = lib().lbft_oracle_run_until(self.h, max_clock)
+        if rc != 0:
+            raise RuntimeError("oracle panic: %s" % lib().lbft_oracle_last_error(self.h).decode())
+        return self
+
+    def commit_counts(self):
+        return [lib().lbft_oracle_commit_count(self.h, n) for n in range(self.cfg.num_nodes)]
+
+    def committed_history(self, node):
+        n = lib().lbft_oracle_commit_count(self.h, node)
+        out = np.zeros(n, dtype=COMMIT_DTYPE)
+        lib().lbft_oracle_committed_history(self.h, node, out.ctypes.data, n)
+        return out
+
+    def last_committed_states(self):
+        return [lib().lbft_oracle_last_committed_state(self.h, n) for n in range(self.cfg.num_nodes)]
+
+    def active_rounds(self):
+        return [lib().lbft_oracle_active_round(self.h, n) for n in range(self.cfg.num_nodes)]
+
+    def epochs(self):
+        return [lib().lbft_oracle_epoch(self.h, n) for n in range(self.cfg.num_nodes)]
+
+    def startup_times(self):
+        return [lib().lbft_oracle_startup_time(self.h, n) for n in range(self.cfg.num_nodes)]
+
+    def counters(self):
+        c = OracleCounters()
+        lib().lbft_oracle_counters_get(self.h, C.byref(c))
+        return c.as_dict()
+
+    def close(self):
+        if self.h:
+            lib().lbft_oracle_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def run_batch(cfg, seeds, max_clock, threads=1, history_cap=0):
+    """Run len(seeds) independent instances; returns dict of numpy arrays + summed counters."""
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    m, nn = len(seeds), cfg.num_nodes
+    commit_counts = np.zeros((m, nn), dtype=np.uint32)
+    active_rounds = np.zeros((m, nn), dtype=np.uint64)
+    last_states = np.zeros((m, nn), dtype=np.uint64)
+    hist = np.zeros((m, nn, history_cap), dtype=COMMIT_DTYPE) if history_cap else None
+    ctr = OracleCounters()
+    rc = lib().lbft_oracle_run_batch(
+        C.byref(cfg), seeds.ctypes.data, m, max_clock, threads, commit_counts.ctypes.data,
+        active_rounds.ctypes.data, last_states.ctypes.data, hist.ctypes.data if hist is not None else None,
+        history_cap, C.byref(ctr))
+    if rc != 0:
+        raise RuntimeError("oracle batch failed: %d" % rc)
+    return {"commit_counts": commit_counts, "active_rounds": active_rounds, "last_states": last_states,
+            "histories": hist, "counters": ctr.as_dict()}
+
+
+def leader(num_nodes, rnd, weights=None):
+    w = None
+    if weights is not None:
+        w = np.ascontiguousarray(weights, dtype=np.uint64)
+    return lib().lbft_oracle_leader(w.ctypes.data if w is not None else None, num_nodes, rnd)
