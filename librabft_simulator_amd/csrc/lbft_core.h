@@ -1,0 +1,872 @@
+// lbft_core.h -- the batched LibraBFTv2 discrete-event simulation step, written once for the HIP
+// kernels (lbft_kernels.hip).  One GPU lane simulates one independent network ("instance"); the state
+// of all instances lives in HBM as word-interleaved struct-of-arrays rows (row w of instance i is
+// state[w * stride + i]), so a wavefront touching the same field of its 64 instances issues one
+// coalesced 256-byte access.  See DESIGN.md for the layout and the reasoning.
+//
+// The reference keeps records in HashMaps keyed by 64-bit BCS/SipHash values; those hashes are
+// identities only, so this model replaces them with structural ids:
+//   * one block pool per instance (block id b >= 1; the QC of block b, its state and its ledger
+//     snapshot are all identified by b as well: only the block's author ever forms its QC);
+//   * per-node knowledge = three node-bitmasks per block (block known / QC in map / state pending);
+//   * timeouts, TCs and votes = author bitmasks (+ the timeout's highest_certified_block_round);
+//   * a notification = a refcounted snapshot slot holding a handful of ids and masks;
+//   * requests/responses are payload-free (the reference answers a request on the requester
+//     itself, so a response can never insert a record -- quirk Q1, asserted by the oracle).
+//
+// The file also compiles with a host C++ compiler: oracle/host_model.cpp builds it for the CPU-only
+// differential tests (compact model == full-fidelity oracle on thousands of seeds).  That host build
+// is test infrastructure; the product library (liblbft_hip.so) contains only the device build.
+//
+// Reference citations use the SURVEY.md shorthand (simulator.rs = bft-lib/src/simulator.rs, etc.).
+#ifndef LBFT_CORE_H
+#define LBFT_CORE_H
+
+#include <stdint.h>
+
+#include "lbft_math.h"
+
+namespace lbft {
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef int32_t i32;
+typedef uint64_t u64;
+typedef int64_t i64;
+
+#define LBFT_MAX_NODES 32  // masks are 32-bit words in this kernel family
+
+// Sticky per-instance fault bits (readable after the run; never abort the process).
+enum Fault : u32 {
+  F_QUEUE_OVERFLOW = 1u << 0,
+  F_SNAP_OVERFLOW = 1u << 1,
+  F_BLOCK_OVERFLOW = 1u << 2,
+  F_LOG_OVERFLOW = 1u << 3,
+  F_BALLOT_OVERFLOW = 1u << 4,
+  F_DURATION_TABLE = 1u << 5,
+  F_COMMIT_UNKNOWN_STATE = 1u << 6,  // reference would panic: "Committed states should be known"
+  F_COMMIT_NOT_SUCCESSOR = 1u << 7,  // reference would panic in SimulatedContext::commit
+  F_STAMP_OVERFLOW = 1u << 8,
+  F_INTERNAL = 1u << 9,
+  F_STEP_LIMIT = 1u << 10,
+};
+
+// Batch-uniform parameters (kernel argument).
+struct Params {
+  u32 n;       // nodes per instance
+  u32 m;       // instances in this batch (on this GPU)
+  u32 stride;  // row stride in words (m padded to a multiple of 64)
+  u32 qcap, scap, bcap, lcap;
+  i32 max_clock;
+  u32 delay_model;  // 0 LogNormal, 1 uniform integer
+  double mu, sigma;
+  i64 uni_lo;
+  u64 uni_span;
+  u64 cpe;  // commands_per_epoch
+  i64 tci;  // target_commit_interval
+  double lambda;
+  u32 weights[LBFT_MAX_NODES];
+  u32 total_votes, quorum;
+  u32 dur_len, leader_len;
+  const i64* dur_tab;    // dur_tab[k] = (i64)(delta * pow(k, gamma)) computed by the host libm (pacemaker.rs:123)
+  const u8* leader_tab;  // leader_tab[r] = PacemakerState::leader(r), filled by lbft_fill_leader_table
+  const u64* exp_tab;
+  const u64* zig_x;
+  const u64* zig_f;
+  // layout (word offsets of the per-instance rows)
+  u32 off_node, node_words;
+  u32 off_qhi, off_qlo, off_qmeta;
+  u32 off_snap, snap_words, off_snap_ref, off_snap_free;
+  u32 off_blk, blk_words;
+  u32 off_log;
+  u32 total_words;
+  u32 max_steps;  // events per instance per launch (0 = unlimited)
+};
+
+// Instance-level rows.
+enum InstField : u32 {
+  I_CLOCK = 0, I_STAMP, I_RNG0, I_RNG1, I_RNG2, I_RNG3, I_RNG4, I_RNG5, I_RNG6, I_RNG7,
+  I_QLEN, I_SNAP_FREE, I_NBLOCKS, I_FAULT, I_EV0, I_EV1, I_EV2, I_EV3, I_DRAWS, I_DONE,
+  I_MAXQ, I_MAXSNAP, I_WORDS
+};
+
+// Node-level rows (RecordStoreState record_store.rs:93-119, PacemakerState pacemaker.rs:60-77,
+// NodeState node.rs:28-45, CommitTracker node.rs:50-59, SimulatedNode simulator.rs:53-59,
+// SimulatedContext simulated_context.rs:75-83).
+enum NodeField : u32 {
+  NF_STARTUP = 0, NF_IGNORE_UNTIL, NF_EPOCH, NF_INIT_STATE_BLK, NF_PROPOSED_BLK, NF_HQC_ROUND, NF_HQC_BLK,
+  NF_HTC_ROUND, NF_CUR_ROUND, NF_HC_ROUND, NF_HCC_BLK, NF_TC_MASK, NF_TO_MASK, NF_TO_WEIGHT,
+  NF_ELECTION,  // 0 ongoing, 1 won, 2 closed; won block in bits 8..31
+  NF_BAL0_BLK, NF_BAL0_WEIGHT, NF_BAL0_AUTHORS, NF_BAL1_BLK, NF_BAL1_WEIGHT, NF_BAL1_AUTHORS,
+  NF_PM_EPOCH, NF_PM_ROUND, NF_PM_LEADER, NF_PM_START, NF_PM_DUR_LO, NF_PM_DUR_HI,
+  NF_LVR, NF_LOCKED, NF_LQAT, NF_TR_EPOCH, NF_TR_HCR, NF_TR_LCT,
+  NF_NEXT_CMD, NF_LAST_COMMITTED_BLK, NF_NCOMMITS,
+  NF_FIXED_WORDS  // followed by tc_hcbr[n] and to_hcbr[n]
+};
+
+// Block rows.
+enum BlockField : u32 { B_ROUND = 0, B_LINK /* prev | author << 16 */, B_TIME, B_CMD, B_DEPTH, B_EPOCH, B_KNOWN, B_QC, B_PEND, B_WORDS };
+
+// Snapshot (notification, data_sync.rs:16-39) rows; followed by tc_hcbr[n], to_hcbr[n].
+enum SnapField : u32 { S_EPOCH = 0, S_CERTS /* hcc | hqc << 16 */, S_PROP_VOTE /* proposed | vote << 16 */, S_TC_ROUND, S_TO_ROUND, S_TC_MASK, S_TO_MASK, S_FIXED_WORDS };
+
+#define LBFT_NO_LEADER 0xffu
+#define LBFT_NEVER INT64_MAX
+
+LBFT_HD u64 rotl64(u64 x, int b) { return (x << b) | (x >> (64 - b)); }
+
+LBFT_HD u64 mulhi64(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul64hi(a, b);
+#else
+  return (u64)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+LBFT_HD int clz64(u64 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __clzll((long long)x);
+#else
+  return __builtin_clzll(x);
+#endif
+}
+LBFT_HD int clz32(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __clz((int)x);
+#else
+  return __builtin_clz(x);
+#endif
+}
+LBFT_HD int ctz32(u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __ffs((int)x) - 1;
+#else
+  return __builtin_ctz(x);
+#endif
+}
+
+// Rust `f64 as i64` (saturating; NaN -> 0).
+LBFT_HD i64 f64_to_i64_sat(double v) {
+  if (v != v) return 0;
+  if (v >= 9223372036854775808.0) return INT64_MAX;
+  if (v <= -9223372036854775808.0) return INT64_MIN;
+  return (i64)v;
+}
+
+// ---- Xoshiro256** (rand_xoshiro 0.6) as a value type held in registers ---------------------------
+struct Rng {
+  u64 s0, s1, s2, s3;
+  u32 draws;
+  LBFT_HD void seed(u64 seed) {  // seed_from_u64: four SplitMix64 outputs
+    u64 x = seed, z;
+    x += 0x9e3779b97f4a7c15ULL; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; s0 = z ^ (z >> 31);
+    x += 0x9e3779b97f4a7c15ULL; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; s1 = z ^ (z >> 31);
+    x += 0x9e3779b97f4a7c15ULL; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; s2 = z ^ (z >> 31);
+    x += 0x9e3779b97f4a7c15ULL; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; s3 = z ^ (z >> 31);
+    draws = 0;
+  }
+  LBFT_HD u64 next_u64() {
+    draws++;
+    u64 r = rotl64(s1 * 5, 7) * 9;
+    u64 t = s1 << 17;
+    s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3;
+    s2 ^= t;
+    s3 = rotl64(s3, 45);
+    return r;
+  }
+  // rand 0.8 UniformInt<u64>::sample_single(0, n)  (configuration.rs:67)
+  LBFT_HD u64 gen_range_u64(u64 n) {
+    u64 zone = (n << clz64(n)) - 1;
+    for (;;) {
+      u64 v = next_u64();
+      u64 lo = v * n;
+      if (lo <= zone) return mulhi64(v, n);
+    }
+  }
+  // rand 0.8 UniformInt<u32>::sample_single(0, n) on next_u32 = next_u64 >> 32  (shuffle, simulator.rs:343,370)
+  LBFT_HD u32 gen_range_u32(u32 n) {
+    u32 zone = (n << clz32(n)) - 1;
+    for (;;) {
+      u32 v = (u32)(next_u64() >> 32);
+      u64 mm = (u64)v * n;
+      if ((u32)mm <= zone) return (u32)(mm >> 32);
+    }
+  }
+};
+
+// SipHash-1-3 (keys 0,0) of one little-endian u64 == Rust DefaultHasher over `Round(usize)`
+// (pacemaker.rs:101-108).
+LBFT_HD u64 siphash13_u64(u64 m) {
+  u64 v0 = 0x736f6d6570736575ULL, v1 = 0x646f72616e646f6dULL, v2 = 0x6c7967656e657261ULL, v3 = 0x7465646279746573ULL;
+#define LBFT_SIPROUND                                                         \
+  v0 += v1; v1 = rotl64(v1, 13); v1 ^= v0; v0 = rotl64(v0, 32);              \
+  v2 += v3; v3 = rotl64(v3, 16); v3 ^= v2;                                    \
+  v0 += v3; v3 = rotl64(v3, 21); v3 ^= v0;                                    \
+  v2 += v1; v1 = rotl64(v1, 17); v1 ^= v2; v2 = rotl64(v2, 32);
+  v3 ^= m; LBFT_SIPROUND v0 ^= m;
+  u64 b = 8ULL << 56;
+  v3 ^= b; LBFT_SIPROUND v0 ^= b;
+  v2 ^= 0xff;
+  LBFT_SIPROUND LBFT_SIPROUND LBFT_SIPROUND
+  return v0 ^ v1 ^ v2 ^ v3;
+}
+
+// Streaming SipHash-1-3 over u64 words (ledger State = hash of the committed history,
+// simulated_context.rs:51-55).
+struct Sip13 {
+  u64 v0, v1, v2, v3, nwords;
+  LBFT_HD void init() {
+    v0 = 0x736f6d6570736575ULL; v1 = 0x646f72616e646f6dULL; v2 = 0x6c7967656e657261ULL; v3 = 0x7465646279746573ULL;
+    nwords = 0;
+  }
+  LBFT_HD void word(u64 m) { v3 ^= m; LBFT_SIPROUND v0 ^= m; nwords++; }
+  LBFT_HD u64 finish() {
+    u64 b = (nwords * 8) << 56;
+    v3 ^= b; LBFT_SIPROUND v0 ^= b;
+    v2 ^= 0xff;
+    LBFT_SIPROUND LBFT_SIPROUND LBFT_SIPROUND
+    return v0 ^ v1 ^ v2 ^ v3;
+  }
+};
+
+// EpochConfiguration::pick_author(SipHash13(round)) (configuration.rs:65-75, pacemaker.rs:100-109)
+LBFT_HD u32 compute_leader(const u32* weights, u32 n, u32 total_votes, u64 round) {
+  Rng r;
+  r.seed(siphash13_u64(round));
+  u64 target = r.gen_range_u64(total_votes);
+  for (u32 a = 0; a < n; a++) {
+    if (weights[a] > target) return a;
+    target -= weights[a];
+  }
+  return 0;  // unreachable
+}
+
+struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at most one element
+  i64 next;
+  i32 send_to;  // -1 = none
+  bool broadcast;
+  bool query_all;
+};
+
+// ------------------------------------------------------------------------------------------------
+// One simulated network.  `row0` points at this instance's column (state + inst).
+// ------------------------------------------------------------------------------------------------
+struct Sim {
+  const Params& P;
+  u32* row0;
+  // instance scalars cached in registers for the duration of a launch
+  i32 clock;
+  u32 stamp, qlen, snap_free, nblocks, fault, maxq, maxsnap;
+  u32 ev0, ev1, ev2, ev3;
+  Rng rng;
+
+  LBFT_HD Sim(const Params& p, u32* r) : P(p), row0(r) {}
+
+  LBFT_HD u32 ld(u32 w) const { return row0[(size_t)w * P.stride]; }
+  LBFT_HD void st(u32 w, u32 v) const { row0[(size_t)w * P.stride] = v; }
+
+  // ---- field accessors ----
+  LBFT_HD u32 nfw(u32 node, u32 f) const { return P.off_node + node * P.node_words + f; }
+  LBFT_HD u32 nf(u32 node, u32 f) const { return ld(nfw(node, f)); }
+  LBFT_HD void nfs(u32 node, u32 f, u32 v) const { st(nfw(node, f), v); }
+  LBFT_HD u32 bfw(u32 b, u32 f) const { return P.off_blk + (b - 1) * P.blk_words + f; }
+  LBFT_HD u32 bf(u32 b, u32 f) const { return ld(bfw(b, f)); }
+  LBFT_HD void bfs(u32 b, u32 f, u32 v) const { st(bfw(b, f), v); }
+  LBFT_HD u32 blk_prev(u32 b) const { return bf(b, B_LINK) & 0xffffu; }
+  LBFT_HD u32 blk_author(u32 b) const { return bf(b, B_LINK) >> 16; }
+  LBFT_HD u32 blk_round(u32 b) const { return bf(b, B_ROUND); }
+  LBFT_HD bool bit(u32 b, u32 f, u32 node) const { return (bf(b, f) >> node) & 1u; }
+  LBFT_HD void set_bit(u32 b, u32 f, u32 node) const { bfs(b, f, bf(b, f) | (1u << node)); }
+  LBFT_HD void clr_bit(u32 b, u32 f, u32 node) const { bfs(b, f, bf(b, f) & ~(1u << node)); }
+  LBFT_HD u32 sfw(u32 slot, u32 f) const { return P.off_snap + slot * P.snap_words + f; }
+
+  LBFT_HD void load_scalars() {
+    clock = (i32)ld(I_CLOCK); stamp = ld(I_STAMP);
+    rng.s0 = ld(I_RNG0) | ((u64)ld(I_RNG1) << 32); rng.s1 = ld(I_RNG2) | ((u64)ld(I_RNG3) << 32);
+    rng.s2 = ld(I_RNG4) | ((u64)ld(I_RNG5) << 32); rng.s3 = ld(I_RNG6) | ((u64)ld(I_RNG7) << 32);
+    rng.draws = ld(I_DRAWS);
+    qlen = ld(I_QLEN); snap_free = ld(I_SNAP_FREE); nblocks = ld(I_NBLOCKS); fault = ld(I_FAULT);
+    ev0 = ld(I_EV0); ev1 = ld(I_EV1); ev2 = ld(I_EV2); ev3 = ld(I_EV3);
+    maxq = ld(I_MAXQ); maxsnap = ld(I_MAXSNAP);
+  }
+  LBFT_HD void store_scalars(bool done) {
+    st(I_CLOCK, (u32)clock); st(I_STAMP, stamp);
+    st(I_RNG0, (u32)rng.s0); st(I_RNG1, (u32)(rng.s0 >> 32)); st(I_RNG2, (u32)rng.s1); st(I_RNG3, (u32)(rng.s1 >> 32));
+    st(I_RNG4, (u32)rng.s2); st(I_RNG5, (u32)(rng.s2 >> 32)); st(I_RNG6, (u32)rng.s3); st(I_RNG7, (u32)(rng.s3 >> 32));
+    st(I_DRAWS, rng.draws);
+    st(I_QLEN, qlen); st(I_SNAP_FREE, snap_free); st(I_NBLOCKS, nblocks); st(I_FAULT, fault);
+    st(I_EV0, ev0); st(I_EV1, ev1); st(I_EV2, ev2); st(I_EV3, ev3);
+    st(I_MAXQ, maxq); st(I_MAXSNAP, maxsnap);
+    st(I_DONE, done ? 1u : 0u);
+  }
+
+  // ---- network delay (simulator.rs:110-118; rand_distr 0.4 LogNormal / StandardNormal ziggurat) ----
+  LBFT_HD double standard_normal() {
+    const double R = lbft_asdouble(0x400d3bb48209ad33ULL);  // ZIG_NORM_R
+    for (;;) {
+      u64 bits = rng.next_u64();
+      u32 i = (u32)(bits & 0xff);
+      double u = lbft_asdouble((1024ULL << 52) | (bits >> 12)) - 3.0;
+      double xi = lbft_asdouble(P.zig_x[i]);
+      double x = u * xi;
+      double ax = x < 0.0 ? -x : x;
+      if (ax < lbft_asdouble(P.zig_x[i + 1])) return x;
+      if (i == 0) {
+        double xx = 1.0, yy = 0.0;
+        while (-2.0 * yy < xx * xx) {
+          double a = lbft_asdouble((1023ULL << 52) | (rng.next_u64() >> 12)) - (1.0 - 0x1p-53);
+          double b = lbft_asdouble((1023ULL << 52) | (rng.next_u64() >> 12)) - (1.0 - 0x1p-53);
+          xx = lbft_log(a) / R;
+          yy = lbft_log(b);
+        }
+        return u < 0.0 ? xx - R : R - xx;
+      }
+      double f0 = lbft_asdouble(P.zig_f[i]), f1 = lbft_asdouble(P.zig_f[i + 1]);
+      double f01 = (double)(rng.next_u64() >> 11) * 0x1p-53;
+      if (f1 + (f0 - f1) * f01 < lbft_exp(-x * x / 2.0, P.exp_tab)) return x;
+    }
+  }
+  LBFT_HD i64 sample_delay() {
+    if (P.delay_model == 1) return P.uni_lo + (i64)rng.gen_range_u64(P.uni_span);
+    double nrm = standard_normal();
+    return f64_to_i64_sat(lbft_exp(P.mu + P.sigma * nrm, P.exp_tab));
+  }
+
+  // ---- event queue: unsorted compact array, ordered by (time asc, kind desc, stamp asc)
+  //      (ScheduledEvent::cmp, simulator.rs:149-161).  Events scheduled after max_clock can never
+  //      run (loop_until breaks at the first one, simulator.rs:389) and are dropped at push time;
+  //      they still consume a creation stamp.
+  LBFT_HD bool push_event(i64 time, u32 kind, u32 node, u32 sender, u32 slot) {
+    u32 my_stamp = stamp++;
+    if (time > (i64)P.max_clock) return false;
+    if (my_stamp >= (1u << 30)) { fault |= F_STAMP_OVERFLOW; return false; }
+    if (qlen >= P.qcap) { fault |= F_QUEUE_OVERFLOW; return false; }
+    st(P.off_qhi + qlen, (u32)time);
+    st(P.off_qlo + qlen, ((3u - kind) << 30) | my_stamp);
+    st(P.off_qmeta + qlen, node | (sender << 8) | (slot << 16));
+    qlen++;
+    if (qlen > maxq) maxq = qlen;
+    return true;
+  }
+  // Removes the minimum; returns false when the queue is empty.
+  LBFT_HD bool pop_event(i32& time, u32& kind, u32& meta) {
+    if (qlen == 0) return false;
+    u32 best = 0;
+    u32 bhi = ld(P.off_qhi), blo = ld(P.off_qlo);
+    for (u32 i = 1; i < qlen; i++) {
+      u32 hi = ld(P.off_qhi + i), lo = ld(P.off_qlo + i);
+      if (hi < bhi || (hi == bhi && lo < blo)) { bhi = hi; blo = lo; best = i; }
+    }
+    time = (i32)bhi;
+    kind = 3u - (blo >> 30);
+    meta = ld(P.off_qmeta + best);
+    qlen--;
+    if (best != qlen) {
+      st(P.off_qhi + best, ld(P.off_qhi + qlen));
+      st(P.off_qlo + best, ld(P.off_qlo + qlen));
+      st(P.off_qmeta + best, ld(P.off_qmeta + qlen));
+    }
+    return true;
+  }
+
+  // ---- snapshot slots (free stack + refcount) ----
+  LBFT_HD i32 snap_alloc() {
+    if (snap_free == 0) { fault |= F_SNAP_OVERFLOW; return -1; }
+    snap_free--;
+    u32 live = P.scap - snap_free;
+    if (live > maxsnap) maxsnap = live;
+    return (i32)ld(P.off_snap_free + snap_free);
+  }
+  LBFT_HD void snap_release(u32 slot) {
+    u32 r = ld(P.off_snap_ref + slot) - 1;
+    st(P.off_snap_ref + slot, r);
+    if (r == 0) { st(P.off_snap_free + snap_free, slot); snap_free++; }
+  }
+
+  // ---- leader / duration ----
+  LBFT_HD u32 leader(u32 round) const {
+    if (round < P.leader_len) return P.leader_tab[round];
+    return compute_leader(P.weights, P.n, P.total_votes, round);
+  }
+
+  // ---- SimulatedContext (simulated_context.rs:102-158): is the ledger state `blk` available? ----
+  LBFT_HD bool state_available(u32 node, u32 blk) const {
+    if (blk == nf(node, NF_LAST_COMMITTED_BLK)) return true;
+    if (blk == 0) return false;
+    return bit(blk, B_PEND, node);
+  }
+  // RecordStoreState::compute_state (record_store.rs:426-454) + CommandExecutor::compute
+  LBFT_HD bool compute_state(u32 node, u32 b) const {
+    u32 prev = blk_prev(b);
+    u32 base = prev ? prev : nf(node, NF_INIT_STATE_BLK);
+    if (!state_available(node, base)) return false;
+    set_bit(b, B_PEND, node);
+    return true;
+  }
+
+  // ---- RecordStoreState ----
+  LBFT_HD void clear_ballot(u32 node) const {
+    nfs(node, NF_BAL0_BLK, 0); nfs(node, NF_BAL0_WEIGHT, 0); nfs(node, NF_BAL0_AUTHORS, 0);
+    nfs(node, NF_BAL1_BLK, 0); nfs(node, NF_BAL1_WEIGHT, 0); nfs(node, NF_BAL1_AUTHORS, 0);
+  }
+  LBFT_HD void update_current_round(u32 node, u32 round) const {  // record_store.rs:207-219
+    if (round <= nf(node, NF_CUR_ROUND)) return;
+    nfs(node, NF_CUR_ROUND, round);
+    nfs(node, NF_PROPOSED_BLK, 0);
+    nfs(node, NF_TO_MASK, 0);
+    nfs(node, NF_TO_WEIGHT, 0);
+    nfs(node, NF_ELECTION, 0);
+    clear_ballot(node);
+  }
+  LBFT_HD void update_commit_3chain_round(u32 node, u32 b) const {  // record_store.rs:221-235
+    u32 p = blk_prev(b);
+    if (!p) return;
+    u32 pp = blk_prev(p);
+    if (!pp) return;
+    u32 r3 = blk_round(b), r2 = blk_round(p), r1 = blk_round(pp);
+    if (r3 == r2 + 1 && r2 == r1 + 1 && r1 > nf(node, NF_HC_ROUND)) {
+      nfs(node, NF_HC_ROUND, r1);
+      nfs(node, NF_HCC_BLK, b);
+    }
+  }
+  // verify_network_record + try_insert_network_record for a QC (record_store.rs:330-389,500-526).
+  // Caller has already checked qc.epoch_id == node epoch (node.rs:151-167).
+  LBFT_HD void insert_qc(u32 node, u32 b) const {
+    if (bit(b, B_QC, node)) return;       // "QuorumCertificate was already inserted."
+    if (!bit(b, B_KNOWN, node)) return;   // "The certified block hash of a QC must be verified first."
+    set_bit(b, B_QC, node);               // Q3: stored before the execution check
+    if (!compute_state(node, b)) return;  // bail!("I failed to execute a block with a QC ...")
+    u32 r = blk_round(b);
+    if (r > nf(node, NF_HQC_ROUND)) { nfs(node, NF_HQC_ROUND, r); nfs(node, NF_HQC_BLK, b); }
+    update_current_round(node, r + 1);
+    update_commit_3chain_round(node, b);
+  }
+  // Block (record_store.rs:263-291,466-476)
+  LBFT_HD void insert_block(u32 node, u32 b) const {
+    if (bit(b, B_KNOWN, node)) return;  // "Block was already inserted."
+    u32 p = blk_prev(b);
+    if (p && !bit(p, B_QC, node)) return;  // "The previous QC (if any) must be verified first."
+    u32 r = blk_round(b);
+    if (r == nf(node, NF_CUR_ROUND) && leader(r) == blk_author(b)) nfs(node, NF_PROPOSED_BLK, b);
+    set_bit(b, B_KNOWN, node);
+  }
+  // Vote (record_store.rs:292-329,477-499).  Caller checked the epoch.
+  LBFT_HD void insert_vote(u32 node, u32 author, u32 b) {
+    if (!bit(b, B_KNOWN, node)) return;
+    if (blk_round(b) != nf(node, NF_CUR_ROUND)) return;
+    u32 a0 = nf(node, NF_BAL0_AUTHORS), a1 = nf(node, NF_BAL1_AUTHORS);
+    if (((a0 | a1) >> author) & 1u) return;  // one vote per author
+    u32 b0 = nf(node, NF_BAL0_BLK), b1 = nf(node, NF_BAL1_BLK);
+    u32 fb, fw, fa;
+    if (b0 == b || b0 == 0) { fb = NF_BAL0_BLK; fw = NF_BAL0_WEIGHT; fa = NF_BAL0_AUTHORS; }
+    else if (b1 == b || b1 == 0) { fb = NF_BAL1_BLK; fw = NF_BAL1_WEIGHT; fa = NF_BAL1_AUTHORS; }
+    else { fault |= F_BALLOT_OVERFLOW; return; }
+    nfs(node, fb, b);
+    nfs(node, fa, nf(node, fa) | (1u << author));
+    if ((nf(node, NF_ELECTION) & 0xff) == 0) {
+      u32 w = nf(node, fw) + P.weights[author];
+      nfs(node, fw, w);
+      if (w >= P.quorum) nfs(node, NF_ELECTION, 1u | (b << 8));
+    }
+  }
+  // Timeout (record_store.rs:390-415,527-538).  Caller checked the epoch.
+  LBFT_HD void insert_timeout(u32 node, u32 author, u32 round, u32 hcbr) const {
+    if (hcbr > nf(node, NF_HQC_ROUND)) return;
+    u32 cur = nf(node, NF_CUR_ROUND);
+    if (round != cur) return;
+    u32 mask = nf(node, NF_TO_MASK);
+    if ((mask >> author) & 1u) return;
+    mask |= 1u << author;
+    nfs(node, NF_TO_MASK, mask);
+    nfs(node, NF_FIXED_WORDS + P.n + author, hcbr);
+    u32 w = nf(node, NF_TO_WEIGHT) + P.weights[author];
+    nfs(node, NF_TO_WEIGHT, w);
+    if (w >= P.quorum) {
+      nfs(node, NF_TC_MASK, mask);
+      for (u32 a = 0; a < P.n; a++) nfs(node, NF_FIXED_WORDS + a, nf(node, NF_FIXED_WORDS + P.n + a));
+      nfs(node, NF_HTC_ROUND, cur);
+      update_current_round(node, cur + 1);
+    }
+  }
+  // RecordStore::proposed_block (record_store.rs:611-634): block id or 0
+  LBFT_HD u32 proposed_block(u32 node) const {
+    if (nf(node, NF_EPOCH) != nf(node, NF_PM_EPOCH) || nf(node, NF_CUR_ROUND) != nf(node, NF_PM_ROUND)) return 0;
+    if (nf(node, NF_PM_LEADER) == LBFT_NO_LEADER) return 0;
+    return nf(node, NF_PROPOSED_BLK);
+  }
+  // propose_block (record_store.rs:655-674) + CommandFetcher::fetch (simulated_context.rs:116-125)
+  LBFT_HD void propose_block(u32 node, u32 prev_blk, i64 local_clock) {
+    u32 cmd = nf(node, NF_NEXT_CMD);
+    nfs(node, NF_NEXT_CMD, cmd + 1);
+    if (nblocks >= P.bcap || nblocks >= 0xfffeu) { fault |= F_BLOCK_OVERFLOW; return; }
+    u32 b = ++nblocks;
+    u32 base = prev_blk ? prev_blk : nf(node, NF_INIT_STATE_BLK);
+    u32 depth = (base ? bf(base, B_DEPTH) : 0) + 1;
+    bfs(b, B_ROUND, nf(node, NF_CUR_ROUND));
+    bfs(b, B_LINK, prev_blk | (node << 16));
+    bfs(b, B_TIME, (u32)(i32)local_clock);
+    bfs(b, B_CMD, cmd);
+    bfs(b, B_DEPTH, depth);
+    bfs(b, B_EPOCH, nf(node, NF_EPOCH));
+    bfs(b, B_KNOWN, 0); bfs(b, B_QC, 0); bfs(b, B_PEND, 0);
+    insert_block(node, b);
+  }
+  // create_vote (record_store.rs:676-700)
+  LBFT_HD bool create_vote(u32 node, u32 b) {
+    if (!compute_state(node, b)) return false;
+    insert_vote(node, node, b);
+    return true;
+  }
+  // check_for_new_quorum_certificate (record_store.rs:702-738)
+  LBFT_HD bool check_for_new_qc(u32 node) const {
+    u32 e = nf(node, NF_ELECTION);
+    if ((e & 0xff) != 1) return false;
+    u32 b = e >> 8;
+    if (blk_author(b) != node) return false;
+    nfs(node, NF_ELECTION, 2);
+    insert_qc(node, b);
+    return true;
+  }
+
+  // ---- Pacemaker (pacemaker.rs:111-124,142-207) ----
+  struct PmActions { bool propose; u32 propose_prev; bool create_timeout; u32 timeout_round; i32 send_to; bool broadcast; bool query_all; i64 next; };
+
+  LBFT_HD i64 duration(u32 node, u32 round) {
+    u32 hc = nf(node, NF_HC_ROUND);
+    u32 hccr = hc > 0 ? hc + 2 : 0;
+    if (round <= hccr) { fault |= F_INTERNAL; return 0; }
+    u32 k = round - hccr;
+    if (k >= P.dur_len) { fault |= F_DURATION_TABLE; k = P.dur_len - 1; }
+    return P.dur_tab[k];
+  }
+  LBFT_HD PmActions update_pacemaker(u32 node, i64 lqat, i64 lclock) {
+    PmActions a;
+    a.propose = false; a.propose_prev = 0; a.create_timeout = false; a.timeout_round = 0;
+    a.send_to = -1; a.broadcast = false; a.query_all = false; a.next = LBFT_NEVER;
+    u32 hqc = nf(node, NF_HQC_ROUND), htc = nf(node, NF_HTC_ROUND);
+    u32 ar = (hqc > htc ? hqc : htc) + 1;
+    u32 epoch = nf(node, NF_EPOCH), pe = nf(node, NF_PM_EPOCH);
+    u32 pm_round = nf(node, NF_PM_ROUND);
+    u32 pm_leader = nf(node, NF_PM_LEADER);
+    i64 start = (i64)(i32)nf(node, NF_PM_START);
+    i64 dur = (i64)(nf(node, NF_PM_DUR_LO) | ((u64)nf(node, NF_PM_DUR_HI) << 32));
+    if (epoch > pe || (epoch == pe && ar > pm_round)) {
+      pm_round = ar;
+      pm_leader = leader(ar);
+      start = lclock;
+      dur = duration(node, ar);
+      nfs(node, NF_PM_EPOCH, epoch); nfs(node, NF_PM_ROUND, ar); nfs(node, NF_PM_LEADER, pm_leader);
+      nfs(node, NF_PM_START, (u32)(i32)lclock);
+      nfs(node, NF_PM_DUR_LO, (u32)(u64)dur); nfs(node, NF_PM_DUR_HI, (u32)((u64)dur >> 32));
+      if (pm_leader != node) a.send_to = (i32)pm_leader;
+    }
+    if (pm_leader == node && proposed_block(node) == 0) {
+      a.propose = true;
+      a.propose_prev = nf(node, NF_HQC_BLK);
+      a.broadcast = true;
+      a.next = lclock;
+    }
+    // has_timeout(local_author, active_round) (record_store.rs:651-653); `ar` is the recomputed
+    // active round exactly as in the reference (pacemaker.rs:183)
+    bool has_timeout = (ar == nf(node, NF_CUR_ROUND)) && ((nf(node, NF_TO_MASK) >> node) & 1u);
+    if (!has_timeout) {
+      i64 deadline = (i64)((u64)start + (u64)dur);
+      if (lclock >= deadline) { a.create_timeout = true; a.timeout_round = ar; a.broadcast = true; }
+      else if (deadline < a.next) a.next = deadline;
+    } else {
+      i64 period = f64_to_i64_sat(P.lambda * (double)dur);
+      i64 qd = (i64)((u64)lqat + (u64)period);
+      if (lclock >= qd) { a.query_all = true; qd = (i64)((u64)lclock + (u64)period); }
+      if (qd < a.next) a.next = qd;
+    }
+    return a;
+  }
+
+  // ---- CommitTracker::update_tracker (node.rs:364-396) ----
+  LBFT_HD void update_tracker(u32 node, i64 lqat, i64 lclock, bool& query_all, i64& next) const {
+    u32 epoch = nf(node, NF_EPOCH);
+    i64 lct = (i64)(i32)nf(node, NF_TR_LCT);
+    if (epoch > nf(node, NF_TR_EPOCH)) {
+      nfs(node, NF_TR_EPOCH, epoch);
+      nfs(node, NF_TR_HCR, nf(node, NF_HC_ROUND));
+      lct = lclock;
+      nfs(node, NF_TR_LCT, (u32)(i32)lclock);
+    } else {
+      u32 hcr = nf(node, NF_HC_ROUND);
+      if (hcr > nf(node, NF_TR_HCR)) {
+        nfs(node, NF_TR_HCR, hcr);
+        lct = lclock;
+        nfs(node, NF_TR_LCT, (u32)(i32)lclock);
+      }
+    }
+    i64 deadline = (i64)((u64)(lct > lqat ? lct : lqat) + (u64)P.tci);
+    query_all = false;
+    if (lclock >= deadline) { query_all = true; deadline = (i64)((u64)lclock + (u64)P.tci); }
+    next = deadline;
+  }
+
+  // ---- NodeState::process_commits (node.rs:313-350) + StateFinalizer::commit ----
+  LBFT_HD void process_commits(u32 node) {
+    u32 after = nf(node, NF_TR_HCR);
+    u32 x = nf(node, NF_HCC_BLK);  // committed_states_after (record_store.rs:557-574)
+    if (x) x = blk_prev(x);
+    if (x) x = blk_prev(x);
+    u32 start = x, k = 0;
+    while (x && blk_round(x) > after) { k++; x = blk_prev(x); }
+    for (u32 j = k; j-- > 0;) {  // oldest first
+      u32 y = start;
+      for (u32 s = 0; s < j; s++) y = blk_prev(y);
+      // SimulatedContext::commit (simulated_context.rs:160-185)
+      if (!bit(y, B_PEND, node)) { fault |= F_COMMIT_UNKNOWN_STATE; return; }
+      u32 prev = blk_prev(y);
+      u32 base = prev ? prev : nf(node, NF_INIT_STATE_BLK);
+      if (base != nf(node, NF_LAST_COMMITTED_BLK)) { fault |= F_COMMIT_NOT_SUCCESSOR; return; }
+      clr_bit(y, B_PEND, node);
+      nfs(node, NF_LAST_COMMITTED_BLK, y);
+      u32 nc = nf(node, NF_NCOMMITS);
+      if (nc >= P.lcap) { fault |= F_LOG_OVERFLOW; return; }
+      st(P.off_log + node * P.lcap + nc, y);
+      nfs(node, NF_NCOMMITS, nc + 1);
+      // read_epoch_id (simulated_context.rs:199-207)
+      u64 new_epoch = (u64)bf(y, B_DEPTH) / P.cpe;
+      if (new_epoch > (u64)nf(node, NF_EPOCH)) {
+        // fresh RecordStoreState for the new epoch (node.rs:331-348, record_store.rs:169-198)
+        nfs(node, NF_EPOCH, (u32)new_epoch);
+        nfs(node, NF_INIT_STATE_BLK, y);
+        nfs(node, NF_PROPOSED_BLK, 0);
+        nfs(node, NF_HQC_ROUND, 0); nfs(node, NF_HQC_BLK, 0); nfs(node, NF_HTC_ROUND, 0);
+        nfs(node, NF_CUR_ROUND, 1); nfs(node, NF_HC_ROUND, 0); nfs(node, NF_HCC_BLK, 0);
+        nfs(node, NF_TC_MASK, 0); nfs(node, NF_TO_MASK, 0); nfs(node, NF_TO_WEIGHT, 0);
+        nfs(node, NF_ELECTION, 0);
+        clear_ballot(node);
+        nfs(node, NF_LVR, 0); nfs(node, NF_LOCKED, 0);
+        break;
+      }
+    }
+  }
+
+  // ---- NodeState::update_node (node.rs:240-304) ----
+  LBFT_HD Actions update_node(u32 node, i64 lclock) {
+    i64 lqat = (i64)(i32)nf(node, NF_LQAT);
+    PmActions pa = update_pacemaker(node, lqat, lclock);
+    Actions act;
+    act.next = pa.next; act.send_to = pa.send_to; act.broadcast = pa.broadcast; act.query_all = pa.query_all;
+    // process_pacemaker_actions (node.rs:179-202)
+    if (pa.create_timeout) {
+      insert_timeout(node, node, pa.timeout_round, nf(node, NF_HQC_ROUND));  // create_timeout record_store.rs:636-649
+      u32 lvr = nf(node, NF_LVR);
+      if (pa.timeout_round > lvr) nfs(node, NF_LVR, pa.timeout_round);
+    }
+    if (pa.propose) propose_block(node, pa.propose_prev, lclock);
+    // vote
+    u32 pb = proposed_block(node);
+    if (pb) {
+      u32 br = blk_round(pb);
+      u32 p = blk_prev(pb);
+      u32 prev_round = p ? blk_round(p) : 0;  // previous_round (record_store.rs:588-598)
+      u32 locked = nf(node, NF_LOCKED);
+      if (br > nf(node, NF_LVR) && prev_round >= locked) {
+        nfs(node, NF_LVR, br);
+        u32 pp = p ? blk_prev(p) : 0;
+        u32 second_prev = pp ? blk_round(pp) : 0;  // second_previous_round (record_store.rs:600-609)
+        if (second_prev > locked) nfs(node, NF_LOCKED, second_prev);
+        if (create_vote(node, pb)) act.send_to = (i32)blk_author(pb);
+      }
+    }
+    if (check_for_new_qc(node)) { act.broadcast = true; act.next = lclock; }
+    process_commits(node);
+    bool tq; i64 tnext;
+    update_tracker(node, lqat, lclock, tq, tnext);
+    act.query_all = act.query_all || tq;
+    if (tnext < act.next) act.next = tnext;
+    if (act.query_all) nfs(node, NF_LQAT, (u32)(i32)lclock);
+    return act;
+  }
+
+  // ---- DataSyncNode::create_notification (data_sync.rs:82-111) into snapshot slot ----
+  LBFT_HD void write_snapshot(u32 node, u32 slot) const {
+    st(sfw(slot, S_EPOCH), nf(node, NF_EPOCH));
+    // highest_commit_certificate: Q2 makes the previous-epoch lookup return None (base_types.rs:31-37)
+    st(sfw(slot, S_CERTS), nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16));
+    u32 pb = proposed_block(node);
+    if (pb && blk_author(pb) != node) pb = 0;  // "Do not reshare other leaders' proposals."
+    u32 a0 = nf(node, NF_BAL0_AUTHORS), a1 = nf(node, NF_BAL1_AUTHORS);
+    u32 vote = 0;  // current_vote(local author) (record_store.rs:762-764)
+    if ((a0 >> node) & 1u) vote = nf(node, NF_BAL0_BLK);
+    else if ((a1 >> node) & 1u) vote = nf(node, NF_BAL1_BLK);
+    st(sfw(slot, S_PROP_VOTE), pb | (vote << 16));
+    u32 htc = nf(node, NF_HTC_ROUND);
+    u32 tcm = htc ? nf(node, NF_TC_MASK) : 0;
+    u32 tom = nf(node, NF_TO_MASK);
+    st(sfw(slot, S_TC_ROUND), htc);
+    st(sfw(slot, S_TO_ROUND), nf(node, NF_CUR_ROUND));
+    st(sfw(slot, S_TC_MASK), tcm);
+    st(sfw(slot, S_TO_MASK), tom);
+    for (u32 m = tcm; m;) { u32 a = ctz32(m); m &= m - 1; st(sfw(slot, S_FIXED_WORDS + a), nf(node, NF_FIXED_WORDS + a)); }
+    for (u32 m = tom; m;) { u32 a = ctz32(m); m &= m - 1; st(sfw(slot, S_FIXED_WORDS + P.n + a), nf(node, NF_FIXED_WORDS + P.n + a)); }
+  }
+
+  // ---- DataSyncNode::handle_notification (data_sync.rs:113-177); returns should_sync ----
+  LBFT_HD bool handle_notification(u32 node, u32 sender, u32 slot) {
+    u32 epoch = nf(node, NF_EPOCH);
+    u32 n_epoch = ld(sfw(slot, S_EPOCH));
+    bool should_sync = n_epoch > epoch;
+    u32 certs = ld(sfw(slot, S_CERTS));
+    u32 hcc = certs & 0xffffu, hqc = certs >> 16;
+    if (hcc) {
+      u32 qe = bf(hcc, B_EPOCH);
+      if (qe == epoch) insert_qc(node, hcc);
+      should_sync |= (qe > epoch) || (qe == epoch && blk_round(hcc) > nf(node, NF_HC_ROUND) + 2);
+    }
+    if (hqc) {
+      u32 qe = bf(hqc, B_EPOCH);
+      if (qe == epoch) insert_qc(node, hqc);
+      should_sync |= (qe > epoch) || (qe == epoch && blk_round(hqc) > nf(node, NF_HQC_ROUND));
+    }
+    if (n_epoch == epoch) {
+      u32 pv = ld(sfw(slot, S_PROP_VOTE));
+      u32 pb = pv & 0xffffu, vote = pv >> 16;
+      if (pb) insert_block(node, pb);
+      u32 tc_round = ld(sfw(slot, S_TC_ROUND)), to_round = ld(sfw(slot, S_TO_ROUND));
+      for (u32 m = ld(sfw(slot, S_TC_MASK)); m;) {
+        u32 a = ctz32(m); m &= m - 1;
+        insert_timeout(node, a, tc_round, ld(sfw(slot, S_FIXED_WORDS + a)));
+      }
+      for (u32 m = ld(sfw(slot, S_TO_MASK)); m;) {
+        u32 a = ctz32(m); m &= m - 1;
+        insert_timeout(node, a, to_round, ld(sfw(slot, S_FIXED_WORDS + P.n + a)));
+      }
+      if (vote) insert_vote(node, sender, vote);
+    }
+    return should_sync;
+  }
+
+  // ---- SimulatedNode::update (simulator.rs:176-179) ----
+  LBFT_HD Actions node_update(u32 node) { return update_node(node, (i64)clock - (i64)(i32)nf(node, NF_STARTUP)); }
+
+  // ---- Simulator::process_node_actions (simulator.rs:296-378) ----
+  LBFT_HD void process_node_actions(u32 node, const Actions& act) {
+    i64 startup = (i64)(i32)nf(node, NF_STARTUP);
+    i64 t_new = (i64)((u64)act.next + (u64)startup);
+    if (t_new < (i64)clock + 1) t_new = (i64)clock + 1;
+    i64 ign = t_new - 1;
+    if (ign > (i64)P.max_clock) ign = P.max_clock;  // only ever compared with clock <= max_clock
+    nfs(node, NF_IGNORE_UNTIL, (u32)(i32)ign);
+    push_event(t_new, 3, node, 0, 0);
+    // receivers, packed 4 bits each (n <= 16) or walked directly
+    u32 list[LBFT_MAX_NODES];
+    u32 cnt = 0;
+    if (act.broadcast) { for (u32 i = 0; i < P.n; i++) if (i != node) list[cnt++] = i; }
+    else if (act.send_to >= 0 && (u32)act.send_to != node) list[cnt++] = (u32)act.send_to;
+    for (u32 i = cnt; i-- > 1;) {  // SliceRandom::shuffle
+      u32 j = rng.gen_range_u32(i + 1);
+      u32 t = list[i]; list[i] = list[j]; list[j] = t;
+    }
+    i32 slot = -1;
+    u32 refs = 0;
+    for (u32 i = 0; i < cnt; i++) {
+      i64 t = (i64)clock + sample_delay();
+      if (t <= (i64)P.max_clock && slot == -1) {
+        slot = snap_alloc();
+        if (slot < 0) slot = -2; else write_snapshot(node, (u32)slot);
+      }
+      if (slot >= 0) { if (push_event(t, 0, list[i], node, (u32)slot)) refs++; }
+      else stamp++;  // dropped event still consumes a creation stamp
+    }
+    if (slot >= 0) {
+      if (refs) st(P.off_snap_ref + (u32)slot, refs);
+      else { st(P.off_snap_free + snap_free, (u32)slot); snap_free++; }
+    }
+    if (act.query_all) {
+      cnt = 0;
+      for (u32 i = 0; i < P.n; i++) if (i != node) list[cnt++] = i;
+      for (u32 i = cnt; i-- > 1;) {
+        u32 j = rng.gen_range_u32(i + 1);
+        u32 t = list[i]; list[i] = list[j]; list[j] = t;
+      }
+      for (u32 i = 0; i < cnt; i++) {
+        i64 t = (i64)clock + sample_delay();
+        push_event(t, 1, node, list[i], 0);
+      }
+    }
+  }
+
+  // ---- Simulator::new (simulator.rs:200-250) + NodeState::make_initial_state (node.rs:87-114) ----
+  LBFT_HD void init(u64 seed) {
+    for (u32 w = 0; w < I_WORDS; w++) st(w, 0);
+    clock = 0; stamp = 0; qlen = 0; nblocks = 0; fault = 0; maxq = 0; maxsnap = 0;
+    ev0 = ev1 = ev2 = ev3 = 0;
+    snap_free = P.scap;
+    for (u32 s = 0; s < P.scap; s++) { st(P.off_snap_free + s, P.scap - 1 - s); st(P.off_snap_ref + s, 0); }
+    rng.seed(seed);
+    for (u32 node = 0; node < P.n; node++) {
+      for (u32 f = 0; f < P.node_words; f++) nfs(node, f, 0);
+      nfs(node, NF_CUR_ROUND, 1);
+      nfs(node, NF_PM_LEADER, LBFT_NO_LEADER);
+      i64 startup = 0 + sample_delay() + 1;
+      if (startup > (i64)P.max_clock + 1) startup = (i64)P.max_clock + 1;  // node never starts; equivalent
+      nfs(node, NF_STARTUP, (u32)(i32)startup);
+      nfs(node, NF_IGNORE_UNTIL, (u32)(i32)(startup - 1));
+      push_event(startup, 3, node, 0, 0);
+    }
+    store_scalars(false);
+  }
+
+  // ---- Simulator::loop_until (simulator.rs:380-475); returns true when the queue drained ----
+  LBFT_HD bool run() {
+    u32 steps = 0;
+    for (;;) {
+      if (P.max_steps && steps >= P.max_steps) return false;
+      i32 t; u32 kind, meta;
+      if (!pop_event(t, kind, meta)) return true;
+      steps++;
+      if (t > clock) clock = t;
+      u32 node = meta & 0xffu, sender = (meta >> 8) & 0xffu, slot = meta >> 16;
+      // One shared call site for update_node + process_node_actions: lanes of a wavefront that
+      // handle different event kinds reconverge here instead of running three inlined copies.
+      bool do_update = true, sync = false;
+      if (kind == 3) {  // UpdateTimerEvent (simulator.rs:403-415)
+        ev3++;
+        if (clock <= (i32)nf(node, NF_IGNORE_UNTIL)) do_update = false;  // cancelled timer
+      } else if (kind == 0) {  // DataSyncNotifyEvent (simulator.rs:416-440)
+        ev0++;
+        sync = handle_notification(node, sender, slot);
+        snap_release(slot);
+      } else if (kind == 1) {  // DataSyncRequestEvent (simulator.rs:441-453)
+        ev1++;
+        // Q1: answered by the requester itself; the response carries nothing insertable
+        push_event((i64)clock + sample_delay(), 2, node, sender, 0);
+        do_update = false;
+      } else {  // DataSyncResponseEvent (simulator.rs:454-466): handle_response inserts nothing (Q1)
+        ev2++;
+      }
+      if (do_update) {
+        Actions a = node_update(node);
+        if (sync) push_event((i64)clock + sample_delay(), 1, node, sender, 0);
+        process_node_actions(node, a);
+      }
+    }
+  }
+};
+
+// Row layout for a batch; fills the offset fields of `p` and returns words per instance.
+inline u32 compute_layout(Params& p) {
+  u32 w = I_WORDS;
+  p.off_node = w; p.node_words = NF_FIXED_WORDS + 2 * p.n; w += p.n * p.node_words;
+  p.off_qhi = w; w += p.qcap;
+  p.off_qlo = w; w += p.qcap;
+  p.off_qmeta = w; w += p.qcap;
+  p.snap_words = S_FIXED_WORDS + 2 * p.n;
+  p.off_snap = w; w += p.scap * p.snap_words;
+  p.off_snap_ref = w; w += p.scap;
+  p.off_snap_free = w; w += p.scap;
+  p.blk_words = B_WORDS;
+  p.off_blk = w; w += p.bcap * p.blk_words;
+  p.off_log = w; w += p.n * p.lcap;
+  p.total_words = w;
+  return w;
+}
+
+}  // namespace lbft
+
+#endif  // LBFT_CORE_H

@@ -1,0 +1,117 @@
+// host_model.cpp -- TEST INFRASTRUCTURE: compiles the kernel logic (librabft_simulator_amd/csrc/lbft_core.h)
+// for the host so that the compact structural model the HIP kernels execute can be differential-tested
+// against the full-fidelity oracle on CPU-only machines (tests/test_host_model.py).  It is never linked
+// into the product library and never used as a fallback.
+#include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../librabft_simulator_amd/csrc/lbft_core.h"
+#include "../librabft_simulator_amd/csrc/lbft_tables.h"
+#include "lbft_oracle.h"
+
+using namespace lbft;
+
+static const u64 ZX[257] = LBFT_ZIG_NORM_X_BITS_INIT;
+static const u64 ZF[257] = LBFT_ZIG_NORM_F_BITS_INIT;
+static const u64 ET[256] = LBFT_EXP_TAB_INIT;
+
+extern "C" {
+
+typedef struct lbft_hostmodel_caps {
+  uint32_t qcap, scap, bcap, lcap;
+} lbft_hostmodel_caps;
+
+// Same outputs as lbft_oracle_run_batch, plus per-instance fault words and max queue/snapshot use.
+int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel_caps* caps, const uint64_t* seeds,
+                             size_t n_instances, int64_t max_clock, uint32_t threads, uint32_t* commit_counts,
+                             uint64_t* active_rounds, uint64_t* last_states, lbft_oracle_commit* histories,
+                             size_t history_cap, lbft_oracle_counters* counters, uint32_t* faults,
+                             uint32_t* maxq_out, uint32_t* maxsnap_out) {
+  if (cfg->quirks != 0 || cfg->num_nodes > LBFT_MAX_NODES) return -10;
+  Params p;
+  memset(&p, 0, sizeof(p));
+  p.n = cfg->num_nodes;
+  p.m = (u32)n_instances;
+  p.stride = (u32)n_instances;
+  p.qcap = caps->qcap; p.scap = caps->scap; p.bcap = caps->bcap; p.lcap = caps->lcap;
+  p.max_clock = (i32)max_clock;
+  p.delay_model = cfg->delay_model;
+  p.mu = std::log(cfg->mean / std::sqrt(1.0 + cfg->variance / (cfg->mean * cfg->mean)));
+  p.sigma = std::sqrt(std::log(1.0 + cfg->variance / (cfg->mean * cfg->mean)));
+  p.uni_lo = cfg->uniform_lo;
+  p.uni_span = (u64)(cfg->uniform_hi - cfg->uniform_lo) + 1;
+  p.cpe = cfg->commands_per_epoch;
+  p.tci = cfg->target_commit_interval;
+  p.lambda = cfg->lambda;
+  p.total_votes = 0;
+  for (u32 i = 0; i < p.n; i++) { p.weights[i] = cfg->voting_rights ? (u32)cfg->voting_rights[i] : 1; p.total_votes += p.weights[i]; }
+  p.quorum = 2 * p.total_votes / 3 + 1;
+  std::vector<i64> dur(4096);
+  for (size_t k = 0; k < dur.size(); k++) dur[k] = f64_to_i64_sat((double)cfg->delta * std::pow((double)k, cfg->gamma));
+  std::vector<u8> leaders(4096);
+  for (size_t r = 0; r < leaders.size(); r++) leaders[r] = (u8)compute_leader(p.weights, p.n, p.total_votes, r);
+  p.dur_tab = dur.data(); p.dur_len = (u32)dur.size();
+  p.leader_tab = leaders.data(); p.leader_len = (u32)leaders.size();
+  p.exp_tab = ET; p.zig_x = ZX; p.zig_f = ZF;
+  compute_layout(p);
+  std::vector<u32> state((size_t)p.total_words * p.stride, 0);
+
+  if (threads == 0) threads = 1;
+  auto worker = [&](u32 tid) {
+    for (size_t i = tid; i < n_instances; i += threads) {
+      Sim s(p, state.data() + i);
+      s.init(seeds[i]);
+      s.load_scalars();
+      bool done = s.run();
+      s.store_scalars(done);
+    }
+  };
+  std::vector<std::thread> ts;
+  for (u32 t = 1; t < threads; t++) ts.emplace_back(worker, t);
+  worker(0);
+  for (auto& t : ts) t.join();
+
+  if (counters) memset(counters, 0, sizeof(*counters));
+  int rc = 0;
+  for (size_t i = 0; i < n_instances; i++) {
+    Sim s(p, state.data() + i);
+    s.load_scalars();
+    if (faults) faults[i] = s.fault;
+    if (s.fault) rc = 1;
+    if (maxq_out) maxq_out[i] = s.maxq;
+    if (maxsnap_out) maxsnap_out[i] = s.maxsnap;
+    u64 min_round = UINT64_MAX, min_commits = UINT64_MAX;
+    for (u32 n = 0; n < p.n; n++) {
+      size_t o = i * p.n + n;
+      u32 nc = s.nf(n, NF_NCOMMITS);
+      u64 ar = s.nf(n, NF_PM_ROUND);
+      if (commit_counts) commit_counts[o] = nc;
+      if (active_rounds) active_rounds[o] = ar;
+      min_round = ar < min_round ? ar : min_round;
+      min_commits = nc < min_commits ? nc : min_commits;
+      Sip13 h;
+      h.init();
+      h.word(nc);
+      for (u32 k = 0; k < nc; k++) {
+        u32 b = s.ld(p.off_log + n * p.lcap + k);
+        u64 proposer = s.blk_author(b), index = s.bf(b, B_CMD);
+        i64 time = (i64)(i32)s.bf(b, B_TIME);
+        h.word(proposer); h.word(index); h.word((u64)time);
+        if (histories && k < history_cap) histories[o * history_cap + k] = lbft_oracle_commit{proposer, index, time};
+      }
+      if (last_states) last_states[o] = h.finish();
+    }
+    if (counters) {
+      counters->events[0] += s.ev0; counters->events[1] += s.ev1; counters->events[2] += s.ev2; counters->events[3] += s.ev3;
+      counters->rng_draws += s.rng.draws;
+      counters->rounds += min_round; counters->commits += min_commits;
+      counters->events_scheduled += s.stamp;
+      if (s.maxq > counters->max_queue) counters->max_queue = s.maxq;
+    }
+  }
+  return rc;
+}
+
+}  // extern "C"

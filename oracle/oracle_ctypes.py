@@ -222,3 +222,52 @@ def leader(num_nodes, rnd, weights=None):
     if weights is not None:
         w = np.ascontiguousarray(weights, dtype=np.uint64)
     return lib().lbft_oracle_leader(w.ctypes.data if w is not None else None, num_nodes, rnd)
+
+
+# ----------------------------------------------------------------------------------------------
+# Host build of the kernel logic (oracle/host_model.cpp) -- CPU-only differential testing.
+# ----------------------------------------------------------------------------------------------
+class HostModelCaps(C.Structure):
+    _fields_ = [("qcap", C.c_uint32), ("scap", C.c_uint32), ("bcap", C.c_uint32), ("lcap", C.c_uint32)]
+
+
+_hm = None
+
+
+def hostmodel_lib():
+    global _hm
+    if _hm is None:
+        build()
+        path = os.path.join(_HERE, "liblbft_hostmodel.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-C", _HERE, "-s"])
+        L = C.CDLL(path)
+        vp = C.c_void_p
+        L.lbft_hostmodel_run_batch.argtypes = [
+            C.POINTER(OracleConfig), C.POINTER(HostModelCaps), vp, C.c_size_t, C.c_int64, C.c_uint32, vp, vp, vp,
+            vp, C.c_size_t, C.POINTER(OracleCounters), vp, vp, vp]
+        L.lbft_hostmodel_run_batch.restype = C.c_int
+        _hm = L
+    return _hm
+
+
+def hostmodel_run_batch(cfg, seeds, max_clock, threads=1, history_cap=0, qcap=256, scap=128, bcap=256, lcap=256):
+    seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+    m, nn = len(seeds), cfg.num_nodes
+    caps = HostModelCaps(qcap, scap, bcap, lcap)
+    commit_counts = np.zeros((m, nn), dtype=np.uint32)
+    active_rounds = np.zeros((m, nn), dtype=np.uint64)
+    last_states = np.zeros((m, nn), dtype=np.uint64)
+    hist = np.zeros((m, nn, history_cap), dtype=COMMIT_DTYPE) if history_cap else None
+    faults = np.zeros(m, dtype=np.uint32)
+    maxq = np.zeros(m, dtype=np.uint32)
+    maxsnap = np.zeros(m, dtype=np.uint32)
+    ctr = OracleCounters()
+    rc = hostmodel_lib().lbft_hostmodel_run_batch(
+        C.byref(cfg), C.byref(caps), seeds.ctypes.data, m, max_clock, threads, commit_counts.ctypes.data,
+        active_rounds.ctypes.data, last_states.ctypes.data, hist.ctypes.data if hist is not None else None,
+        history_cap, C.byref(ctr), faults.ctypes.data, maxq.ctypes.data, maxsnap.ctypes.data)
+    if rc < 0:
+        raise RuntimeError("host model failed: %d" % rc)
+    return {"commit_counts": commit_counts, "active_rounds": active_rounds, "last_states": last_states,
+            "histories": hist, "counters": ctr.as_dict(), "faults": faults, "maxq": maxq, "maxsnap": maxsnap}
