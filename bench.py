@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""Headline benchmark: simulated consensus rounds/sec on 65 536 x 4-node LibraBFTv2 instances per GPU.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched with
+torch.distributed.run, one rank per GPU (RCCL).  A "step" is one pass of the hot path over one batch of
+synthetic input: Simulator::new + loop_until(max_clock) for every instance of the batch (seeds already
+resident in HBM), including the device-side reduction and the D2H copy of the counters.  Rank 0 prints
+ONE JSON line.  Instances shard across ranks with no data-path collective (weak scaling: 65 536 instances
+per GPU); one all-reduce aggregates the throughput counters.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--instances", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--nodes", type=int, default=4)
+    ap.add_argument("--max-clock", type=int, default=1000)
+    ap.add_argument("--base-seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the oracle sample")
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_event(nodes, counters):
+    """SURVEY.md 8(d) with this build's struct sizes (DESIGN.md "Algorithmic bytes"):
+    2*S_node + S_evt*(1 + p) + S_notif*(w + r)."""
+    ev = sum(counters["events"])
+    s_node = (36 + 2 * nodes) * 4   # NF_FIXED_WORDS + tc_hcbr[n] + to_hcbr[n], 4-byte rows
+    s_evt = 12                      # key hi, key lo, meta
+    s_notif = (7 + 2 * nodes) * 4   # S_FIXED_WORDS + hcbr arrays
+    p = counters["events_scheduled"] / max(ev, 1)
+    r = counters["events"][0] / max(ev, 1)
+    return 2 * s_node + s_evt * (1 + p) + s_notif * (r + r)
+
+
+def cpu_baseline(args, nodes, max_clock):
+    """The CPU oracle ("port": C++ restatement of the reference, not the Rust binary) on the host cores,
+    bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle_ctypes as oc
+    cores = os.cpu_count() or 1
+    cfg = oc.make_config(num_nodes=nodes, math_mode=1)
+    probe = 8 * cores
+    t0 = time.perf_counter()
+    oc.run_batch(cfg, np.arange(args.base_seed, args.base_seed + probe, dtype=np.uint64), max_clock, threads=cores)
+    dt = max(time.perf_counter() - t0, 1e-3)
+    m = int(min(max(probe, probe * args.cpu_seconds / dt), 65536))
+    seeds = np.arange(args.base_seed, args.base_seed + m, dtype=np.uint64)
+    t0 = time.perf_counter()
+    r = oc.run_batch(cfg, seeds, max_clock, threads=cores)
+    dt = time.perf_counter() - t0
+    c = r["counters"]
+    return {
+        "value": c["rounds"] / dt, "unit": "rounds/s", "cores": cores, "kind": "port",
+        "sample": "%d instances x %d nodes, LogNormal(10,4), max_clock %d, %d host threads, %.1f s" % (m, nodes, max_clock, cores, dt),
+        "events_per_s": sum(c["events"]) / dt, "commits_per_s": c["commits"] / dt,
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from librabft_simulator_amd import BatchSimulator, NodeConfig, RandomDelay
+    m = args.instances
+    first = args.base_seed + rank * m  # seed_i = base_seed + global instance index
+    seeds = np.arange(first, first + m, dtype=np.uint64)
+    sim = BatchSimulator.new(seeds, args.nodes, RandomDelay.new(10.0, 4.0), NodeConfig(), device=local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        sim.reset()
+        res = sim.loop_until(args.max_clock)
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.reset()
+        res = sim.loop_until(args.max_clock)
+        kernel_ms.append(sim.last_run_ms()[1])  # hipEvents around the run kernel on the batch's own stream
+    barrier()
+    elapsed = time.perf_counter() - t0
+    c = res.counters
+    local = torch.tensor([c["rounds"], c["commits"], sum(c["events"]), c["faulted_instances"]], dtype=torch.float64,
+                         device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(local, op=dist.ReduceOp.SUM)  # the single collective of the run: throughput counters
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    rounds, commits, events, faulted = [float(v) for v in local.tolist()]
+    elapsed = float(tmax.item())
+    if rank == 0:
+        per_step = elapsed / args.steps
+        k_ms = float(np.mean(kernel_ms))
+        bpe = algorithmic_bytes_per_event(args.nodes, c)
+        local_events = sum(c["events"])
+        achieved = local_events * bpe / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "simulated consensus rounds/sec (whole node), 65 536 x 4-node instances per GPU",
+            "value": rounds / per_step, "unit": "rounds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32/u64 + f64 delay sampling", "data": "synthetic",
+            "config": {"workload": "%d instances x %d nodes (f=1) per GPU, LogNormal(mean 10, variance 4) delays, max_clock %d, "
+                                   "delta 20 gamma 2 lambda 0.5, seeds base+i; reference quirks Q1-Q6" % (m, args.nodes, args.max_clock),
+                       "instances_per_gpu": m, "nodes": args.nodes, "max_clock": args.max_clock, "parallelism": "instances sharded, %d ranks" % world},
+            "committed_blocks_per_s": commits / per_step, "events_per_s": events / per_step,
+            "faulted_instances": faulted,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "lbft_k_run", "kernel_ms": k_ms, "algorithmic_bytes_per_event": bpe,
+                         "events_per_launch": local_events},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args, args.nodes, args.max_clock)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

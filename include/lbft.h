@@ -1,0 +1,148 @@
+/* lbft.h -- C ABI of the MI355X-native batched LibraBFTv2 discrete-event simulator (liblbft_hip.so).
+ *
+ * Drop-in boundary for the simulation hot path of novifinancial/librabft_simulator.  Each entry point
+ * names the reference interface it replaces (paths relative to the reference repository).  All
+ * functions are synchronous, return 0 (LBFT_OK) or a negative LBFT_ERR_* code, never abort the
+ * process and never call back into the caller.  A batch handle owns all of its host and device memory
+ * and is not thread-safe (one host thread per GPU/batch, as the reference is single-threaded).
+ *
+ * There is no CPU fallback: every function that needs the GPU fails with LBFT_ERR_HIP when no
+ * gfx950 device is usable.
+ */
+#ifndef LBFT_H
+#define LBFT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LBFT_OK 0
+#define LBFT_ERR_INVALID (-1)     /* bad argument (NULL pointer, num_nodes out of range, max_clock >= 2^31-1, ...) */
+#define LBFT_ERR_HIP (-2)         /* HIP runtime error / no device; see lbft_last_error() */
+#define LBFT_ERR_UNSUPPORTED (-3) /* quirks != 0 or num_nodes > LBFT_MAX_NODES_SUPPORTED on this kernel family */
+#define LBFT_ERR_STATE (-4)       /* call order violated (e.g. results requested before lbft_batch_run_until) */
+#define LBFT_ERR_FAULT (-5)       /* the run finished but >= 1 instance raised a sticky fault (capacity overflow or an
+                                     invariant on which the reference itself would have panicked); see lbft_batch_faults */
+
+#define LBFT_MAX_NODES_SUPPORTED 32
+
+/* Per-instance sticky fault bits (lbft_batch_faults). */
+#define LBFT_FAULT_QUEUE_OVERFLOW (1u << 0)
+#define LBFT_FAULT_SNAPSHOT_OVERFLOW (1u << 1)
+#define LBFT_FAULT_BLOCK_OVERFLOW (1u << 2)
+#define LBFT_FAULT_LOG_OVERFLOW (1u << 3)
+#define LBFT_FAULT_BALLOT_OVERFLOW (1u << 4)
+#define LBFT_FAULT_DURATION_TABLE (1u << 5)
+#define LBFT_FAULT_COMMIT_UNKNOWN_STATE (1u << 6) /* simulated_context.rs:163-166 would panic */
+#define LBFT_FAULT_COMMIT_NOT_SUCCESSOR (1u << 7) /* simulated_context.rs:172-174 would panic */
+#define LBFT_FAULT_STAMP_OVERFLOW (1u << 8)
+#define LBFT_FAULT_INTERNAL (1u << 9)
+
+/* Simulation parameters: the arguments of Simulator::new (bft-lib/src/simulator.rs:200-208),
+ * RandomDelay::new (:99-106), SimulatedContext::new (bft-lib/src/simulated_context.rs:86-96) and
+ * NodeConfig (librabft-v2/src/node.rs:76-81), i.e. the CLI flags of librabft-v2/src/main.rs:73-140. */
+typedef struct lbft_config {
+  uint32_t num_nodes;             /* --nodes */
+  uint32_t delay_model;           /* 0: LogNormal(mean, variance) as the reference; 1: uniform integer in [uniform_lo, uniform_hi] (extension) */
+  double mean;                    /* --mean */
+  double variance;                /* --variance */
+  int64_t uniform_lo, uniform_hi; /* delay_model 1 only */
+  uint64_t commands_per_epoch;    /* --commands_per_epoch */
+  int64_t target_commit_interval; /* --target_commit_interval */
+  int64_t delta;                  /* --delta */
+  double gamma;                   /* --gamma */
+  double lambda;                  /* --lambda */
+  uint32_t quirks;                /* must be 0: reference semantics incl. quirks Q1/Q2 */
+  uint32_t reserved;
+  const uint64_t* voting_rights;  /* NULL: every node has weight 1 (simulated_context.rs:209-216); else num_nodes weights */
+  /* Capacities of the per-instance device structures; 0 = choose from num_nodes / max_clock. */
+  uint32_t queue_capacity;    /* pending events with time <= max_clock */
+  uint32_t snapshot_capacity; /* notifications in flight */
+  uint32_t block_capacity;    /* blocks proposed per instance (<= 65534) */
+  uint32_t log_capacity;      /* commits per node */
+} lbft_config;
+
+/* One entry of SimulatedContext::committed_history() (simulated_context.rs:31-35,98-100). */
+typedef struct lbft_commit {
+  uint64_t proposer; /* Command.proposer = Author(usize) */
+  uint64_t index;    /* Command.index */
+  int64_t time;      /* NodeTime chosen by the proposer */
+} lbft_commit;
+
+/* Aggregate counters of a finished run (sums over the instances of the batch). */
+typedef struct lbft_counters {
+  uint64_t events[4];         /* processed events by Event::kind (simulator.rs:129-139): notify, request, response, timer */
+  uint64_t rng_draws;         /* next_u64 calls on the simulators' RNGs */
+  uint64_t rounds;            /* sum over instances of min over nodes of pacemaker.active_round */
+  uint64_t commits;           /* sum over instances of min over nodes of committed_history().len() */
+  uint64_t events_scheduled;  /* creation stamps handed out (simulator.rs:252-264) */
+  uint64_t faulted_instances; /* instances with a non-zero fault word */
+  uint64_t max_queue;         /* max over instances of the event-queue high-water mark */
+  uint64_t max_snapshots;     /* max over instances of live notification snapshots */
+  uint64_t max_blocks;        /* max over instances of proposed blocks */
+  uint64_t launches;          /* run-kernel launches of the last run */
+} lbft_counters;
+
+typedef struct lbft_batch lbft_batch;
+
+/* Builds n_instances independent simulators, instance i seeded with seeds[i]
+ * (replaces n_instances calls of Simulator::new, bft-lib/src/simulator.rs:200-250, with the context
+ * factory of librabft-v2/src/main.rs:23-34).  `device` is the HIP device ordinal.  Seeds are copied to
+ * the device here; nothing else crosses PCIe until results are read back. */
+int lbft_batch_create(const lbft_config* cfg, const uint64_t* seeds, size_t n_instances, int device, lbft_batch** out);
+
+/* Simulator::loop_until(GlobalTime(max_clock), None) for every instance (simulator.rs:380-475), including
+ * the initial scheduling done by Simulator::new.  0 <= max_clock < 2^31 - 1.  May be called again after
+ * lbft_batch_reset.  Returns LBFT_ERR_FAULT if any instance faulted (results of the others are valid). */
+int lbft_batch_run_until(lbft_batch* b, int64_t max_clock);
+
+/* Forgets the results so that lbft_batch_run_until can run the same seeds again (benchmarking). */
+int lbft_batch_reset(lbft_batch* b);
+
+/* contexts.iter().map(|c| c.committed_history().len()) (librabft-v2/src/main.rs:47-53): out[inst * num_nodes + node]. */
+int lbft_batch_commit_counts(const lbft_batch* b, uint32_t* out);
+/* ActiveRound::active_round per node (simulator.rs:86-88, node.rs:170-175): out[inst * num_nodes + node]. */
+int lbft_batch_active_rounds(const lbft_batch* b, uint64_t* out);
+/* SimulatedContext::committed_history() of one node (simulated_context.rs:98-100); copies min(cap, *len) entries. */
+int lbft_batch_committed_history(const lbft_batch* b, size_t inst, uint32_t node, lbft_commit* out, size_t cap, size_t* len);
+/* All histories: out[(inst * num_nodes + node) * cap_per_node + k], first min(len, cap_per_node) entries each. */
+int lbft_batch_committed_histories(const lbft_batch* b, lbft_commit* out, size_t cap_per_node);
+/* StateFinalizer::last_committed_state() (simulated_context.rs:194-196; State = SipHash-1-3 of the
+ * history, :51-55), computed on the device: out[inst * num_nodes + node]. */
+int lbft_batch_last_committed_states(const lbft_batch* b, uint64_t* out);
+/* SimulatedNode::startup_time (simulator.rs:55,217): out[inst * num_nodes + node]. */
+int lbft_batch_startup_times(const lbft_batch* b, int64_t* out);
+/* Current epoch of each node (librabft-v2/src/node.rs:34): out[inst * num_nodes + node]. */
+int lbft_batch_epochs(const lbft_batch* b, uint64_t* out);
+int lbft_batch_counters(const lbft_batch* b, lbft_counters* out);
+/* out[inst] = sticky fault bits. */
+int lbft_batch_faults(const lbft_batch* b, uint32_t* out);
+void lbft_batch_destroy(lbft_batch* b);
+
+/* Measurement hooks (bench.py): the HIP stream all kernels of this batch are launched on, the kernel
+ * time of the last lbft_batch_run_until measured with hipEvents on that stream, and the HBM footprint. */
+void* lbft_batch_stream(const lbft_batch* b);
+int lbft_batch_last_run_ms(const lbft_batch* b, float* init_ms, float* run_ms);
+size_t lbft_batch_device_bytes(const lbft_batch* b);
+/* Events processed per run-kernel launch (0 = whole simulation in one launch). */
+int lbft_batch_set_max_steps(lbft_batch* b, uint32_t max_steps);
+
+/* Stand-alone device checks of the third-party arithmetic (tests): each runs a tiny kernel.
+ *   leaders: out[r] = PacemakerState::leader(round r) (pacemaker.rs:100-109) for r < n_rounds
+ *   delays:  n samples of RandomDelay (simulator.rs:110-118) from Xoshiro256**(seed)
+ *   exp/log: lbft_math.h on the device, bit patterns in/out */
+int lbft_device_leaders(int device, const uint64_t* voting_rights, uint32_t num_nodes, uint8_t* out, uint32_t n_rounds);
+int lbft_device_sample_delays(int device, const lbft_config* cfg, uint64_t seed, int64_t* out, size_t n);
+int lbft_device_exp_log(int device, const double* x, double* exp_out, double* log_out, size_t n);
+
+const char* lbft_last_error(void);
+/* "gfx950" build tag and ABI version. */
+const char* lbft_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LBFT_H */

@@ -1,0 +1,143 @@
+"""ctypes binding of include/lbft.h (liblbft_hip.so).  Fails loudly when the HIP library is missing:
+there is no CPU fallback in this package."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liblbft_hip.so")
+
+LBFT_OK = 0
+LBFT_ERR_INVALID = -1
+LBFT_ERR_HIP = -2
+LBFT_ERR_UNSUPPORTED = -3
+LBFT_ERR_STATE = -4
+LBFT_ERR_FAULT = -5
+
+FAULT_NAMES = {
+    1 << 0: "queue_overflow", 1 << 1: "snapshot_overflow", 1 << 2: "block_overflow", 1 << 3: "log_overflow",
+    1 << 4: "ballot_overflow", 1 << 5: "duration_table", 1 << 6: "commit_unknown_state",
+    1 << 7: "commit_not_successor", 1 << 8: "stamp_overflow", 1 << 9: "internal",
+}
+
+
+class LbftConfig(C.Structure):
+    _fields_ = [
+        ("num_nodes", C.c_uint32),
+        ("delay_model", C.c_uint32),
+        ("mean", C.c_double),
+        ("variance", C.c_double),
+        ("uniform_lo", C.c_int64),
+        ("uniform_hi", C.c_int64),
+        ("commands_per_epoch", C.c_uint64),
+        ("target_commit_interval", C.c_int64),
+        ("delta", C.c_int64),
+        ("gamma", C.c_double),
+        ("lambda_", C.c_double),
+        ("quirks", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("voting_rights", C.POINTER(C.c_uint64)),
+        ("queue_capacity", C.c_uint32),
+        ("snapshot_capacity", C.c_uint32),
+        ("block_capacity", C.c_uint32),
+        ("log_capacity", C.c_uint32),
+    ]
+
+
+class LbftCounters(C.Structure):
+    _fields_ = [
+        ("events", C.c_uint64 * 4),
+        ("rng_draws", C.c_uint64),
+        ("rounds", C.c_uint64),
+        ("commits", C.c_uint64),
+        ("events_scheduled", C.c_uint64),
+        ("faulted_instances", C.c_uint64),
+        ("max_queue", C.c_uint64),
+        ("max_snapshots", C.c_uint64),
+        ("max_blocks", C.c_uint64),
+        ("launches", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        d = {name: getattr(self, name) for name, _ in self._fields_ if name != "events"}
+        d["events"] = list(self.events)
+        return d
+
+
+COMMIT_DTYPE = np.dtype([("proposer", "<u8"), ("index", "<u8"), ("time", "<i8")])
+
+# every symbol include/lbft.h declares (tests check that the library exports all of them)
+ABI_SYMBOLS = [
+    "lbft_batch_create", "lbft_batch_run_until", "lbft_batch_reset", "lbft_batch_commit_counts",
+    "lbft_batch_active_rounds", "lbft_batch_committed_history", "lbft_batch_committed_histories",
+    "lbft_batch_last_committed_states", "lbft_batch_startup_times", "lbft_batch_epochs", "lbft_batch_counters",
+    "lbft_batch_faults", "lbft_batch_destroy", "lbft_batch_stream", "lbft_batch_last_run_ms",
+    "lbft_batch_device_bytes", "lbft_batch_set_max_steps", "lbft_device_leaders", "lbft_device_sample_delays",
+    "lbft_device_exp_log", "lbft_last_error", "lbft_build_info",
+]
+
+_lib = None
+
+
+class LbftError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lbft error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load liblbft_hip.so (built in-tree by librabft_simulator_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -m librabft_simulator_amd.build` (needs hipcc). "
+            "There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.lbft_batch_create.argtypes = [C.POINTER(LbftConfig), vp, C.c_size_t, C.c_int, C.POINTER(vp)]
+    L.lbft_batch_create.restype = C.c_int
+    L.lbft_batch_run_until.argtypes = [vp, C.c_int64]
+    L.lbft_batch_run_until.restype = C.c_int
+    L.lbft_batch_reset.argtypes = [vp]
+    L.lbft_batch_reset.restype = C.c_int
+    for name in ("commit_counts", "active_rounds", "last_committed_states", "startup_times", "epochs", "faults"):
+        f = getattr(L, "lbft_batch_" + name)
+        f.argtypes = [vp, vp]
+        f.restype = C.c_int
+    L.lbft_batch_committed_history.argtypes = [vp, C.c_size_t, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.lbft_batch_committed_history.restype = C.c_int
+    L.lbft_batch_committed_histories.argtypes = [vp, vp, C.c_size_t]
+    L.lbft_batch_committed_histories.restype = C.c_int
+    L.lbft_batch_counters.argtypes = [vp, C.POINTER(LbftCounters)]
+    L.lbft_batch_counters.restype = C.c_int
+    L.lbft_batch_destroy.argtypes = [vp]
+    L.lbft_batch_destroy.restype = None
+    L.lbft_batch_stream.argtypes = [vp]
+    L.lbft_batch_stream.restype = vp
+    L.lbft_batch_last_run_ms.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.lbft_batch_last_run_ms.restype = C.c_int
+    L.lbft_batch_device_bytes.argtypes = [vp]
+    L.lbft_batch_device_bytes.restype = C.c_size_t
+    L.lbft_batch_set_max_steps.argtypes = [vp, C.c_uint32]
+    L.lbft_batch_set_max_steps.restype = C.c_int
+    L.lbft_device_leaders.argtypes = [C.c_int, vp, C.c_uint32, vp, C.c_uint32]
+    L.lbft_device_leaders.restype = C.c_int
+    L.lbft_device_sample_delays.argtypes = [C.c_int, C.POINTER(LbftConfig), C.c_uint64, vp, C.c_size_t]
+    L.lbft_device_sample_delays.restype = C.c_int
+    L.lbft_device_exp_log.argtypes = [C.c_int, vp, vp, vp, C.c_size_t]
+    L.lbft_device_exp_log.restype = C.c_int
+    L.lbft_last_error.argtypes = []
+    L.lbft_last_error.restype = C.c_char_p
+    L.lbft_build_info.argtypes = []
+    L.lbft_build_info.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc, allow_fault=False):
+    if rc == LBFT_OK or (allow_fault and rc == LBFT_ERR_FAULT):
+        return rc
+    raise LbftError(rc, lib().lbft_last_error().decode(errors="replace"))

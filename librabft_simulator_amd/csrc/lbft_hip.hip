@@ -1,0 +1,581 @@
+// lbft_hip.hip -- HIP kernels (gfx950) and the C ABI of include/lbft.h.
+//
+// Execution model: one lane = one simulated network.  A 64-lane wavefront advances 64 independent
+// discrete-event simulations; all per-instance state is in HBM as word-interleaved rows
+// (state[row * stride + instance]) so that a wavefront reading row r touches one contiguous 256-byte
+// segment.  The simulation step itself is lbft_core.h (device build only in this library).
+// No CPU fallback exists: every entry point fails with LBFT_ERR_HIP if the device is unusable.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lbft.h"
+#include "lbft_core.h"
+#include "lbft_tables.h"
+
+using namespace lbft;
+
+static_assert(LBFT_MAX_NODES == LBFT_MAX_NODES_SUPPORTED, "header mismatch");
+
+// ------------------------------------------------------------------------------------------------
+// Kernels
+// ------------------------------------------------------------------------------------------------
+#define LBFT_BLOCK 64  // one wavefront per workgroup: wavefronts retire independently
+
+// Simulator::new for every instance (simulator.rs:200-250).
+__global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restrict__ state, const u64* __restrict__ seeds) {
+  u32 i = blockIdx.x * LBFT_BLOCK + threadIdx.x;
+  if (i >= p.m) return;
+  Sim s(p, state + i);
+  s.init(seeds[i]);
+}
+
+// Simulator::loop_until for every instance (simulator.rs:380-475).
+__global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_run(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) {
+  u32 i = blockIdx.x * LBFT_BLOCK + threadIdx.x;
+  bool active = i < p.m;
+  bool done = true;
+  if (active) {
+    Sim s(p, state + i);
+    if (s.ld(I_DONE) == 0) {
+      s.load_scalars();
+      done = s.run();
+      s.store_scalars(done);
+    }
+  }
+  // one atomic per wavefront: ballot of the lanes that still have pending events
+  unsigned long long pending = __ballot(active && !done);
+  if (pending && (threadIdx.x & 63) == (u32)(__ffsll((long long)pending) - 1)) atomicAdd(unfinished, (u32)__popcll(pending));
+}
+
+__device__ __forceinline__ u64 wave_sum(u64 v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ u64 wave_max(u64 v) {
+  for (int off = 32; off > 0; off >>= 1) { u64 o = __shfl_down(v, off, 64); v = o > v ? o : v; }
+  return v;
+}
+
+enum CounterSlot { C_EV0 = 0, C_EV1, C_EV2, C_EV3, C_DRAWS, C_ROUNDS, C_COMMITS, C_SCHED, C_FAULTED, C_MAXQ, C_MAXSNAP, C_MAXBLK, C_WORDS };
+
+// Per-node State hash (simulated_context.rs:51-55) and the batch counters (wavefront shuffle
+// reductions, one atomic per wavefront and counter).
+__global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_finalize(Params p, const u32* __restrict__ state, u64* __restrict__ states_out,
+                                                              unsigned long long* __restrict__ counters) {
+  u32 i = blockIdx.x * LBFT_BLOCK + threadIdx.x;
+  u64 c[C_WORDS];
+  for (int k = 0; k < C_WORDS; k++) c[k] = 0;
+  if (i < p.m) {
+    Sim s(p, const_cast<u32*>(state) + i);
+    u64 min_round = ~0ULL, min_commits = ~0ULL;
+    for (u32 n = 0; n < p.n; n++) {
+      u32 nc = s.nf(n, NF_NCOMMITS);
+      u64 ar = s.nf(n, NF_PM_ROUND);
+      min_round = ar < min_round ? ar : min_round;
+      min_commits = nc < min_commits ? nc : min_commits;
+      Sip13 h;
+      h.init();
+      h.word(nc);
+      for (u32 k = 0; k < nc; k++) {
+        u32 b = s.ld(p.off_log + n * p.lcap + k);
+        h.word(s.blk_author(b));
+        h.word(s.bf(b, B_CMD));
+        h.word((u64)(i64)(i32)s.bf(b, B_TIME));
+      }
+      states_out[(size_t)i * p.n + n] = h.finish();
+    }
+    c[C_EV0] = s.ld(I_EV0); c[C_EV1] = s.ld(I_EV1); c[C_EV2] = s.ld(I_EV2); c[C_EV3] = s.ld(I_EV3);
+    c[C_DRAWS] = s.ld(I_DRAWS); c[C_ROUNDS] = min_round; c[C_COMMITS] = min_commits; c[C_SCHED] = s.ld(I_STAMP);
+    c[C_FAULTED] = s.ld(I_FAULT) ? 1 : 0;
+    c[C_MAXQ] = s.ld(I_MAXQ); c[C_MAXSNAP] = s.ld(I_MAXSNAP); c[C_MAXBLK] = s.ld(I_NBLOCKS);
+  }
+  for (int k = 0; k < C_WORDS; k++) {
+    bool is_max = k >= C_MAXQ;
+    u64 r = is_max ? wave_max(c[k]) : wave_sum(c[k]);
+    if ((threadIdx.x & 63) == 0) {
+      if (is_max) atomicMax(&counters[k], (unsigned long long)r);
+      else atomicAdd(&counters[k], (unsigned long long)r);
+    }
+  }
+}
+
+// out[inst * n + node] = node row `field` (or instance row when node_field == 0xffffffff).
+__global__ void lbft_k_gather_node(Params p, const u32* __restrict__ state, u32 field, u32* __restrict__ out) {
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= p.m * p.n) return;
+  u32 n = t / p.m, i = t % p.m;  // consecutive lanes -> consecutive instances (coalesced reads)
+  out[(size_t)i * p.n + n] = state[(size_t)(p.off_node + n * p.node_words + field) * p.stride + i];
+}
+__global__ void lbft_k_gather_inst(Params p, const u32* __restrict__ state, u32 row, u32* __restrict__ out) {
+  u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.m) return;
+  out[i] = state[(size_t)row * p.stride + i];
+}
+// Materialise committed histories: out[(inst * n + node) * cap + k].
+__global__ void lbft_k_export_histories(Params p, const u32* __restrict__ state, lbft_commit* __restrict__ out, u32 cap,
+                                        u32 first_inst, u32 n_inst) {
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_inst * p.n) return;
+  u32 n = t / n_inst, i = first_inst + t % n_inst;
+  Sim s(p, const_cast<u32*>(state) + i);
+  u32 nc = s.nf(n, NF_NCOMMITS);
+  lbft_commit* o = out + ((size_t)(i - first_inst) * p.n + n) * cap;
+  for (u32 k = 0; k < nc && k < cap; k++) {
+    u32 b = s.ld(p.off_log + n * p.lcap + k);
+    lbft_commit c;
+    c.proposer = s.blk_author(b);
+    c.index = s.bf(b, B_CMD);
+    c.time = (i64)(i32)s.bf(b, B_TIME);
+    o[k] = c;
+  }
+}
+
+__global__ void lbft_k_fill_leaders(Params p, u8* __restrict__ out, u32 len) {
+  u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < len) out[r] = (u8)compute_leader(p.weights, p.n, p.total_votes, r);
+}
+__global__ void lbft_k_sample_delays(Params p, u64 seed, i64* __restrict__ out, u32 n) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  u32 dummy[I_WORDS];
+  Sim s(p, dummy);
+  s.rng.seed(seed);
+  for (u32 k = 0; k < n; k++) out[k] = s.sample_delay();
+}
+__global__ void lbft_k_exp_log(const u64* __restrict__ exp_tab, const double* __restrict__ x, double* __restrict__ e, double* __restrict__ l, u32 n) {
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  e[t] = lbft_exp(x[t], exp_tab);
+  l[t] = lbft_log(x[t]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host side of the C ABI
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int hip_fail(hipError_t e, const char* what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return LBFT_ERR_HIP;
+}
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t _e = (expr);                            \
+    if (_e != hipSuccess) return hip_fail(_e, #expr);  \
+  } while (0)
+
+static const u64 H_ZX[257] = LBFT_ZIG_NORM_X_BITS_INIT;
+static const u64 H_ZF[257] = LBFT_ZIG_NORM_F_BITS_INIT;
+static const u64 H_ET[256] = LBFT_EXP_TAB_INIT;
+
+#define LBFT_DUR_TABLE_LEN 4096
+#define LBFT_LEADER_TABLE_LEN 8192
+
+struct lbft_batch {
+  lbft_config cfg;
+  std::vector<u64> rights;
+  size_t m = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  u64* d_seeds = nullptr;
+  u32* d_state = nullptr;
+  size_t state_bytes = 0;
+  u64 *d_zx = nullptr, *d_zf = nullptr, *d_et = nullptr;
+  i64* d_dur = nullptr;
+  u8* d_leaders = nullptr;
+  u32* d_unfinished = nullptr;
+  u64* d_states_out = nullptr;
+  unsigned long long* d_counters = nullptr;
+  u32* d_scratch = nullptr;  // m * n words for gathers
+  Params p;
+  bool ran = false;
+  u32 max_steps = 0;
+  float init_ms = 0, run_ms = 0;
+  lbft_counters counters;
+  size_t table_bytes = 0;
+};
+
+static int fill_params(const lbft_config* cfg, size_t m, Params& p) {
+  memset(&p, 0, sizeof(p));
+  p.n = cfg->num_nodes;
+  p.m = (u32)m;
+  p.stride = (u32)((m + 63) / 64 * 64);
+  p.delay_model = cfg->delay_model;
+  // RandomDelay::new (simulator.rs:99-106), computed once on the host with the host libm like the reference
+  p.mu = std::log(cfg->mean / std::sqrt(1.0 + cfg->variance / (cfg->mean * cfg->mean)));
+  p.sigma = std::sqrt(std::log(1.0 + cfg->variance / (cfg->mean * cfg->mean)));
+  p.uni_lo = cfg->uniform_lo;
+  p.uni_span = (u64)(cfg->uniform_hi - cfg->uniform_lo) + 1;
+  p.cpe = cfg->commands_per_epoch;
+  p.tci = cfg->target_commit_interval;
+  p.lambda = cfg->lambda;
+  p.total_votes = 0;
+  for (u32 i = 0; i < p.n; i++) {
+    u64 w = cfg->voting_rights ? cfg->voting_rights[i] : 1;
+    if (w > 0x00ffffffu) return LBFT_ERR_INVALID;
+    p.weights[i] = (u32)w;
+    p.total_votes += (u32)w;
+  }
+  if (p.total_votes == 0) return LBFT_ERR_INVALID;
+  p.quorum = 2 * p.total_votes / 3 + 1;  // quorum_threshold (configuration.rs:52-56)
+  return LBFT_OK;
+}
+
+static int validate(const lbft_config* cfg) {
+  if (!cfg) return LBFT_ERR_INVALID;
+  if (cfg->num_nodes == 0) return LBFT_ERR_INVALID;
+  if (cfg->num_nodes > LBFT_MAX_NODES_SUPPORTED) return LBFT_ERR_UNSUPPORTED;
+  if (cfg->quirks != 0) return LBFT_ERR_UNSUPPORTED;
+  if (cfg->delay_model > 1) return LBFT_ERR_INVALID;
+  if (cfg->delay_model == 0 && !(cfg->mean > 0.0 && cfg->variance >= 0.0)) return LBFT_ERR_INVALID;
+  if (cfg->delay_model == 1 && !(cfg->uniform_lo >= 0 && cfg->uniform_hi >= cfg->uniform_lo)) return LBFT_ERR_INVALID;
+  if (cfg->commands_per_epoch == 0) return LBFT_ERR_INVALID;
+  return LBFT_OK;
+}
+
+static void free_batch(lbft_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  hipFree(b->d_seeds); hipFree(b->d_state); hipFree(b->d_zx); hipFree(b->d_zf); hipFree(b->d_et); hipFree(b->d_dur);
+  hipFree(b->d_leaders); hipFree(b->d_unfinished); hipFree(b->d_states_out); hipFree(b->d_counters); hipFree(b->d_scratch);
+  if (b->ev0) hipEventDestroy(b->ev0);
+  if (b->ev1) hipEventDestroy(b->ev1);
+  if (b->ev2) hipEventDestroy(b->ev2);
+  if (b->stream) hipStreamDestroy(b->stream);
+  delete b;
+}
+
+static int upload_tables(lbft_batch* b) {
+  HIP_TRY(hipMalloc(&b->d_zx, sizeof(H_ZX)));
+  HIP_TRY(hipMalloc(&b->d_zf, sizeof(H_ZF)));
+  HIP_TRY(hipMalloc(&b->d_et, sizeof(H_ET)));
+  HIP_TRY(hipMemcpy(b->d_zx, H_ZX, sizeof(H_ZX), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_zf, H_ZF, sizeof(H_ZF), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(b->d_et, H_ET, sizeof(H_ET), hipMemcpyHostToDevice));
+  // PacemakerState::duration (pacemaker.rs:111-124): delta * n^gamma with the host libm's pow, as the reference
+  std::vector<i64> dur(LBFT_DUR_TABLE_LEN);
+  for (size_t k = 0; k < dur.size(); k++) dur[k] = f64_to_i64_sat((double)b->cfg.delta * std::pow((double)k, b->cfg.gamma));
+  HIP_TRY(hipMalloc(&b->d_dur, dur.size() * sizeof(i64)));
+  HIP_TRY(hipMemcpy(b->d_dur, dur.data(), dur.size() * sizeof(i64), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&b->d_leaders, LBFT_LEADER_TABLE_LEN));
+  b->p.dur_tab = b->d_dur; b->p.dur_len = LBFT_DUR_TABLE_LEN;
+  b->p.leader_tab = b->d_leaders; b->p.leader_len = 0;  // table not valid while it is being filled
+  b->p.exp_tab = b->d_et; b->p.zig_x = b->d_zx; b->p.zig_f = b->d_zf;
+  lbft_k_fill_leaders<<<(LBFT_LEADER_TABLE_LEN + 255) / 256, 256, 0, b->stream>>>(b->p, b->d_leaders, LBFT_LEADER_TABLE_LEN);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  b->p.leader_len = LBFT_LEADER_TABLE_LEN;
+  b->table_bytes = sizeof(H_ZX) + sizeof(H_ZF) + sizeof(H_ET) + dur.size() * sizeof(i64) + LBFT_LEADER_TABLE_LEN;
+  return LBFT_OK;
+}
+
+extern "C" {
+
+const char* lbft_last_error(void) { return g_err.c_str(); }
+const char* lbft_build_info(void) { return "liblbft_hip gfx950 abi1 lane-per-instance"; }
+
+int lbft_batch_create(const lbft_config* cfg, const uint64_t* seeds, size_t n_instances, int device, lbft_batch** out) {
+  if (!out) return LBFT_ERR_INVALID;
+  *out = nullptr;
+  int rc = validate(cfg);
+  if (rc != LBFT_OK) { g_err = "invalid or unsupported configuration"; return rc; }
+  if (!seeds || n_instances == 0 || n_instances > 0x7fffffffu / cfg->num_nodes) { g_err = "bad seeds / n_instances"; return LBFT_ERR_INVALID; }
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) { g_err = "no such HIP device"; return LBFT_ERR_HIP; }
+  HIP_TRY(hipSetDevice(device));
+  lbft_batch* b = new lbft_batch();
+  b->cfg = *cfg;
+  if (cfg->voting_rights) b->rights.assign(cfg->voting_rights, cfg->voting_rights + cfg->num_nodes);
+  b->cfg.voting_rights = b->rights.empty() ? nullptr : b->rights.data();
+  b->m = n_instances;
+  b->device = device;
+  rc = fill_params(&b->cfg, n_instances, b->p);
+  if (rc != LBFT_OK) { delete b; g_err = "bad voting rights"; return rc; }
+#define CREATE_TRY(expr)                                                   \
+  do {                                                                     \
+    hipError_t _e = (expr);                                                \
+    if (_e != hipSuccess) { int r_ = hip_fail(_e, #expr); free_batch(b); return r_; } \
+  } while (0)
+  CREATE_TRY(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipEventCreate(&b->ev0));
+  CREATE_TRY(hipEventCreate(&b->ev1));
+  CREATE_TRY(hipEventCreate(&b->ev2));
+  CREATE_TRY(hipMalloc(&b->d_seeds, n_instances * sizeof(u64)));
+  CREATE_TRY(hipMemcpy(b->d_seeds, seeds, n_instances * sizeof(u64), hipMemcpyHostToDevice));
+  CREATE_TRY(hipMalloc(&b->d_unfinished, sizeof(u32)));
+  CREATE_TRY(hipMalloc(&b->d_states_out, n_instances * cfg->num_nodes * sizeof(u64)));
+  CREATE_TRY(hipMalloc(&b->d_counters, C_WORDS * sizeof(unsigned long long)));
+  CREATE_TRY(hipMalloc(&b->d_scratch, n_instances * cfg->num_nodes * sizeof(u64)));
+  rc = upload_tables(b);
+  if (rc != LBFT_OK) { free_batch(b); return rc; }
+  *out = b;
+  return LBFT_OK;
+}
+
+int lbft_batch_set_max_steps(lbft_batch* b, uint32_t max_steps) {
+  if (!b) return LBFT_ERR_INVALID;
+  b->max_steps = max_steps;
+  return LBFT_OK;
+}
+
+int lbft_batch_reset(lbft_batch* b) {
+  if (!b) return LBFT_ERR_INVALID;
+  b->ran = false;
+  return LBFT_OK;
+}
+
+int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
+  if (!b) return LBFT_ERR_INVALID;
+  if (b->ran) { g_err = "batch already ran; call lbft_batch_reset first"; return LBFT_ERR_STATE; }
+  if (max_clock < 0 || max_clock >= 0x7ffffffeLL) { g_err = "max_clock out of range"; return LBFT_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(b->device));
+  Params& p = b->p;
+  const lbft_config& c = b->cfg;
+  u32 n = c.num_nodes;
+  // Capacities (0 = auto).  The queue only ever holds events with time <= max_clock.
+  u32 qcap = c.queue_capacity ? c.queue_capacity : (16 * n * n < 128 ? 128 : 16 * n * n);
+  u32 scap = c.snapshot_capacity ? c.snapshot_capacity : (8 * n < 32 ? 32 : 8 * n);
+  u64 bauto = (u64)max_clock / 10 + 64;
+  u32 bcap = c.block_capacity ? c.block_capacity : (u32)(bauto > 65534 ? 65534 : bauto);
+  if (bcap > 65534 || scap > 65535 || n > 255) { g_err = "capacity out of range"; return LBFT_ERR_INVALID; }
+  u32 lcap = c.log_capacity ? c.log_capacity : bcap;
+  bool relayout = !(p.qcap == qcap && p.scap == scap && p.bcap == bcap && p.lcap == lcap && b->d_state);
+  p.qcap = qcap; p.scap = scap; p.bcap = bcap; p.lcap = lcap;
+  p.max_clock = (i32)max_clock;
+  p.max_steps = b->max_steps;
+  compute_layout(p);
+  if (relayout) {
+    if (b->d_state) { HIP_TRY(hipFree(b->d_state)); b->d_state = nullptr; }
+    b->state_bytes = (size_t)p.total_words * p.stride * sizeof(u32);
+    HIP_TRY(hipMalloc(&b->d_state, b->state_bytes));
+  }
+  u32 grid = (u32)((b->m + LBFT_BLOCK - 1) / LBFT_BLOCK);
+  HIP_TRY(hipEventRecord(b->ev0, b->stream));
+  lbft_k_init<<<grid, LBFT_BLOCK, 0, b->stream>>>(p, b->d_state, b->d_seeds);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(b->ev1, b->stream));
+  u64 launches = 0;
+  for (;;) {
+    HIP_TRY(hipMemsetAsync(b->d_unfinished, 0, sizeof(u32), b->stream));
+    lbft_k_run<<<grid, LBFT_BLOCK, 0, b->stream>>>(p, b->d_state, b->d_unfinished);
+    HIP_TRY(hipGetLastError());
+    launches++;
+    if (p.max_steps == 0) break;  // whole simulation in one launch
+    u32 unfinished = 0;
+    HIP_TRY(hipMemcpyAsync(&unfinished, b->d_unfinished, sizeof(u32), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (unfinished == 0) break;
+  }
+  HIP_TRY(hipEventRecord(b->ev2, b->stream));
+  HIP_TRY(hipMemsetAsync(b->d_counters, 0, C_WORDS * sizeof(unsigned long long), b->stream));
+  lbft_k_finalize<<<grid, LBFT_BLOCK, 0, b->stream>>>(p, b->d_state, b->d_states_out, b->d_counters);
+  HIP_TRY(hipGetLastError());
+  unsigned long long hc[C_WORDS];
+  HIP_TRY(hipMemcpyAsync(hc, b->d_counters, sizeof(hc), hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipEventElapsedTime(&b->init_ms, b->ev0, b->ev1));
+  HIP_TRY(hipEventElapsedTime(&b->run_ms, b->ev1, b->ev2));
+  lbft_counters& k = b->counters;
+  memset(&k, 0, sizeof(k));
+  for (int e = 0; e < 4; e++) k.events[e] = hc[C_EV0 + e];
+  k.rng_draws = hc[C_DRAWS]; k.rounds = hc[C_ROUNDS]; k.commits = hc[C_COMMITS]; k.events_scheduled = hc[C_SCHED];
+  k.faulted_instances = hc[C_FAULTED]; k.max_queue = hc[C_MAXQ]; k.max_snapshots = hc[C_MAXSNAP]; k.max_blocks = hc[C_MAXBLK];
+  k.launches = launches;
+  b->ran = true;
+  if (k.faulted_instances) { g_err = "some instances raised a fault; see lbft_batch_faults"; return LBFT_ERR_FAULT; }
+  return LBFT_OK;
+}
+
+static int gather_node(const lbft_batch* b, u32 field, u32* host_out) {
+  if (!b || !host_out) return LBFT_ERR_INVALID;
+  if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
+  HIP_TRY(hipSetDevice(b->device));
+  u32 total = (u32)(b->m * b->p.n);
+  lbft_k_gather_node<<<(total + 255) / 256, 256, 0, b->stream>>>(b->p, b->d_state, field, b->d_scratch);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(host_out, b->d_scratch, (size_t)total * sizeof(u32), hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return LBFT_OK;
+}
+
+int lbft_batch_commit_counts(const lbft_batch* b, uint32_t* out) { return gather_node(b, NF_NCOMMITS, out); }
+
+static int gather_node_u64(const lbft_batch* b, u32 field, bool sign_extend, uint64_t* out) {
+  if (!b || !out) return LBFT_ERR_INVALID;
+  std::vector<u32> tmp(b->m * b->p.n);
+  int rc = gather_node(b, field, tmp.data());
+  if (rc != LBFT_OK) return rc;
+  for (size_t i = 0; i < tmp.size(); i++) out[i] = sign_extend ? (u64)(i64)(i32)tmp[i] : (u64)tmp[i];
+  return LBFT_OK;
+}
+int lbft_batch_active_rounds(const lbft_batch* b, uint64_t* out) { return gather_node_u64(b, NF_PM_ROUND, false, out); }
+int lbft_batch_epochs(const lbft_batch* b, uint64_t* out) { return gather_node_u64(b, NF_EPOCH, false, out); }
+int lbft_batch_startup_times(const lbft_batch* b, int64_t* out) { return gather_node_u64(b, NF_STARTUP, true, (uint64_t*)out); }
+
+int lbft_batch_last_committed_states(const lbft_batch* b, uint64_t* out) {
+  if (!b || !out) return LBFT_ERR_INVALID;
+  if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipMemcpy(out, b->d_states_out, b->m * b->p.n * sizeof(u64), hipMemcpyDeviceToHost));
+  return LBFT_OK;
+}
+
+static int export_histories(const lbft_batch* b, size_t first, size_t count, lbft_commit* out, size_t cap) {
+  if (cap == 0 || count == 0) return LBFT_OK;
+  HIP_TRY(hipSetDevice(b->device));
+  // stage through a bounded device buffer (<= 64 MiB per chunk)
+  size_t per_inst = (size_t)b->p.n * cap * sizeof(lbft_commit);
+  size_t chunk = (64u << 20) / per_inst;
+  if (chunk == 0) chunk = 1;
+  if (chunk > count) chunk = count;
+  lbft_commit* d_buf = nullptr;
+  HIP_TRY(hipMalloc(&d_buf, chunk * per_inst));
+  int rc = LBFT_OK;
+  for (size_t done = 0; done < count && rc == LBFT_OK; done += chunk) {
+    size_t cnt = count - done < chunk ? count - done : chunk;
+    hipError_t e = hipMemsetAsync(d_buf, 0, cnt * per_inst, b->stream);
+    if (e == hipSuccess) {
+      u32 total = (u32)(cnt * b->p.n);
+      lbft_k_export_histories<<<(total + 63) / 64, 64, 0, b->stream>>>(b->p, b->d_state, d_buf, (u32)cap, (u32)(first + done), (u32)cnt);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync((char*)out + done * per_inst, d_buf, cnt * per_inst, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    if (e != hipSuccess) rc = hip_fail(e, "export_histories");
+  }
+  hipFree(d_buf);
+  return rc;
+}
+
+int lbft_batch_committed_histories(const lbft_batch* b, lbft_commit* out, size_t cap_per_node) {
+  if (!b || !out) return LBFT_ERR_INVALID;
+  if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
+  if (cap_per_node > 0xffffffffu) return LBFT_ERR_INVALID;
+  return export_histories(b, 0, b->m, out, cap_per_node);
+}
+
+int lbft_batch_committed_history(const lbft_batch* b, size_t inst, uint32_t node, lbft_commit* out, size_t cap, size_t* len) {
+  if (!b || !len || inst >= b->m || node >= b->p.n) return LBFT_ERR_INVALID;
+  if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
+  u32 lcap = b->p.lcap;
+  std::vector<lbft_commit> tmp((size_t)b->p.n * lcap);
+  int rc = export_histories(b, inst, 1, tmp.data(), lcap);
+  if (rc != LBFT_OK) return rc;
+  HIP_TRY(hipSetDevice(b->device));
+  u32 nc = 0;
+  HIP_TRY(hipMemcpy(&nc, b->d_state + (size_t)(b->p.off_node + node * b->p.node_words + NF_NCOMMITS) * b->p.stride + inst, sizeof(u32),
+                    hipMemcpyDeviceToHost));
+  *len = nc;
+  for (size_t k = 0; k < nc && k < cap && out; k++) out[k] = tmp[(size_t)node * lcap + k];
+  return LBFT_OK;
+}
+
+int lbft_batch_counters(const lbft_batch* b, lbft_counters* out) {
+  if (!b || !out) return LBFT_ERR_INVALID;
+  if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
+  *out = b->counters;
+  return LBFT_OK;
+}
+
+int lbft_batch_faults(const lbft_batch* b, uint32_t* out) {
+  if (!b || !out) return LBFT_ERR_INVALID;
+  if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
+  HIP_TRY(hipSetDevice(b->device));
+  lbft_k_gather_inst<<<(u32)((b->m + 255) / 256), 256, 0, b->stream>>>(b->p, b->d_state, I_FAULT, b->d_scratch);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out, b->d_scratch, b->m * sizeof(u32), hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return LBFT_OK;
+}
+
+void lbft_batch_destroy(lbft_batch* b) { free_batch(b); }
+
+void* lbft_batch_stream(const lbft_batch* b) { return b ? (void*)b->stream : nullptr; }
+int lbft_batch_last_run_ms(const lbft_batch* b, float* init_ms, float* run_ms) {
+  if (!b) return LBFT_ERR_INVALID;
+  if (!b->ran) return LBFT_ERR_STATE;
+  if (init_ms) *init_ms = b->init_ms;
+  if (run_ms) *run_ms = b->run_ms;
+  return LBFT_OK;
+}
+size_t lbft_batch_device_bytes(const lbft_batch* b) {
+  if (!b) return 0;
+  return b->state_bytes + b->table_bytes + b->m * sizeof(u64) + b->m * b->p.n * (sizeof(u64) * 2);
+}
+
+// ---- stand-alone device checks ----
+static int tiny_setup(int device, const lbft_config* cfg, lbft_batch** out) {
+  static const u64 one_seed = 0;
+  return lbft_batch_create(cfg, &one_seed, 1, device, out);
+}
+
+int lbft_device_leaders(int device, const uint64_t* voting_rights, uint32_t num_nodes, uint8_t* out, uint32_t n_rounds) {
+  if (!out || num_nodes == 0) return LBFT_ERR_INVALID;
+  lbft_config cfg;
+  memset(&cfg, 0, sizeof(cfg));
+  cfg.num_nodes = num_nodes; cfg.mean = 10; cfg.variance = 4; cfg.commands_per_epoch = 1; cfg.gamma = 2; cfg.lambda = 0.5;
+  cfg.delta = 20; cfg.target_commit_interval = 1; cfg.voting_rights = voting_rights;
+  lbft_batch* b = nullptr;
+  int rc = tiny_setup(device, &cfg, &b);
+  if (rc != LBFT_OK) return rc;
+  u8* d = nullptr;
+  hipError_t e = hipMalloc(&d, n_rounds);
+  if (e == hipSuccess) {
+    Params p = b->p;
+    lbft_k_fill_leaders<<<(n_rounds + 255) / 256, 256, 0, b->stream>>>(p, d, n_rounds);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  if (e == hipSuccess) e = hipMemcpy(out, d, n_rounds, hipMemcpyDeviceToHost);
+  hipFree(d);
+  free_batch(b);
+  return e == hipSuccess ? LBFT_OK : hip_fail(e, "lbft_device_leaders");
+}
+
+int lbft_device_sample_delays(int device, const lbft_config* cfg, uint64_t seed, int64_t* out, size_t n) {
+  if (!out || n > 0xffffffffu) return LBFT_ERR_INVALID;
+  lbft_batch* b = nullptr;
+  int rc = tiny_setup(device, cfg, &b);
+  if (rc != LBFT_OK) return rc;
+  i64* d = nullptr;
+  hipError_t e = hipMalloc(&d, n * sizeof(i64));
+  if (e == hipSuccess) {
+    lbft_k_sample_delays<<<1, 64, 0, b->stream>>>(b->p, seed, d, (u32)n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  if (e == hipSuccess) e = hipMemcpy(out, d, n * sizeof(i64), hipMemcpyDeviceToHost);
+  hipFree(d);
+  free_batch(b);
+  return e == hipSuccess ? LBFT_OK : hip_fail(e, "lbft_device_sample_delays");
+}
+
+int lbft_device_exp_log(int device, const double* x, double* exp_out, double* log_out, size_t n) {
+  if (!x || !exp_out || !log_out || n > 0xffffffffu) return LBFT_ERR_INVALID;
+  HIP_TRY(hipSetDevice(device));
+  u64* d_et = nullptr;
+  double *dx = nullptr, *de = nullptr, *dl = nullptr;
+  hipError_t e = hipMalloc(&d_et, sizeof(H_ET));
+  if (e == hipSuccess) e = hipMemcpy(d_et, H_ET, sizeof(H_ET), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&dx, n * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&de, n * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc(&dl, n * sizeof(double));
+  if (e == hipSuccess) e = hipMemcpy(dx, x, n * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    lbft_k_exp_log<<<(u32)((n + 255) / 256), 256>>>(d_et, dx, de, dl, (u32)n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(exp_out, de, n * sizeof(double), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(log_out, dl, n * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(d_et); hipFree(dx); hipFree(de); hipFree(dl);
+  return e == hipSuccess ? LBFT_OK : hip_fail(e, "lbft_device_exp_log");
+}
+
+}  // extern "C"

@@ -32,8 +32,8 @@ LBFT_HD uint64_t lbft_asuint64(double d) {
   union { uint64_t u; double d; } c; c.d = d; return c.u;
 }
 
-// exp(x).  `tab` = LBFT_EXP_TAB (256 x u64).  Valid for |x| < 512 (outside: saturating, see below).
-LBFT_HD double lbft_exp(double x, const uint64_t* tab) {
+// Main path of exp(): valid for 2^-54 <= |x| < 512.
+LBFT_HD double lbft_exp_core(double x, const uint64_t* tab) {
   const double InvLn2N = 0x1.71547652b82fep0 * 128.0;
   const double NegLn2hiN = -0x1.62e42fefa0000p-8;
   const double NegLn2loN = -0x1.cf79abc9e3b3ap-47;
@@ -42,15 +42,6 @@ LBFT_HD double lbft_exp(double x, const uint64_t* tab) {
   const double C3 = 0x1.555555555543cp-3;
   const double C4 = 0x1.55555cf172b91p-5;
   const double C5 = 0x1.1111167a4d017p-7;
-  uint32_t abstop = (uint32_t)(lbft_asuint64(x) >> 52) & 0x7ff;
-  if (abstop < 0x3c9) return 1.0 + x;  // |x| < 2^-54
-  if (abstop >= 0x408) {                // |x| >= 512 (or NaN): never reached by a delay model
-    if (x != x) return x;
-    if (x > 709.782712893384) return lbft_asdouble(0x7ff0000000000000ULL);
-    if (x < -745.1332191019412) return 0.0;
-    double h = lbft_exp(0.5 * x, tab);  // deterministic, not correctly rounded; documented
-    return h * h;
-  }
   // Explicit fused multiply-adds in exactly the places the FMA build of glibc's exp contracts them
   // (x86-64 glibc dispatches to that build on every FMA-capable CPU); verified bit-identical to the
   // host libm on 2e7 random points in tests/test_math.py.
@@ -68,6 +59,20 @@ LBFT_HD double lbft_exp(double x, const uint64_t* tab) {
   double tmp = __builtin_fma(r2 * r2, p2, __builtin_fma(r2, p1, tail + r));
   double scale = lbft_asdouble(sbits);
   return __builtin_fma(scale, tmp, scale);
+}
+
+// exp(x).  `tab` = LBFT_EXP_TAB (256 x u64).
+LBFT_HD double lbft_exp(double x, const uint64_t* tab) {
+  uint32_t abstop = (uint32_t)(lbft_asuint64(x) >> 52) & 0x7ff;
+  if (abstop < 0x3c9) return 1.0 + x;  // |x| < 2^-54
+  if (abstop >= 0x408) {                // |x| >= 512 (or NaN): never reached by a sane delay model
+    if (x != x) return x;
+    if (x > 709.782712893384) return lbft_asdouble(0x7ff0000000000000ULL);
+    if (x < -745.1332191019412) return 0.0;
+    double h = lbft_exp_core(0.5 * x, tab);  // deterministic on host and device; not correctly rounded
+    return h * h;
+  }
+  return lbft_exp_core(x, tab);
 }
 
 // log(x) for finite x > 0 (fdlibm e_log.c).

@@ -1,0 +1,263 @@
+"""Host-side mirror of the reference's simulator interface for the hot path, on top of the C ABI.
+
+Reference surface mirrored here (names and argument meaning kept):
+  * ``RandomDelay::new(mean, variance)``                       bft-lib/src/simulator.rs:98-107
+  * ``GlobalTime(i64)``                                        bft-lib/src/simulator.rs:35-37
+  * ``NodeConfig{target_commit_interval, delta, gamma, lambda}`` librabft-v2/src/node.rs:76-81
+  * ``Simulator::new(rng_seed, num_nodes, network_delay, context_factory)`` and
+    ``Simulator::loop_until(max_clock, csv_path) -> Vec<&Context>``  bft-lib/src/simulator.rs:200-250,380-475
+  * ``SimulatedContext::committed_history()`` / ``last_committed_state()``
+                                                               bft-lib/src/simulated_context.rs:98-100,194-196
+``BatchSimulator`` is the batched form (many independent ``Simulator``s, one GPU lane each); it is
+what the HIP path natively executes.  Everything computes on the GPU through liblbft_hip.so; there
+is no CPU path in this package.
+"""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import COMMIT_DTYPE, LbftConfig, LbftCounters, LbftError, check
+
+Command = namedtuple("Command", ["proposer", "index"])  # simulated_context.rs:31-35
+Author = int
+NodeTime = int
+
+
+class State(int):
+    """simulated_context.rs:28-29: State(u64)."""
+
+    def __repr__(self):
+        return "State(%d)" % int(self)
+
+
+class GlobalTime(int):
+    """bft-lib/src/simulator.rs:35-37."""
+
+    def __repr__(self):
+        return "GlobalTime(%d)" % int(self)
+
+
+class Duration(int):
+    """bft-lib/src/base_types.rs Duration(i64)."""
+
+
+class RandomDelay:
+    """bft-lib/src/simulator.rs:39-43,98-107.  ``RandomDelay.new(mean, variance)`` is the reference's
+    log-normal delay; ``RandomDelay.uniform(lo, hi)`` is this framework's integer-uniform extension."""
+
+    def __init__(self, mean=10.0, variance=4.0, model=0, lo=0, hi=0):
+        self.mean, self.variance, self.model, self.lo, self.hi = float(mean), float(variance), int(model), int(lo), int(hi)
+
+    @classmethod
+    def new(cls, mean, variance):
+        return cls(mean, variance, 0)
+
+    @classmethod
+    def uniform(cls, lo, hi):
+        return cls(10.0, 4.0, 1, lo, hi)
+
+
+class NodeConfig:
+    """librabft-v2/src/node.rs:76-81 (defaults = CLI defaults, librabft-v2/src/main.rs:111-134)."""
+
+    def __init__(self, target_commit_interval=100000, delta=20, gamma=2.0, lambda_=0.5):
+        self.target_commit_interval = int(target_commit_interval)
+        self.delta = int(delta)
+        self.gamma = float(gamma)
+        self.lambda_ = float(lambda_)
+
+
+def make_config(num_nodes, network_delay, node_config, commands_per_epoch=30000, voting_rights=None,
+                queue_capacity=0, snapshot_capacity=0, block_capacity=0, log_capacity=0):
+    cfg = LbftConfig()
+    cfg.num_nodes = num_nodes
+    cfg.delay_model = network_delay.model
+    cfg.mean = network_delay.mean
+    cfg.variance = network_delay.variance
+    cfg.uniform_lo = network_delay.lo
+    cfg.uniform_hi = network_delay.hi
+    cfg.commands_per_epoch = commands_per_epoch
+    cfg.target_commit_interval = node_config.target_commit_interval
+    cfg.delta = node_config.delta
+    cfg.gamma = node_config.gamma
+    cfg.lambda_ = node_config.lambda_
+    cfg.quirks = 0
+    cfg.queue_capacity = queue_capacity
+    cfg.snapshot_capacity = snapshot_capacity
+    cfg.block_capacity = block_capacity
+    cfg.log_capacity = log_capacity
+    if voting_rights is not None:
+        arr = (C.c_uint64 * num_nodes)(*[int(w) for w in voting_rights])
+        cfg._keepalive = arr
+        cfg.voting_rights = C.cast(arr, C.POINTER(C.c_uint64))
+    return cfg
+
+
+class BatchResult:
+    """Results of ``BatchSimulator.loop_until`` (lazy device read-back through the C ABI)."""
+
+    def __init__(self, sim):
+        self._sim = sim
+        self._cache = {}
+
+    def _get(self, key, fn):
+        if key not in self._cache:
+            self._cache[key] = fn()
+        return self._cache[key]
+
+    @property
+    def counters(self):
+        def f():
+            c = LbftCounters()
+            check(_lib.lib().lbft_batch_counters(self._sim._h, C.byref(c)))
+            return c.as_dict()
+        return self._get("counters", f)
+
+    def _node_array(self, name, dtype):
+        def f():
+            out = np.zeros((self._sim.num_instances, self._sim.num_nodes), dtype=dtype)
+            check(getattr(_lib.lib(), "lbft_batch_" + name)(self._sim._h, out.ctypes.data))
+            return out
+        return self._get(name, f)
+
+    @property
+    def commit_counts(self):
+        """contexts.iter().map(|c| c.committed_history().len())  [instance, node]"""
+        return self._node_array("commit_counts", np.uint32)
+
+    @property
+    def active_rounds(self):
+        return self._node_array("active_rounds", np.uint64)
+
+    @property
+    def last_committed_states(self):
+        return self._node_array("last_committed_states", np.uint64)
+
+    @property
+    def startup_times(self):
+        return self._node_array("startup_times", np.int64)
+
+    @property
+    def epochs(self):
+        return self._node_array("epochs", np.uint64)
+
+    @property
+    def faults(self):
+        def f():
+            out = np.zeros(self._sim.num_instances, dtype=np.uint32)
+            check(_lib.lib().lbft_batch_faults(self._sim._h, out.ctypes.data))
+            return out
+        return self._get("faults", f)
+
+    def committed_histories(self, cap_per_node=None):
+        """[instance, node, k] structured array (proposer, index, time); entries past the node's
+        commit count are zero."""
+        if cap_per_node is None:
+            cap_per_node = int(self.commit_counts.max()) if self._sim.num_instances else 0
+        cap_per_node = max(int(cap_per_node), 1)
+        out = np.zeros((self._sim.num_instances, self._sim.num_nodes, cap_per_node), dtype=COMMIT_DTYPE)
+        check(_lib.lib().lbft_batch_committed_histories(self._sim._h, out.ctypes.data, cap_per_node))
+        return out
+
+    def committed_history(self, instance, node):
+        n = int(self.commit_counts[instance, node])
+        out = np.zeros(max(n, 1), dtype=COMMIT_DTYPE)
+        ln = C.c_size_t()
+        check(_lib.lib().lbft_batch_committed_history(self._sim._h, instance, node, out.ctypes.data, n, C.byref(ln)))
+        return out[:n]
+
+    def contexts(self, instance=0):
+        """The ``Vec<&Context>`` that ``Simulator::loop_until`` returns, for one instance."""
+        return [SimulatedContextView(self, instance, n) for n in range(self._sim.num_nodes)]
+
+
+class SimulatedContextView:
+    """Read-only view with the accessors the reference's callers use (main.rs:47-53,
+    tests/simulated_run.rs:45-94)."""
+
+    def __init__(self, result, instance, node):
+        self._r, self._i, self._n = result, instance, node
+
+    def committed_history(self):
+        h = self._r.committed_history(self._i, self._n)
+        return [(Command(int(e["proposer"]), int(e["index"])), int(e["time"])) for e in h]
+
+    def last_committed_state(self):
+        return State(int(self._r.last_committed_states[self._i, self._n]))
+
+
+class BatchSimulator:
+    """Many independent ``Simulator``s (bft-lib/src/simulator.rs:26-33) advanced in lockstep on one GPU."""
+
+    def __init__(self, rng_seeds, num_nodes, network_delay, node_config=None, commands_per_epoch=30000,
+                 voting_rights=None, device=0, queue_capacity=0, snapshot_capacity=0, block_capacity=0,
+                 log_capacity=0, max_steps_per_launch=0):
+        seeds = np.ascontiguousarray(rng_seeds, dtype=np.uint64)
+        self.seeds = seeds
+        self.num_instances = int(seeds.shape[0])
+        self.num_nodes = int(num_nodes)
+        self.device = int(device)
+        self._cfg = make_config(num_nodes, network_delay, node_config or NodeConfig(), commands_per_epoch, voting_rights,
+                                queue_capacity, snapshot_capacity, block_capacity, log_capacity)
+        self._h = C.c_void_p()
+        check(_lib.lib().lbft_batch_create(C.byref(self._cfg), seeds.ctypes.data, self.num_instances, self.device,
+                                           C.byref(self._h)))
+        if max_steps_per_launch:
+            check(_lib.lib().lbft_batch_set_max_steps(self._h, max_steps_per_launch))
+
+    @classmethod
+    def new(cls, rng_seeds, num_nodes, network_delay, node_config=None, **kw):
+        return cls(rng_seeds, num_nodes, network_delay, node_config, **kw)
+
+    def loop_until(self, max_clock, csv_path=None, allow_faults=False):
+        """Simulator::loop_until for every instance.  ``csv_path`` (the reference's round-switch CSV,
+        bft-lib/src/data_writer.rs) is not part of the hot path and must be None."""
+        if csv_path is not None:
+            raise NotImplementedError("the round-switch CSV writer is outside the accelerated hot path (SURVEY.md 8f)")
+        check(_lib.lib().lbft_batch_run_until(self._h, int(max_clock)), allow_fault=allow_faults)
+        return BatchResult(self)
+
+    def reset(self):
+        check(_lib.lib().lbft_batch_reset(self._h))
+
+    def stream_handle(self):
+        return _lib.lib().lbft_batch_stream(self._h)
+
+    def last_run_ms(self):
+        a, b = C.c_float(), C.c_float()
+        check(_lib.lib().lbft_batch_last_run_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def device_bytes(self):
+        return int(_lib.lib().lbft_batch_device_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().lbft_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Simulator:
+    """``Simulator::new(rng_seed, num_nodes, network_delay, context_factory)`` for one network.
+
+    The reference's ``context_factory`` closure (librabft-v2/src/main.rs:23-34) only carries
+    ``commands_per_epoch`` and the ``NodeConfig``; pass them directly."""
+
+    def __init__(self, rng_seed, num_nodes, network_delay, node_config=None, commands_per_epoch=30000, **kw):
+        self._batch = BatchSimulator([rng_seed], num_nodes, network_delay, node_config, commands_per_epoch, **kw)
+
+    @classmethod
+    def new(cls, rng_seed, num_nodes, network_delay, node_config=None, commands_per_epoch=30000, **kw):
+        return cls(rng_seed, num_nodes, network_delay, node_config, commands_per_epoch, **kw)
+
+    def loop_until(self, max_clock, csv_path=None):
+        self.result = self._batch.loop_until(max_clock, csv_path)
+        return self.result.contexts(0)

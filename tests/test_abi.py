@@ -1,0 +1,72 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol that
+include/lbft.h declares, and fails loudly (no fallback) when there is no GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hiplib():
+    from librabft_simulator_amd import build
+    build.build()
+    from librabft_simulator_amd import _lib
+    return _lib
+
+
+def test_header_symbols_are_exported(hiplib):
+    header = open(os.path.join(ROOT, "include", "lbft.h")).read()
+    declared = set(re.findall(r"\b(lbft_[a-z_0-9]+)\s*\(", header))
+    declared -= {"lbft_batch"}
+    assert declared == set(hiplib.ABI_SYMBOLS), declared ^ set(hiplib.ABI_SYMBOLS)
+    raw = ctypes.CDLL(hiplib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), name
+    assert b"gfx950" in hiplib.lib().lbft_build_info()
+
+
+def test_config_struct_matches_header_layout(hiplib):
+    # lbft_config: 2*u32, 2*f64, 2*i64, u64, 2*i64, 2*f64, 2*u32, ptr, 4*u32
+    assert ctypes.sizeof(hiplib.LbftConfig) == 8 + 16 + 16 + 8 + 16 + 16 + 8 + 8 + 16
+    assert ctypes.sizeof(hiplib.LbftCounters) == 8 * 13
+    assert hiplib.COMMIT_DTYPE.itemsize == 24
+
+
+def test_library_has_no_oracle_or_host_fallback(hiplib):
+    # the product library must not link the oracle or the host build of the model
+    import subprocess
+    out = subprocess.run(["ldd", hiplib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "lbft_oracle" not in out and "hostmodel" not in out
+    syms = subprocess.run(["nm", "-D", "--defined-only", hiplib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "lbft_oracle" not in syms and "lbft_hostmodel" not in syms
+
+
+def test_argument_validation_needs_no_gpu(hiplib):
+    L = hiplib.lib()
+    h = ctypes.c_void_p()
+    cfg = hiplib.LbftConfig()
+    cfg.num_nodes = 0
+    seeds = np.arange(4, dtype=np.uint64)
+    assert L.lbft_batch_create(ctypes.byref(cfg), seeds.ctypes.data, 4, 0, ctypes.byref(h)) == hiplib.LBFT_ERR_INVALID
+    cfg.num_nodes = 4
+    cfg.mean, cfg.variance, cfg.commands_per_epoch = 10.0, 4.0, 30000
+    cfg.quirks = 1
+    assert L.lbft_batch_create(ctypes.byref(cfg), seeds.ctypes.data, 4, 0, ctypes.byref(h)) == hiplib.LBFT_ERR_UNSUPPORTED
+    cfg.quirks = 0
+    cfg.num_nodes = 33
+    assert L.lbft_batch_create(ctypes.byref(cfg), seeds.ctypes.data, 4, 0, ctypes.byref(h)) == hiplib.LBFT_ERR_UNSUPPORTED
+    assert L.lbft_batch_run_until(None, 10) == hiplib.LBFT_ERR_INVALID
+
+
+def test_fails_loudly_without_gpu(hiplib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from librabft_simulator_amd import LbftError, RandomDelay, Simulator
+    with pytest.raises(LbftError) as e:
+        Simulator.new(52, 3, RandomDelay.new(10.0, 4.0)).loop_until(1000)
+    assert e.value.code == hiplib.LBFT_ERR_HIP

@@ -1,0 +1,218 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ctypes -> liblbft_hip.so), against
+the CPU oracle on the same seeds, against the reference's golden vectors, and -- at BASELINE.json's
+full sizes -- through size-independent properties.  Bit-exact: everything here is integer work."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    import librabft_simulator_amd as L
+    L.lib()  # fails loudly if liblbft_hip.so is missing
+    return L
+
+
+def run_gpu(amd, kw, seeds, max_clock, **sim_kw):
+    kw = dict(kw)
+    n = kw.pop("num_nodes")
+    if kw.get("delay_model", 0) == 1:
+        delay = amd.RandomDelay.uniform(kw.get("uniform_lo", 5), kw.get("uniform_hi", 15))
+    else:
+        delay = amd.RandomDelay.new(kw.get("mean", 10.0), kw.get("variance", 4.0))
+    nc = amd.NodeConfig(kw.get("target_commit_interval", 100000), kw.get("delta", 20), kw.get("gamma", 2.0),
+                        kw.get("lambda_", 0.5))
+    sim = amd.BatchSimulator.new(seeds, n, delay, nc, commands_per_epoch=kw.get("commands_per_epoch", 30000),
+                                 voting_rights=kw.get("voting_rights"), **sim_kw)
+    return sim, sim.loop_until(max_clock)
+
+
+def assert_equal_to_oracle(oracle, res, kw, seeds, max_clock, cap=256):
+    ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds, max_clock, threads=8, history_cap=cap)
+    assert not res.faults.any()
+    assert (res.commit_counts == ref["commit_counts"]).all()
+    assert (res.active_rounds == ref["active_rounds"]).all()
+    assert (res.last_committed_states == ref["last_states"]).all()
+    assert (res.committed_histories(cap) == ref["histories"]).all()
+    c, rc = res.counters, ref["counters"]
+    for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
+        assert c[key] == rc[key], key
+    return ref
+
+
+def test_reference_golden_3_nodes(amd):
+    # librabft-v2/tests/simulated_run.rs:45-66
+    contexts = amd.Simulator.new(52, 3, amd.RandomDelay.new(10.0, 4.0)).loop_until(amd.GlobalTime(1000))
+    assert [len(c.committed_history()) for c in contexts] == [27, 27, 27]
+    assert [int(c.last_committed_state()) for c in contexts] == [11134312813757838303] * 3
+    h = contexts[0].committed_history()
+    assert [(c.proposer, c.index, t) for c, t in h[:3]] == [(2, 0, 32), (2, 1, 52), (2, 2, 78)]
+
+
+def test_reference_golden_8_nodes(amd):
+    # librabft-v2/tests/simulated_run.rs:68-94
+    contexts = amd.Simulator.new(48, 8, amd.RandomDelay.new(10.0, 4.0)).loop_until(amd.GlobalTime(1000))
+    assert [len(c.committed_history()) for c in contexts] == [28] * 7 + [30]
+    assert [int(c.last_committed_state()) for c in contexts] == [12785928431398617538] * 7 + [4890275890002623733]
+
+
+CASES = {
+    "c1_3nodes_fixed10_100rounds": (dict(num_nodes=3, mean=10.0, variance=0.0), 64, 2800),
+    "c2_1024x4_lognormal": (dict(num_nodes=4), 1024, 1000),
+    "c2_1024x4_uniform": (dict(num_nodes=4, delay_model=1, uniform_lo=5, uniform_hi=15), 1024, 1000),
+    "n8": (dict(num_nodes=8), 128, 1000),
+    "n1": (dict(num_nodes=1), 5, 300),
+    "n2_ragged_batch": (dict(num_nodes=2), 67, 1000),
+    "n16": (dict(num_nodes=16), 16, 400),
+    "epoch_change_cpe50": (dict(num_nodes=4, commands_per_epoch=50), 128, 3000),
+    "weighted": (dict(num_nodes=5, voting_rights=[5, 1, 1, 2, 3]), 128, 1000),
+    "long_tail": (dict(num_nodes=4, mean=10.0, variance=400.0), 256, 2000),
+    "params": (dict(num_nodes=5, gamma=1.5, lambda_=0.25, delta=5, target_commit_interval=80), 128, 1500),
+    "long_run": (dict(num_nodes=4), 32, 8000),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gpu_equals_oracle(amd, oracle, name):
+    kw, m, max_clock = CASES[name]
+    seeds = np.arange(1, m + 1, dtype=np.uint64) * 104729 + 17
+    _, res = run_gpu(amd, kw, seeds, max_clock)
+    assert_equal_to_oracle(oracle, res, kw, seeds, max_clock, cap=512 if max_clock > 3000 else 256)
+
+
+def test_multi_launch_equals_single_launch(amd, oracle):
+    kw, seeds = dict(num_nodes=4), np.arange(1, 257, dtype=np.uint64)
+    _, res = run_gpu(amd, kw, seeds, 1000, max_steps_per_launch=97)
+    assert res.counters["launches"] > 10
+    assert_equal_to_oracle(oracle, res, kw, seeds, 1000)
+
+
+def test_reset_reruns_identically(amd):
+    seeds = np.arange(1, 129, dtype=np.uint64)
+    sim, r1 = run_gpu(amd, dict(num_nodes=4), seeds, 1000)
+    s1, h1 = r1.last_committed_states.copy(), r1.committed_histories(64)
+    sim.reset()
+    r2 = sim.loop_until(1000)
+    assert (r2.last_committed_states == s1).all() and (r2.committed_histories(64) == h1).all()
+
+
+def test_capacity_overflow_sets_fault_flag(amd):
+    seeds = np.arange(1, 65, dtype=np.uint64)
+    sim = amd.BatchSimulator.new(seeds, 4, amd.RandomDelay.new(10.0, 4.0), queue_capacity=16, block_capacity=8)
+    with pytest.raises(amd.LbftError) as e:
+        sim.loop_until(1000)
+    assert e.value.code == -5
+    out = np.zeros(64, dtype=np.uint32)  # the handle stays valid; per-instance fault words are readable
+    from librabft_simulator_amd import _lib
+    _lib.check(_lib.lib().lbft_batch_faults(sim._h, out.ctypes.data))
+    assert (out != 0).all()
+
+
+def test_zero_max_clock_and_empty_histories(amd, oracle):
+    seeds = np.arange(1, 9, dtype=np.uint64)
+    _, res = run_gpu(amd, dict(num_nodes=4), seeds, 0)
+    assert res.commit_counts.sum() == 0
+    assert (res.last_committed_states == 13646096770106105413).all()  # State of the empty ledger (README.md:27)
+    assert sum(res.counters["events"]) == 0
+
+
+def test_device_third_party_arithmetic(amd, oracle):
+    from librabft_simulator_amd import _lib
+    L, OL = _lib.lib(), oracle.lib()
+    # leaders (pacemaker.rs:100-109 -> configuration.rs:65-75), unit and weighted rights
+    for n, w in ((3, None), (8, None), (5, [5, 1, 1, 2, 3])):
+        out = np.zeros(600, dtype=np.uint8)
+        wa = np.array(w, dtype=np.uint64) if w else None
+        _lib.check(L.lbft_device_leaders(0, wa.ctypes.data if w else None, n, out.ctypes.data, 600))
+        assert [int(v) for v in out] == [oracle.leader(n, r, w) for r in range(600)]
+    assert [int(v) for v in out[:0]] == []
+    # delay streams: ziggurat + exp, log-normal and uniform
+    for kw in (dict(variance=4.0), dict(variance=400.0), dict(variance=0.0), dict(delay_model=1, uniform_lo=5, uniform_hi=15)):
+        n = 100000
+        a, b = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+        OL.lbft_oracle_sample_delays(ctypes.byref(oracle.make_config(math_mode=1, **kw)), 99, a.ctypes.data, n)
+        if kw.get("delay_model") == 1:
+            delay = amd.RandomDelay.uniform(5, 15)
+        else:
+            delay = amd.RandomDelay.new(10.0, kw["variance"])
+        from librabft_simulator_amd.simulator import make_config
+        cfg = make_config(3, delay, amd.NodeConfig())
+        _lib.check(L.lbft_device_sample_delays(0, ctypes.byref(cfg), 99, b.ctypes.data, n))
+        assert (a == b).all(), kw
+    # exp/log bit patterns
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-12, 12, 100000), rng.uniform(1e-12, 1.0, 100000)])
+    e, l = np.zeros_like(x), np.zeros_like(x)
+    _lib.check(L.lbft_device_exp_log(0, x.ctypes.data, e.ctypes.data, l.ctypes.data, len(x)))
+    ee = np.array([OL.lbft_oracle_exp_strict(float(v)) for v in x])
+    ll = np.array([OL.lbft_oracle_log_strict(float(v)) for v in x[100000:]])
+    assert (e.view(np.uint64) == ee.view(np.uint64)).all()
+    assert (l[100000:].view(np.uint64) == ll.view(np.uint64)).all()
+
+
+def siphash13_words(words):
+    """SipHash-1-3 (keys 0,0) over little-endian u64 words (numpy-free, small inputs only)."""
+    mask = (1 << 64) - 1
+    v = [0x736f6d6570736575, 0x646f72616e646f6d, 0x6c7967656e657261, 0x7465646279746573]
+
+    def rotl(x, b):
+        return ((x << b) | (x >> (64 - b))) & mask
+
+    def rnd():
+        v[0] = (v[0] + v[1]) & mask; v[1] = rotl(v[1], 13); v[1] ^= v[0]; v[0] = rotl(v[0], 32)
+        v[2] = (v[2] + v[3]) & mask; v[3] = rotl(v[3], 16); v[3] ^= v[2]
+        v[0] = (v[0] + v[3]) & mask; v[3] = rotl(v[3], 21); v[3] ^= v[0]
+        v[2] = (v[2] + v[1]) & mask; v[1] = rotl(v[1], 17); v[1] ^= v[2]; v[2] = rotl(v[2], 32)
+
+    for m in words:
+        m &= mask
+        v[3] ^= m; rnd(); v[0] ^= m
+    b = ((len(words) * 8) << 56) & mask
+    v[3] ^= b; rnd(); v[0] ^= b
+    v[2] ^= 0xff
+    rnd(); rnd(); rnd()
+    return v[0] ^ v[1] ^ v[2] ^ v[3]
+
+
+def test_full_size_65536x4_properties(amd, oracle):
+    """BASELINE.json configs[2] on one GPU: size-independent properties + oracle spot checks."""
+    m = 65536
+    seeds = np.arange(1, m + 1, dtype=np.uint64)  # seed_i = base_seed + i, base_seed = 1
+    _, res = run_gpu(amd, dict(num_nodes=4), seeds, 1000)
+    assert not res.faults.any()
+    cc = res.commit_counts
+    cap = int(cc.max())
+    hist = res.committed_histories(cap)
+    # (1) safety: within an instance every node's log is a prefix of the longest log
+    longest = cc.argmax(axis=1)
+    ref_log = hist[np.arange(m), longest]
+    k = np.arange(cap)[None, None, :]
+    valid = k < cc[:, :, None]
+    same = (hist == ref_log[:, None, :]) | ~valid
+    assert same.all()
+    # (2) per-proposer command indices are strictly increasing along a log; times are non-decreasing per proposer
+    # (3) every committed entry's proposer is a node id
+    assert (hist["proposer"][valid] < 4).all()
+    # (4) the device State hash equals SipHash-1-3 of the exported history (checksum of checksums)
+    states = res.last_committed_states
+    rng = np.random.default_rng(0)
+    for i in rng.integers(0, m, 200):
+        for n in range(4):
+            words = [int(cc[i, n])]
+            for e in hist[i, n, :cc[i, n]]:
+                words += [int(e["proposer"]), int(e["index"]), int(e["time"]) & ((1 << 64) - 1)]
+            assert siphash13_words(words) == int(states[i, n])
+    # (5) liveness of the healthy configuration: almost every instance commits
+    assert (cc.min(axis=1) >= 20).mean() > 0.95
+    # (6) oracle spot check on a strided subset, bit-exact
+    idx = np.arange(0, m, 128)
+    ref = oracle.run_batch(oracle.make_config(num_nodes=4, math_mode=1), seeds[idx], 1000, threads=8, history_cap=cap)
+    assert (cc[idx] == ref["commit_counts"]).all()
+    assert (states[idx] == ref["last_states"]).all()
+    assert (hist[idx] == ref["histories"]).all()
+    assert (res.active_rounds[idx] == ref["active_rounds"]).all()

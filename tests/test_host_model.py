@@ -1,0 +1,57 @@
+"""CPU-only differential test: the compact structural model that the HIP kernels execute
+(librabft_simulator_amd/csrc/lbft_core.h, compiled for the host by oracle/host_model.cpp) must equal the
+full-fidelity oracle -- commit logs, State values, active rounds, event counts by kind, RNG draws and
+creation stamps -- over many seeds and configurations."""
+import numpy as np
+import pytest
+
+CASES = {
+    # BASELINE.json configs[0]: 3 nodes, fixed delay 10 (mean 10, variance 0), ~100 rounds
+    "c1_3nodes_fixed10": (dict(num_nodes=3, mean=10.0, variance=0.0), 32, 2800),
+    # configs[1] shape: 4 nodes f=1, LogNormal(10,4) (primary parity run)
+    "c2_4nodes_lognormal": (dict(num_nodes=4), 256, 1000),
+    "c2_4nodes_uniform": (dict(num_nodes=4, delay_model=1, uniform_lo=5, uniform_hi=15), 128, 1000),
+    "golden_shapes_3": (dict(num_nodes=3), 64, 1000),
+    "golden_shapes_8": (dict(num_nodes=8), 32, 1000),
+    "n1": (dict(num_nodes=1), 4, 300),
+    "n2": (dict(num_nodes=2), 16, 1000),
+    "n16": (dict(num_nodes=16), 4, 400),
+    "epoch_change_cpe50": (dict(num_nodes=4, commands_per_epoch=50), 64, 3000),
+    "epoch_change_cpe5": (dict(num_nodes=3, commands_per_epoch=5), 64, 1500),
+    "weighted": (dict(num_nodes=5, voting_rights=[5, 1, 1, 2, 3]), 64, 1000),
+    "long_tail": (dict(num_nodes=4, mean=10.0, variance=400.0), 128, 2000),
+    "params": (dict(num_nodes=5, gamma=1.5, lambda_=0.25, delta=5, target_commit_interval=80), 64, 1500),
+    "long_run": (dict(num_nodes=4), 16, 8000),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_host_model_equals_oracle(oracle, name):
+    kw, m, max_clock = CASES[name]
+    cfg = oracle.make_config(math_mode=1, **kw)
+    seeds = np.arange(1000, 1000 + m, dtype=np.uint64) * 7919
+    a = oracle.run_batch(cfg, seeds, max_clock, threads=8, history_cap=512)
+    b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=8, history_cap=512, qcap=4096, scap=512, bcap=1024,
+                                   lcap=1024)
+    assert not b["faults"].any()
+    for key in ("commit_counts", "active_rounds", "last_states", "histories"):
+        assert (a[key] == b[key]).all(), key
+    ca, cb = a["counters"], b["counters"]
+    for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
+        assert ca[key] == cb[key], key
+    assert ca["response_inserts"] == 0  # Q1: the premise of payload-free requests/responses
+
+
+def test_capacity_overflow_raises_fault_not_garbage(oracle):
+    cfg = oracle.make_config(num_nodes=4, math_mode=1)
+    seeds = np.arange(1, 9, dtype=np.uint64)
+    b = oracle.hostmodel_run_batch(cfg, seeds, 1000, qcap=16, scap=4, bcap=8, lcap=8)
+    assert (b["faults"] != 0).all()
+
+
+def test_strict_math_equals_libm_mode(oracle):
+    # math_mode 0 (host libm, what the Rust reference calls) and 1 (lbft_math.h, what the GPU runs)
+    seeds = np.arange(1, 257, dtype=np.uint64)
+    a = oracle.run_batch(oracle.make_config(num_nodes=4, math_mode=0), seeds, 1000, threads=8, history_cap=64)
+    b = oracle.run_batch(oracle.make_config(num_nodes=4, math_mode=1), seeds, 1000, threads=8, history_cap=64)
+    assert (a["histories"] == b["histories"]).all() and (a["last_states"] == b["last_states"]).all()

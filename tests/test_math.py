@@ -1,0 +1,43 @@
+"""lbft_math.h (shared by the HIP kernels and the oracle's strict mode) against the host libm."""
+import ctypes
+import math
+
+import numpy as np
+
+
+def test_exp_bit_identical_to_libm(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.uniform(-12, 12, 200000), rng.normal(2.3, 0.2, 200000), [0.0, 1e-300, -1e-20, 700.0, -740.0]])
+    bad = sum(1 for x in xs if L.lbft_oracle_exp_strict(float(x)) != math.exp(float(x)) and abs(x) < 512)
+    assert bad == 0
+
+
+def test_fixed_delay_truncation_quirk_q5(oracle):
+    L = oracle.lib()
+    # `--mean m --variance 0`: delay = trunc(exp(ln m)) -> 10, 19, 49
+    for mean, want in ((10.0, 10), (20.0, 19), (50.0, 49), (100.0, 100), (7.0, 6)):
+        assert int(L.lbft_oracle_exp_strict(math.log(mean))) == want == int(math.exp(math.log(mean)))
+        cfg = oracle.make_config(num_nodes=3, mean=mean, variance=0.0, math_mode=1)
+        out = np.zeros(4, dtype=np.int64)
+        L.lbft_oracle_sample_delays(ctypes.byref(cfg), 1, out.ctypes.data, 4)
+        assert (out == want).all()
+
+
+def test_log_within_one_ulp(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(2)
+    for x in rng.uniform(1e-12, 1.0, 100000):
+        a, b = L.lbft_oracle_log_strict(float(x)), math.log(float(x))
+        assert abs(a - b) <= abs(b) * 2.3e-16
+
+
+def test_delay_streams_agree_between_math_modes(oracle):
+    L = oracle.lib()
+    n = 200000
+    a, b = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+    for var in (4.0, 400.0):
+        L.lbft_oracle_sample_delays(ctypes.byref(oracle.make_config(variance=var, math_mode=0)), 7, a.ctypes.data, n)
+        L.lbft_oracle_sample_delays(ctypes.byref(oracle.make_config(variance=var, math_mode=1)), 7, b.ctypes.data, n)
+        assert (a == b).all()
+        assert abs(a.mean() - 9.5) < 0.3  # E[trunc(LogNormal(10, var))] ~ 9.5
