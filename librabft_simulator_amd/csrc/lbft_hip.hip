@@ -341,7 +341,8 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
   // Capacities (0 = auto).  The queue only ever holds events with time <= max_clock.
   u32 qcap = c.queue_capacity ? c.queue_capacity : (16 * n * n < 128 ? 128 : 16 * n * n);
   u32 scap = c.snapshot_capacity ? c.snapshot_capacity : (8 * n < 32 ? 32 : 8 * n);
-  u64 bauto = (u64)max_clock / 10 + 64;
+  // one block per round; a 1- or 2-node network can finish a round per time unit
+  u64 bauto = n <= 2 ? (u64)max_clock + 64 : (u64)max_clock / 10 + 64;
   u32 bcap = c.block_capacity ? c.block_capacity : (u32)(bauto > 65534 ? 65534 : bauto);
   if (bcap > 65534 || scap > 65535 || n > 255) { g_err = "capacity out of range"; return LBFT_ERR_INVALID; }
   u32 lcap = c.log_capacity ? c.log_capacity : bcap;
