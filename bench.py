@@ -29,6 +29,7 @@ def parse():
     ap.add_argument("--nodes", type=int, default=4)
     ap.add_argument("--max-clock", type=int, default=1000)
     ap.add_argument("--base-seed", type=int, default=1)
+    ap.add_argument("--lpw", type=int, default=0, help="lanes per wavefront carrying an instance (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the oracle sample")
     return ap.parse_args()
@@ -91,7 +92,7 @@ def main():
     m = args.instances
     first = args.base_seed + rank * m  # seed_i = base_seed + global instance index
     seeds = np.arange(first, first + m, dtype=np.uint64)
-    sim = BatchSimulator.new(seeds, args.nodes, RandomDelay.new(10.0, 4.0), NodeConfig(), device=local_rank)
+    sim = BatchSimulator.new(seeds, args.nodes, RandomDelay.new(10.0, 4.0), NodeConfig(), device=local_rank, lanes_per_wavefront=args.lpw)
 
     def barrier():
         if dist is not None:

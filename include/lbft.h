@@ -129,6 +129,8 @@ int lbft_batch_last_run_ms(const lbft_batch* b, float* init_ms, float* run_ms);
 size_t lbft_batch_device_bytes(const lbft_batch* b);
 /* Events processed per run-kernel launch (0 = whole simulation in one launch). */
 int lbft_batch_set_max_steps(lbft_batch* b, uint32_t max_steps);
+/* Tuning: how many of a wavefront's 64 lanes carry an instance (0 = auto from the batch size). Results do not depend on it. */
+int lbft_batch_set_lanes_per_wavefront(lbft_batch* b, uint32_t lanes);
 
 /* Stand-alone device checks of the third-party arithmetic (tests): each runs a tiny kernel.
  *   leaders: out[r] = PacemakerState::leader(round r) (pacemaker.rs:100-109) for r < n_rounds

@@ -73,7 +73,7 @@ ABI_SYMBOLS = [
     "lbft_batch_active_rounds", "lbft_batch_committed_history", "lbft_batch_committed_histories",
     "lbft_batch_last_committed_states", "lbft_batch_startup_times", "lbft_batch_epochs", "lbft_batch_counters",
     "lbft_batch_faults", "lbft_batch_destroy", "lbft_batch_stream", "lbft_batch_last_run_ms",
-    "lbft_batch_device_bytes", "lbft_batch_set_max_steps", "lbft_device_leaders", "lbft_device_sample_delays",
+    "lbft_batch_device_bytes", "lbft_batch_set_max_steps", "lbft_batch_set_lanes_per_wavefront", "lbft_device_leaders", "lbft_device_sample_delays",
     "lbft_device_exp_log", "lbft_last_error", "lbft_build_info",
 ]
 
@@ -123,6 +123,8 @@ def lib():
     L.lbft_batch_device_bytes.restype = C.c_size_t
     L.lbft_batch_set_max_steps.argtypes = [vp, C.c_uint32]
     L.lbft_batch_set_max_steps.restype = C.c_int
+    L.lbft_batch_set_lanes_per_wavefront.argtypes = [vp, C.c_uint32]
+    L.lbft_batch_set_lanes_per_wavefront.restype = C.c_int
     L.lbft_device_leaders.argtypes = [C.c_int, vp, C.c_uint32, vp, C.c_uint32]
     L.lbft_device_leaders.restype = C.c_int
     L.lbft_device_sample_delays.argtypes = [C.c_int, C.POINTER(LbftConfig), C.c_uint64, vp, C.c_size_t]

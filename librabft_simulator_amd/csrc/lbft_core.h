@@ -81,6 +81,7 @@ struct Params {
   u32 off_log;
   u32 total_words;
   u32 max_steps;  // events per instance per launch (0 = unlimited)
+  u32 lpw;        // lanes of each wavefront that carry an instance (1..64): occupancy vs lane-utilisation knob
 };
 
 // Instance-level rows.
@@ -101,6 +102,7 @@ enum NodeField : u32 {
   NF_PM_EPOCH, NF_PM_ROUND, NF_PM_LEADER, NF_PM_START, NF_PM_DUR_LO, NF_PM_DUR_HI,
   NF_LVR, NF_LOCKED, NF_LQAT, NF_TR_EPOCH, NF_TR_HCR, NF_TR_LCT,
   NF_NEXT_CMD, NF_LAST_COMMITTED_BLK, NF_NCOMMITS,
+  NF_LAST_TIMER_T, NF_TIMER_DUPS,  // duplicate-timer folding (see process_node_actions)
   NF_FIXED_WORDS  // followed by tc_hcbr[n] and to_hcbr[n]
 };
 
@@ -752,7 +754,18 @@ struct Sim {
     i64 ign = t_new - 1;
     if (ign > (i64)P.max_clock) ign = P.max_clock;  // only ever compared with clock <= max_clock
     nfs(node, NF_IGNORE_UNTIL, (u32)(i32)ign);
-    push_event(t_new, 3, node, 0, 0);
+    // Duplicate-timer folding.  A second UpdateTimerEvent for the same (node, time) is always a no-op in
+    // the reference: all timers of one time pop consecutively (kind 3 sorts first, simulator.rs:149-161)
+    // and the first one either fires -- which moves ignore_scheduled_updates_until to >= clock -- or is
+    // itself cancelled, and then so are the others.  So if the node's previously scheduled timer has the
+    // same time (it is still pending: that time is > clock), only count the duplicate.
+    if (t_new <= (i64)P.max_clock && (u32)t_new == nf(node, NF_LAST_TIMER_T)) {
+      nfs(node, NF_TIMER_DUPS, nf(node, NF_TIMER_DUPS) + 1);
+      stamp++;
+    } else {
+      if (t_new <= (i64)P.max_clock) { nfs(node, NF_LAST_TIMER_T, (u32)t_new); }
+      push_event(t_new, 3, node, 0, 0);
+    }
     // receivers, packed 4 bits each (n <= 16) or walked directly
     u32 list[LBFT_MAX_NODES];
     u32 cnt = 0;
@@ -803,6 +816,7 @@ struct Sim {
       for (u32 f = 0; f < P.node_words; f++) nfs(node, f, 0);
       nfs(node, NF_CUR_ROUND, 1);
       nfs(node, NF_PM_LEADER, LBFT_NO_LEADER);
+      nfs(node, NF_LAST_TIMER_T, 0xffffffffu);
       i64 startup = 0 + sample_delay() + 1;
       if (startup > (i64)P.max_clock + 1) startup = (i64)P.max_clock + 1;  // node never starts; equivalent
       nfs(node, NF_STARTUP, (u32)(i32)startup);
@@ -827,6 +841,11 @@ struct Sim {
       bool do_update = true, sync = false;
       if (kind == 3) {  // UpdateTimerEvent (simulator.rs:403-415)
         ev3++;
+        if ((u32)clock == nf(node, NF_LAST_TIMER_T)) {  // folded duplicates of this timer
+          ev3 += nf(node, NF_TIMER_DUPS);
+          nfs(node, NF_TIMER_DUPS, 0);
+          nfs(node, NF_LAST_TIMER_T, 0xffffffffu);
+        }
         if (clock <= (i32)nf(node, NF_IGNORE_UNTIL)) do_update = false;  // cancelled timer
       } else if (kind == 0) {  // DataSyncNotifyEvent (simulator.rs:416-440)
         ev0++;

@@ -28,16 +28,19 @@ static_assert(LBFT_MAX_NODES == LBFT_MAX_NODES_SUPPORTED, "header mismatch");
 
 // Simulator::new for every instance (simulator.rs:200-250).
 __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restrict__ state, const u64* __restrict__ seeds) {
-  u32 i = blockIdx.x * LBFT_BLOCK + threadIdx.x;
-  if (i >= p.m) return;
+  u32 i = blockIdx.x * p.lpw + threadIdx.x;
+  if (threadIdx.x >= p.lpw || i >= p.m) return;
   Sim s(p, state + i);
   s.init(seeds[i]);
 }
 
 // Simulator::loop_until for every instance (simulator.rs:380-475).
 __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_run(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) {
-  u32 i = blockIdx.x * LBFT_BLOCK + threadIdx.x;
-  bool active = i < p.m;
+  // Only the first p.lpw lanes of a wavefront carry an instance: the step is a long chain of dependent
+  // memory accesses, so with few instances per GPU it pays to trade idle lanes for more resident
+  // wavefronts per SIMD (latency hiding) and less intra-wavefront divergence.
+  u32 i = blockIdx.x * p.lpw + threadIdx.x;
+  bool active = threadIdx.x < p.lpw && i < p.m;
   bool done = true;
   if (active) {
     Sim s(p, state + i);
@@ -195,6 +198,7 @@ struct lbft_batch {
   Params p;
   bool ran = false;
   u32 max_steps = 0;
+  u32 lpw = 0;  // 0 = auto
   float init_ms = 0, run_ms = 0;
   lbft_counters counters;
   size_t table_bytes = 0;
@@ -324,6 +328,12 @@ int lbft_batch_set_max_steps(lbft_batch* b, uint32_t max_steps) {
   return LBFT_OK;
 }
 
+int lbft_batch_set_lanes_per_wavefront(lbft_batch* b, uint32_t lanes) {
+  if (!b || lanes > 64) return LBFT_ERR_INVALID;
+  b->lpw = lanes;
+  return LBFT_OK;
+}
+
 int lbft_batch_reset(lbft_batch* b) {
   if (!b) return LBFT_ERR_INVALID;
   b->ran = false;
@@ -356,7 +366,16 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
     b->state_bytes = (size_t)p.total_words * p.stride * sizeof(u32);
     HIP_TRY(hipMalloc(&b->d_state, b->state_bytes));
   }
-  u32 grid = (u32)((b->m + LBFT_BLOCK - 1) / LBFT_BLOCK);
+  // lanes per wavefront: aim at ~3 resident wavefronts on each of the 1024 SIMDs (the run kernel's
+  // register budget), never fewer than 8 lanes so that row accesses stay >= 32 contiguous bytes
+  u32 lpw = b->lpw;
+  if (lpw == 0) {
+    u64 want = (b->m + 3071) / 3072;
+    lpw = want < 8 ? 8 : (want > 64 ? 64 : (u32)want);
+  }
+  p.lpw = lpw;
+  u32 grid_full = (u32)((b->m + LBFT_BLOCK - 1) / LBFT_BLOCK);
+  u32 grid = (u32)((b->m + lpw - 1) / lpw);
   HIP_TRY(hipEventRecord(b->ev0, b->stream));
   lbft_k_init<<<grid, LBFT_BLOCK, 0, b->stream>>>(p, b->d_state, b->d_seeds);
   HIP_TRY(hipGetLastError());
@@ -375,7 +394,7 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
   }
   HIP_TRY(hipEventRecord(b->ev2, b->stream));
   HIP_TRY(hipMemsetAsync(b->d_counters, 0, C_WORDS * sizeof(unsigned long long), b->stream));
-  lbft_k_finalize<<<grid, LBFT_BLOCK, 0, b->stream>>>(p, b->d_state, b->d_states_out, b->d_counters);
+  lbft_k_finalize<<<grid_full, LBFT_BLOCK, 0, b->stream>>>(p, b->d_state, b->d_states_out, b->d_counters);
   HIP_TRY(hipGetLastError());
   unsigned long long hc[C_WORDS];
   HIP_TRY(hipMemcpyAsync(hc, b->d_counters, sizeof(hc), hipMemcpyDeviceToHost, b->stream));

@@ -193,7 +193,7 @@ class BatchSimulator:
 
     def __init__(self, rng_seeds, num_nodes, network_delay, node_config=None, commands_per_epoch=30000,
                  voting_rights=None, device=0, queue_capacity=0, snapshot_capacity=0, block_capacity=0,
-                 log_capacity=0, max_steps_per_launch=0):
+                 log_capacity=0, max_steps_per_launch=0, lanes_per_wavefront=0):
         seeds = np.ascontiguousarray(rng_seeds, dtype=np.uint64)
         self.seeds = seeds
         self.num_instances = int(seeds.shape[0])
@@ -206,6 +206,8 @@ class BatchSimulator:
                                            C.byref(self._h)))
         if max_steps_per_launch:
             check(_lib.lib().lbft_batch_set_max_steps(self._h, max_steps_per_launch))
+        if lanes_per_wavefront:
+            check(_lib.lib().lbft_batch_set_lanes_per_wavefront(self._h, lanes_per_wavefront))
 
     @classmethod
     def new(cls, rng_seeds, num_nodes, network_delay, node_config=None, **kw):
