@@ -269,8 +269,34 @@ struct Sim {
 
   // ---- field accessors ----
   LBFT_HD u32 nfw(u32 node, u32 f) const { return P.off_node + node * P.node_words + f; }
-  LBFT_HD u32 nf(u32 node, u32 f) const { return ld(nfw(node, f)); }
-  LBFT_HD void nfs(u32 node, u32 f, u32 v) const { st(nfw(node, f), v); }
+  // direct (memory) access to any node's rows
+  LBFT_HD u32 nfm(u32 node, u32 f) const { return ld(nfw(node, f)); }
+  LBFT_HD void nfms(u32 node, u32 f, u32 v) const { st(nfw(node, f), v); }
+  // Every event touches exactly one node.  Its fixed rows are staged in registers by begin_node()
+  // (one burst of independent loads instead of a chain of dependent ones: the compiler cannot
+  // reorder row loads across row stores) and the modified ones are written back by end_node().
+  // `f` is a compile-time constant at every call site, so cw[] lives in VGPRs.
+  mutable u32 cw[NF_FIXED_WORDS];
+  mutable u64 cdirty;
+  LBFT_HD u32 nf(u32 node, u32 f) const { return f < NF_FIXED_WORDS ? cw[f] : ld(nfw(node, f)); }
+  LBFT_HD void nfs(u32 node, u32 f, u32 v) const {
+    if (f < NF_FIXED_WORDS) { cw[f] = v; cdirty |= 1ULL << f; }
+    else st(nfw(node, f), v);
+  }
+  LBFT_HD void begin_node(u32 node) const {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 f = 0; f < NF_FIXED_WORDS; f++) cw[f] = ld(nfw(node, f));
+    cdirty = 0;
+  }
+  LBFT_HD void end_node(u32 node) const {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 f = 0; f < NF_FIXED_WORDS; f++)
+      if ((cdirty >> f) & 1ULL) st(nfw(node, f), cw[f]);
+  }
   LBFT_HD u32 bfw(u32 b, u32 f) const { return P.off_blk + (b - 1) * P.blk_words + f; }
   LBFT_HD u32 bf(u32 b, u32 f) const { return ld(bfw(b, f)); }
   LBFT_HD void bfs(u32 b, u32 f, u32 v) const { st(bfw(b, f), v); }
@@ -459,16 +485,27 @@ struct Sim {
     u32 a0 = nf(node, NF_BAL0_AUTHORS), a1 = nf(node, NF_BAL1_AUTHORS);
     if (((a0 | a1) >> author) & 1u) return;  // one vote per author
     u32 b0 = nf(node, NF_BAL0_BLK), b1 = nf(node, NF_BAL1_BLK);
-    u32 fb, fw, fa;
-    if (b0 == b || b0 == 0) { fb = NF_BAL0_BLK; fw = NF_BAL0_WEIGHT; fa = NF_BAL0_AUTHORS; }
-    else if (b1 == b || b1 == 0) { fb = NF_BAL1_BLK; fw = NF_BAL1_WEIGHT; fa = NF_BAL1_AUTHORS; }
-    else { fault |= F_BALLOT_OVERFLOW; return; }
-    nfs(node, fb, b);
-    nfs(node, fa, nf(node, fa) | (1u << author));
-    if ((nf(node, NF_ELECTION) & 0xff) == 0) {
-      u32 w = nf(node, fw) + P.weights[author];
-      nfs(node, fw, w);
-      if (w >= P.quorum) nfs(node, NF_ELECTION, 1u | (b << 8));
+    bool ongoing = (nf(node, NF_ELECTION) & 0xff) == 0;
+    // two ballot entries (block, weight, authors); field indices stay compile-time constants so that
+    // the node cache remains in registers
+    if (b0 == b || b0 == 0) {
+      nfs(node, NF_BAL0_BLK, b);
+      nfs(node, NF_BAL0_AUTHORS, a0 | (1u << author));
+      if (ongoing) {
+        u32 w = nf(node, NF_BAL0_WEIGHT) + P.weights[author];
+        nfs(node, NF_BAL0_WEIGHT, w);
+        if (w >= P.quorum) nfs(node, NF_ELECTION, 1u | (b << 8));
+      }
+    } else if (b1 == b || b1 == 0) {
+      nfs(node, NF_BAL1_BLK, b);
+      nfs(node, NF_BAL1_AUTHORS, a1 | (1u << author));
+      if (ongoing) {
+        u32 w = nf(node, NF_BAL1_WEIGHT) + P.weights[author];
+        nfs(node, NF_BAL1_WEIGHT, w);
+        if (w >= P.quorum) nfs(node, NF_ELECTION, 1u | (b << 8));
+      }
+    } else {
+      fault |= F_BALLOT_OVERFLOW;
     }
   }
   // Timeout (record_store.rs:390-415,527-538).  Caller checked the epoch.
@@ -480,12 +517,12 @@ struct Sim {
     if ((mask >> author) & 1u) return;
     mask |= 1u << author;
     nfs(node, NF_TO_MASK, mask);
-    nfs(node, NF_FIXED_WORDS + P.n + author, hcbr);
+    nfms(node, NF_FIXED_WORDS + P.n + author, hcbr);
     u32 w = nf(node, NF_TO_WEIGHT) + P.weights[author];
     nfs(node, NF_TO_WEIGHT, w);
     if (w >= P.quorum) {
       nfs(node, NF_TC_MASK, mask);
-      for (u32 a = 0; a < P.n; a++) nfs(node, NF_FIXED_WORDS + a, nf(node, NF_FIXED_WORDS + P.n + a));
+      for (u32 a = 0; a < P.n; a++) nfms(node, NF_FIXED_WORDS + a, nfm(node, NF_FIXED_WORDS + P.n + a));
       nfs(node, NF_HTC_ROUND, cur);
       update_current_round(node, cur + 1);
     }
@@ -704,8 +741,8 @@ struct Sim {
     st(sfw(slot, S_TO_ROUND), nf(node, NF_CUR_ROUND));
     st(sfw(slot, S_TC_MASK), tcm);
     st(sfw(slot, S_TO_MASK), tom);
-    for (u32 m = tcm; m;) { u32 a = ctz32(m); m &= m - 1; st(sfw(slot, S_FIXED_WORDS + a), nf(node, NF_FIXED_WORDS + a)); }
-    for (u32 m = tom; m;) { u32 a = ctz32(m); m &= m - 1; st(sfw(slot, S_FIXED_WORDS + P.n + a), nf(node, NF_FIXED_WORDS + P.n + a)); }
+    for (u32 m = tcm; m;) { u32 a = ctz32(m); m &= m - 1; st(sfw(slot, S_FIXED_WORDS + a), nfm(node, NF_FIXED_WORDS + a)); }
+    for (u32 m = tom; m;) { u32 a = ctz32(m); m &= m - 1; st(sfw(slot, S_FIXED_WORDS + P.n + a), nfm(node, NF_FIXED_WORDS + P.n + a)); }
   }
 
   // ---- DataSyncNode::handle_notification (data_sync.rs:113-177); returns should_sync ----
@@ -813,14 +850,14 @@ struct Sim {
     for (u32 s = 0; s < P.scap; s++) { st(P.off_snap_free + s, P.scap - 1 - s); st(P.off_snap_ref + s, 0); }
     rng.seed(seed);
     for (u32 node = 0; node < P.n; node++) {
-      for (u32 f = 0; f < P.node_words; f++) nfs(node, f, 0);
-      nfs(node, NF_CUR_ROUND, 1);
-      nfs(node, NF_PM_LEADER, LBFT_NO_LEADER);
-      nfs(node, NF_LAST_TIMER_T, 0xffffffffu);
+      for (u32 f = 0; f < P.node_words; f++) nfms(node, f, 0);
+      nfms(node, NF_CUR_ROUND, 1);
+      nfms(node, NF_PM_LEADER, LBFT_NO_LEADER);
+      nfms(node, NF_LAST_TIMER_T, 0xffffffffu);
       i64 startup = 0 + sample_delay() + 1;
       if (startup > (i64)P.max_clock + 1) startup = (i64)P.max_clock + 1;  // node never starts; equivalent
-      nfs(node, NF_STARTUP, (u32)(i32)startup);
-      nfs(node, NF_IGNORE_UNTIL, (u32)(i32)(startup - 1));
+      nfms(node, NF_STARTUP, (u32)(i32)startup);
+      nfms(node, NF_IGNORE_UNTIL, (u32)(i32)(startup - 1));
       push_event(startup, 3, node, 0, 0);
     }
     store_scalars(false);
@@ -841,14 +878,16 @@ struct Sim {
       bool do_update = true, sync = false;
       if (kind == 3) {  // UpdateTimerEvent (simulator.rs:403-415)
         ev3++;
-        if ((u32)clock == nf(node, NF_LAST_TIMER_T)) {  // folded duplicates of this timer
-          ev3 += nf(node, NF_TIMER_DUPS);
-          nfs(node, NF_TIMER_DUPS, 0);
-          nfs(node, NF_LAST_TIMER_T, 0xffffffffu);
+        if ((u32)clock == nfm(node, NF_LAST_TIMER_T)) {  // folded duplicates of this timer
+          ev3 += nfm(node, NF_TIMER_DUPS);
+          nfms(node, NF_TIMER_DUPS, 0);
+          nfms(node, NF_LAST_TIMER_T, 0xffffffffu);
         }
-        if (clock <= (i32)nf(node, NF_IGNORE_UNTIL)) do_update = false;  // cancelled timer
+        if (clock <= (i32)nfm(node, NF_IGNORE_UNTIL)) do_update = false;  // cancelled timer
+        else begin_node(node);
       } else if (kind == 0) {  // DataSyncNotifyEvent (simulator.rs:416-440)
         ev0++;
+        begin_node(node);
         sync = handle_notification(node, sender, slot);
         snap_release(slot);
       } else if (kind == 1) {  // DataSyncRequestEvent (simulator.rs:441-453)
@@ -858,11 +897,13 @@ struct Sim {
         do_update = false;
       } else {  // DataSyncResponseEvent (simulator.rs:454-466): handle_response inserts nothing (Q1)
         ev2++;
+        begin_node(node);
       }
       if (do_update) {
         Actions a = node_update(node);
         if (sync) push_event((i64)clock + sample_delay(), 1, node, sender, 0);
         process_node_actions(node, a);
+        end_node(node);
       }
     }
   }

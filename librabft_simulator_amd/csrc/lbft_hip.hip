@@ -77,8 +77,8 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_finalize(Params p, const u3
     Sim s(p, const_cast<u32*>(state) + i);
     u64 min_round = ~0ULL, min_commits = ~0ULL;
     for (u32 n = 0; n < p.n; n++) {
-      u32 nc = s.nf(n, NF_NCOMMITS);
-      u64 ar = s.nf(n, NF_PM_ROUND);
+      u32 nc = s.nfm(n, NF_NCOMMITS);
+      u64 ar = s.nfm(n, NF_PM_ROUND);
       min_round = ar < min_round ? ar : min_round;
       min_commits = nc < min_commits ? nc : min_commits;
       Sip13 h;
@@ -126,7 +126,7 @@ __global__ void lbft_k_export_histories(Params p, const u32* __restrict__ state,
   if (t >= n_inst * p.n) return;
   u32 n = t / n_inst, i = first_inst + t % n_inst;
   Sim s(p, const_cast<u32*>(state) + i);
-  u32 nc = s.nf(n, NF_NCOMMITS);
+  u32 nc = s.nfm(n, NF_NCOMMITS);
   lbft_commit* o = out + ((size_t)(i - first_inst) * p.n + n) * cap;
   for (u32 k = 0; k < nc && k < cap; k++) {
     u32 b = s.ld(p.off_log + n * p.lcap + k);

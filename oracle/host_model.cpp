@@ -85,8 +85,8 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
     u64 min_round = UINT64_MAX, min_commits = UINT64_MAX;
     for (u32 n = 0; n < p.n; n++) {
       size_t o = i * p.n + n;
-      u32 nc = s.nf(n, NF_NCOMMITS);
-      u64 ar = s.nf(n, NF_PM_ROUND);
+      u32 nc = s.nfm(n, NF_NCOMMITS);
+      u64 ar = s.nfm(n, NF_PM_ROUND);
       if (commit_counts) commit_counts[o] = nc;
       if (active_rounds) active_rounds[o] = ar;
       min_round = ar < min_round ? ar : min_round;
