@@ -89,9 +89,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from librabft_simulator_amd import BatchSimulator, NodeConfig, RandomDelay
-    m = args.instances
-    first = args.base_seed + rank * m  # seed_i = base_seed + global instance index
-    seeds = np.arange(first, first + m, dtype=np.uint64)
+    from librabft_simulator_amd.distributed import shard_seeds
+    m = args.instances  # per GPU (weak scaling); seed_i = base_seed + global instance index
+    seeds = shard_seeds(args.base_seed, m * world, rank, world)
     sim = BatchSimulator.new(seeds, args.nodes, RandomDelay.new(10.0, 4.0), NodeConfig(), device=local_rank, lanes_per_wavefront=args.lpw)
 
     def barrier():
