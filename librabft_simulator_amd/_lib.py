@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liblbft_hip.so")
+# LBFT_HIP_LIB selects another in-tree build of the same sources (e.g. the phase-timer diagnostic build)
+LIB_PATH = os.environ.get("LBFT_HIP_LIB") or os.path.join(HERE, "liblbft_hip.so")
 
 LBFT_OK = 0
 LBFT_ERR_INVALID = -1
@@ -73,7 +74,8 @@ ABI_SYMBOLS = [
     "lbft_batch_active_rounds", "lbft_batch_committed_history", "lbft_batch_committed_histories",
     "lbft_batch_last_committed_states", "lbft_batch_startup_times", "lbft_batch_epochs", "lbft_batch_counters",
     "lbft_batch_faults", "lbft_batch_destroy", "lbft_batch_stream", "lbft_batch_last_run_ms",
-    "lbft_batch_device_bytes", "lbft_batch_set_max_steps", "lbft_batch_set_lanes_per_wavefront", "lbft_device_leaders", "lbft_device_sample_delays",
+    "lbft_batch_device_bytes", "lbft_batch_set_max_steps", "lbft_batch_set_lanes_per_wavefront",
+    "lbft_batch_set_lds_queue_slots", "lbft_batch_phase_cycles", "lbft_device_leaders", "lbft_device_sample_delays",
     "lbft_device_exp_log", "lbft_last_error", "lbft_build_info",
 ]
 
@@ -125,6 +127,10 @@ def lib():
     L.lbft_batch_set_max_steps.restype = C.c_int
     L.lbft_batch_set_lanes_per_wavefront.argtypes = [vp, C.c_uint32]
     L.lbft_batch_set_lanes_per_wavefront.restype = C.c_int
+    L.lbft_batch_set_lds_queue_slots.argtypes = [vp, C.c_int32]
+    L.lbft_batch_set_lds_queue_slots.restype = C.c_int
+    L.lbft_batch_phase_cycles.argtypes = [vp, vp]
+    L.lbft_batch_phase_cycles.restype = C.c_int
     L.lbft_device_leaders.argtypes = [C.c_int, vp, C.c_uint32, vp, C.c_uint32]
     L.lbft_device_leaders.restype = C.c_int
     L.lbft_device_sample_delays.argtypes = [C.c_int, C.POINTER(LbftConfig), C.c_uint64, vp, C.c_size_t]

@@ -41,5 +41,16 @@ def build(force=False, verbose=False):
     return OUT
 
 
+def build_variant(tag, defines, verbose=False):
+    """Diagnostic / tuning builds of the same sources (e.g. ("prof", ["-DLBFT_PHASE_TIMERS"])): written next to
+    the product library as liblbft_hip_<tag>.so and selected with LBFT_HIP_LIB=<path>."""
+    out = os.path.join(HERE, "liblbft_hip_%s.so" % tag)
+    cmd = [hipcc_path()] + HIPCC_FLAGS + list(defines) + [SRC, "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

@@ -82,7 +82,36 @@ struct Params {
   u32 total_words;
   u32 max_steps;  // events per instance per launch (0 = unlimited)
   u32 lpw;        // lanes of each wavefront that carry an instance (1..64): occupancy vs lane-utilisation knob
+  u32 ql;         // event-queue slots per instance that live in LDS (slots >= ql spill to the HBM rows)
+  unsigned long long* prof;  // LBFT_PHASE_TIMERS builds only: cycles per phase of the event loop, summed over wavefronts
 };
+
+// Phase timers (diagnostic builds: -DLBFT_PHASE_TIMERS): s_memtime deltas accumulated per phase of the
+// event loop, so that one GPU run tells where a wavefront's time goes.  No-ops in product builds.
+#define LBFT_NPHASES 32  // [0..29] phases, [30] wavefront loop iterations, [31] last mark (device scratch) / total cycles (host view)
+#if defined(LBFT_PHASE_TIMERS) && defined(__HIPCC__)
+// Wavefront-level attribution: the first active lane at the mark charges the time since the wavefront's
+// previous mark (kept in LDS, wprof[31]) to phase k -- whichever lanes are diverged away at that point.
+#define LBFT_MARK(k) do { if (__builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0)) == 0) { \
+    u64 now_ = __builtin_readcyclecounter(); wprof[k] += now_ - wprof[31]; wprof[31] = now_; } } while (0)
+#define LBFT_COUNT(k) do { if (__builtin_amdgcn_mbcnt_hi(__builtin_amdgcn_read_exec_hi(), __builtin_amdgcn_mbcnt_lo(__builtin_amdgcn_read_exec_lo(), 0)) == 0) wprof[k] += 1; } while (0)
+#define LBFT_DRAIN_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70) /* vmcnt(0): attribute the memory drain to the phase that caused it */
+#else
+#define LBFT_DRAIN_VMEM() do { } while (0)
+#define LBFT_MARK(k) do { } while (0)
+#define LBFT_COUNT(k) do { } while (0)
+#endif
+
+// HBM layout: instances are grouped in tiles of 64 (one wavefront's worth); a tile is contiguous and holds
+// its rows word-interleaved: word w of instance i lives at state[(i / 64) * total_words * 64 + w * 64 + i % 64].
+// A wavefront's 64 lanes read row w as one 256-byte segment, and everything a wavefront ever touches sits
+// in one contiguous ~1 MB window (TLB- and DRAM-page-friendly), instead of one row per 256 KB.
+// (-DLBFT_ROW_MAJOR keeps the first layout -- row w of ALL instances contiguous -- for A/B measurements.)
+#if defined(LBFT_ROW_MAJOR)
+#define LBFT_ROW_STRIDE(P) ((P).stride)
+#else
+#define LBFT_ROW_STRIDE(P) 64u
+#endif
 
 // Instance-level rows.
 enum InstField : u32 {
@@ -106,8 +135,18 @@ enum NodeField : u32 {
   NF_FIXED_WORDS  // followed by tc_hcbr[n] and to_hcbr[n]
 };
 
-// Block rows.
-enum BlockField : u32 { B_ROUND = 0, B_LINK /* prev | author << 16 */, B_TIME, B_CMD, B_DEPTH, B_EPOCH, B_KNOWN, B_QC, B_PEND, B_WORDS };
+// Block rows.  The first BC_WORDS rows are the "hot record" that the event loop works on (held in a small
+// register-resident cache, see Sim::blk_get): the block's round and links, the rounds of its parent and
+// grandparent (denormalised at proposal time, so the 3-chain commit rule record_store.rs:221-235 and the
+// voting constraints node.rs:256-276 need one record instead of a pointer chase through three), the
+// epoch, and the three per-node knowledge masks.  B_TIME / B_CMD / B_DEPTH are only read when a block is
+// proposed on top of this one, committed, or exported.
+enum BlockField : u32 {
+  B_ROUND = 0, B_LINK /* prev | author << 16 */, B_PREV_ROUND, B_PP /* grandparent block id */, B_PP_ROUND, B_EPOCH,
+  B_KNOWN, B_QC, B_PEND, BC_WORDS,
+  B_TIME = BC_WORDS, B_CMD, B_DEPTH, B_WORDS
+};
+#define LBFT_BLK_CACHE 6  // register-resident block records per instance (FIFO)
 
 // Snapshot (notification, data_sync.rs:16-39) rows; followed by tc_hcbr[n], to_hcbr[n].
 enum SnapField : u32 { S_EPOCH = 0, S_CERTS /* hcc | hqc << 16 */, S_PROP_VOTE /* proposed | vote << 16 */, S_TC_ROUND, S_TO_ROUND, S_TC_MASK, S_TO_MASK, S_FIXED_WORDS };
@@ -243,6 +282,16 @@ LBFT_HD u32 compute_leader(const u32* weights, u32 n, u32 total_votes, u64 round
   return 0;  // unreachable
 }
 
+// Word offset of instance i's column (row 0) in the state array.
+#if defined(LBFT_ROW_MAJOR)
+LBFT_HD size_t inst_offset(const Params& p, u32 i) { (void)p; return i; }
+LBFT_HD size_t state_words(const Params& p) { return (size_t)p.total_words * p.stride; }
+#else
+LBFT_HD size_t inst_offset(const Params& p, u32 i) { return (size_t)(i >> 6) * p.total_words * 64u + (i & 63u); }
+LBFT_HD size_t state_words(const Params& p) { return (size_t)p.total_words * p.stride; }  // stride = m padded to 64
+#endif
+LBFT_HD size_t word_offset(const Params& p, u32 i, u32 w) { return inst_offset(p, i) + (size_t)w * LBFT_ROW_STRIDE(p); }
+
 struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at most one element
   i64 next;
   i32 send_to;  // -1 = none
@@ -262,10 +311,24 @@ struct Sim {
   u32 ev0, ev1, ev2, ev3;
   Rng rng;
 
-  LBFT_HD Sim(const Params& p, u32* r) : P(p), row0(r) {}
+  // Front of the event queue: slots [0, ql) live in LDS on the device (lane-private column: element k of
+  // this instance is qk[k * qstr], so any per-lane slot index is bank-conflict free); slots >= ql spill to
+  // the HBM rows.  The host build (oracle/host_model.cpp) passes plain arrays.  ql == 0: HBM rows only.
+  u64* qk;
+  u32* qm;
+  u32 qstr, ql;
+  // read-only tables (LDS copies on the device)
+  const u64 *zig_x, *zig_f, *exp_tab;
+#if defined(LBFT_PHASE_TIMERS) && defined(__HIPCC__)
+  u64* wprof;  // this wavefront's LDS accumulators
+#endif
 
-  LBFT_HD u32 ld(u32 w) const { return row0[(size_t)w * P.stride]; }
-  LBFT_HD void st(u32 w, u32 v) const { row0[(size_t)w * P.stride] = v; }
+  LBFT_HD Sim(const Params& p, u32* r) : P(p), row0(r), qk(nullptr), qm(nullptr), qstr(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab) {}
+  LBFT_HD void attach_queue(u64* keys, u32* metas, u32 stride, u32 slots) { qk = keys; qm = metas; qstr = stride; ql = slots; }
+  LBFT_HD void attach_tables(const u64* zx, const u64* zf, const u64* et) { zig_x = zx; zig_f = zf; exp_tab = et; }
+
+  LBFT_HD u32 ld(u32 w) const { return row0[(size_t)w * LBFT_ROW_STRIDE(P)]; }
+  LBFT_HD void st(u32 w, u32 v) const { row0[(size_t)w * LBFT_ROW_STRIDE(P)] = v; }
 
   // ---- field accessors ----
   LBFT_HD u32 nfw(u32 node, u32 f) const { return P.off_node + node * P.node_words + f; }
@@ -284,28 +347,108 @@ struct Sim {
     else st(nfw(node, f), v);
   }
   LBFT_HD void begin_node(u32 node) const {
+    // one base pointer, then constant row offsets: the 38 loads become one burst with immediate offsets
+    const u32* nb = row0 + (size_t)(P.off_node + node * P.node_words) * LBFT_ROW_STRIDE(P);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (u32 f = 0; f < NF_FIXED_WORDS; f++) cw[f] = ld(nfw(node, f));
+    for (u32 f = 0; f < NF_FIXED_WORDS; f++) cw[f] = nb[(size_t)f * LBFT_ROW_STRIDE(P)];
     cdirty = 0;
   }
   LBFT_HD void end_node(u32 node) const {
+    u32* nb = row0 + (size_t)(P.off_node + node * P.node_words) * LBFT_ROW_STRIDE(P);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (u32 f = 0; f < NF_FIXED_WORDS; f++)
-      if ((cdirty >> f) & 1ULL) st(nfw(node, f), cw[f]);
+      if ((cdirty >> f) & 1ULL) nb[(size_t)f * LBFT_ROW_STRIDE(P)] = cw[f];
   }
   LBFT_HD u32 bfw(u32 b, u32 f) const { return P.off_blk + (b - 1) * P.blk_words + f; }
-  LBFT_HD u32 bf(u32 b, u32 f) const { return ld(bfw(b, f)); }
+  LBFT_HD u32 bf(u32 b, u32 f) const { return ld(bfw(b, f)); }   // cold fields (B_TIME, B_CMD, B_DEPTH) and read-back
   LBFT_HD void bfs(u32 b, u32 f, u32 v) const { st(bfw(b, f), v); }
-  LBFT_HD u32 blk_prev(u32 b) const { return bf(b, B_LINK) & 0xffffu; }
   LBFT_HD u32 blk_author(u32 b) const { return bf(b, B_LINK) >> 16; }
-  LBFT_HD u32 blk_round(u32 b) const { return bf(b, B_ROUND); }
-  LBFT_HD bool bit(u32 b, u32 f, u32 node) const { return (bf(b, f) >> node) & 1u; }
-  LBFT_HD void set_bit(u32 b, u32 f, u32 node) const { bfs(b, f, bf(b, f) | (1u << node)); }
-  LBFT_HD void clr_bit(u32 b, u32 f, u32 node) const { bfs(b, f, bf(b, f) & ~(1u << node)); }
+
+  // ---- block records: a FIFO of LBFT_BLK_CACHE hot records in registers.  Only this lane ever touches its
+  // instance's block rows and every update is written through, so the cache stays valid for the whole
+  // launch; the handful of blocks a network is working on (the proposal, its parent and grandparent, the
+  // commit certificate) stop being memory round trips.  All indices below are compile-time after
+  // unrolling, so the records live in VGPRs.
+  struct Blk {
+    u32 w[BC_WORDS];
+    LBFT_HD u32 round() const { return w[B_ROUND]; }
+    LBFT_HD u32 prev() const { return w[B_LINK] & 0xffffu; }
+    LBFT_HD u32 author() const { return w[B_LINK] >> 16; }
+    LBFT_HD u32 prev_round() const { return w[B_PREV_ROUND]; }
+    LBFT_HD u32 pp() const { return w[B_PP]; }
+    LBFT_HD u32 pp_round() const { return w[B_PP_ROUND]; }
+    LBFT_HD u32 epoch() const { return w[B_EPOCH]; }
+    LBFT_HD bool known(u32 node) const { return (w[B_KNOWN] >> node) & 1u; }
+    LBFT_HD bool qc(u32 node) const { return (w[B_QC] >> node) & 1u; }
+    LBFT_HD bool pend(u32 node) const { return (w[B_PEND] >> node) & 1u; }
+  };
+  mutable u32 bc_id[LBFT_BLK_CACHE];
+  mutable u32 bc_w[LBFT_BLK_CACHE][BC_WORDS];
+  mutable u32 bc_next;
+  LBFT_HD void blk_cache_reset() const {
+    for (u32 e = 0; e < LBFT_BLK_CACHE; e++) bc_id[e] = 0;
+    bc_next = 0;
+  }
+  LBFT_HD void blk_cache_insert(u32 b, const Blk& r) const {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 e = 0; e < LBFT_BLK_CACHE; e++) {
+      if (bc_next == e) {
+        bc_id[e] = b;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (u32 f = 0; f < BC_WORDS; f++) bc_w[e][f] = r.w[f];
+      }
+    }
+    bc_next = bc_next + 1 == LBFT_BLK_CACHE ? 0 : bc_next + 1;
+  }
+  LBFT_HD Blk blk_get(u32 b) const {  // b != 0
+    Blk r;
+    bool hit = false;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 e = 0; e < LBFT_BLK_CACHE; e++) {
+      if (bc_id[e] == b) {
+        hit = true;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = bc_w[e][f];
+      }
+    }
+    if (!hit) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = ld(bfw(b, f));  // one burst of independent loads
+      blk_cache_insert(b, r);
+    }
+    return r;
+  }
+  // Write-through update of one mask word of block b (f is B_KNOWN, B_QC or B_PEND).
+  LBFT_HD void blk_put(u32 b, u32 f, u32 v) const {
+    st(bfw(b, f), v);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 e = 0; e < LBFT_BLK_CACHE; e++)
+      if (bc_id[e] == b) {
+        if (f == B_KNOWN) bc_w[e][B_KNOWN] = v;
+        else if (f == B_QC) bc_w[e][B_QC] = v;
+        else bc_w[e][B_PEND] = v;
+      }
+  }
   LBFT_HD u32 sfw(u32 slot, u32 f) const { return P.off_snap + slot * P.snap_words + f; }
 
   LBFT_HD void load_scalars() {
@@ -316,6 +459,7 @@ struct Sim {
     qlen = ld(I_QLEN); snap_free = ld(I_SNAP_FREE); nblocks = ld(I_NBLOCKS); fault = ld(I_FAULT);
     ev0 = ld(I_EV0); ev1 = ld(I_EV1); ev2 = ld(I_EV2); ev3 = ld(I_EV3);
     maxq = ld(I_MAXQ); maxsnap = ld(I_MAXSNAP);
+    blk_cache_reset();
   }
   LBFT_HD void store_scalars(bool done) {
     st(I_CLOCK, (u32)clock); st(I_STAMP, stamp);
@@ -335,10 +479,10 @@ struct Sim {
       u64 bits = rng.next_u64();
       u32 i = (u32)(bits & 0xff);
       double u = lbft_asdouble((1024ULL << 52) | (bits >> 12)) - 3.0;
-      double xi = lbft_asdouble(P.zig_x[i]);
+      double xi = lbft_asdouble(zig_x[i]);
       double x = u * xi;
       double ax = x < 0.0 ? -x : x;
-      if (ax < lbft_asdouble(P.zig_x[i + 1])) return x;
+      if (ax < lbft_asdouble(zig_x[i + 1])) return x;
       if (i == 0) {
         double xx = 1.0, yy = 0.0;
         while (-2.0 * yy < xx * xx) {
@@ -349,29 +493,50 @@ struct Sim {
         }
         return u < 0.0 ? xx - R : R - xx;
       }
-      double f0 = lbft_asdouble(P.zig_f[i]), f1 = lbft_asdouble(P.zig_f[i + 1]);
+      double f0 = lbft_asdouble(zig_f[i]), f1 = lbft_asdouble(zig_f[i + 1]);
       double f01 = (double)(rng.next_u64() >> 11) * 0x1p-53;
-      if (f1 + (f0 - f1) * f01 < lbft_exp(-x * x / 2.0, P.exp_tab)) return x;
+      if (f1 + (f0 - f1) * f01 < lbft_exp(-x * x / 2.0, exp_tab)) return x;
     }
   }
   LBFT_HD i64 sample_delay() {
     if (P.delay_model == 1) return P.uni_lo + (i64)rng.gen_range_u64(P.uni_span);
     double nrm = standard_normal();
-    return f64_to_i64_sat(lbft_exp(P.mu + P.sigma * nrm, P.exp_tab));
+    return f64_to_i64_sat(lbft_exp(P.mu + P.sigma * nrm, exp_tab));
   }
 
   // ---- event queue: unsorted compact array, ordered by (time asc, kind desc, stamp asc)
   //      (ScheduledEvent::cmp, simulator.rs:149-161).  Events scheduled after max_clock can never
   //      run (loop_until breaks at the first one, simulator.rs:389) and are dropped at push time;
   //      they still consume a creation stamp.
+  LBFT_HD void q_set(u32 k, u64 key, u32 meta) const {
+    if (k < ql) { qk[k * qstr] = key; qm[k * qstr] = meta; }
+    else { st(P.off_qhi + k, (u32)(key >> 32)); st(P.off_qlo + k, (u32)key); st(P.off_qmeta + k, meta); }
+  }
+  LBFT_HD void q_get(u32 k, u64& key, u32& meta) const {
+    if (k < ql) { key = qk[k * qstr]; meta = qm[k * qstr]; }
+    else { key = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k); meta = ld(P.off_qmeta + k); }
+  }
+  // The LDS front is a cache of the HBM rows between launches.
+  LBFT_HD void queue_to_lds() const {
+    u32 nl = qlen < ql ? qlen : ql;
+    for (u32 k = 0; k < nl; k++) {
+      qk[k * qstr] = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k);
+      qm[k * qstr] = ld(P.off_qmeta + k);
+    }
+  }
+  LBFT_HD void queue_from_lds() const {
+    u32 nl = qlen < ql ? qlen : ql;
+    for (u32 k = 0; k < nl; k++) {
+      u64 key = qk[k * qstr];
+      st(P.off_qhi + k, (u32)(key >> 32)); st(P.off_qlo + k, (u32)key); st(P.off_qmeta + k, qm[k * qstr]);
+    }
+  }
   LBFT_HD bool push_event(i64 time, u32 kind, u32 node, u32 sender, u32 slot) {
     u32 my_stamp = stamp++;
     if (time > (i64)P.max_clock) return false;
     if (my_stamp >= (1u << 30)) { fault |= F_STAMP_OVERFLOW; return false; }
     if (qlen >= P.qcap) { fault |= F_QUEUE_OVERFLOW; return false; }
-    st(P.off_qhi + qlen, (u32)time);
-    st(P.off_qlo + qlen, ((3u - kind) << 30) | my_stamp);
-    st(P.off_qmeta + qlen, node | (sender << 8) | (slot << 16));
+    q_set(qlen, ((u64)(u32)time << 32) | ((3u - kind) << 30) | my_stamp, node | (sender << 8) | (slot << 16));
     qlen++;
     if (qlen > maxq) maxq = qlen;
     return true;
@@ -380,19 +545,27 @@ struct Sim {
   LBFT_HD bool pop_event(i32& time, u32& kind, u32& meta) {
     if (qlen == 0) return false;
     u32 best = 0;
-    u32 bhi = ld(P.off_qhi), blo = ld(P.off_qlo);
-    for (u32 i = 1; i < qlen; i++) {
-      u32 hi = ld(P.off_qhi + i), lo = ld(P.off_qlo + i);
-      if (hi < bhi || (hi == bhi && lo < blo)) { bhi = hi; blo = lo; best = i; }
+    u64 bkey = ~0ULL;
+    u32 nl = qlen < ql ? qlen : ql;
+#if defined(__HIPCC__)
+#pragma unroll 4
+#endif
+    for (u32 k = 0; k < nl; k++) {
+      u64 key = qk[k * qstr];
+      if (key < bkey) { bkey = key; best = k; }
     }
-    time = (i32)bhi;
-    kind = 3u - (blo >> 30);
-    meta = ld(P.off_qmeta + best);
+    for (u32 k = ql; k < qlen; k++) {  // spilled tail (rare when ql covers the high-water mark)
+      u64 key = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k);
+      if (key < bkey) { bkey = key; best = k; }
+    }
+    time = (i32)(u32)(bkey >> 32);
+    kind = 3u - ((u32)bkey >> 30);
+    meta = best < ql ? qm[best * qstr] : ld(P.off_qmeta + best);
     qlen--;
     if (best != qlen) {
-      st(P.off_qhi + best, ld(P.off_qhi + qlen));
-      st(P.off_qlo + best, ld(P.off_qlo + qlen));
-      st(P.off_qmeta + best, ld(P.off_qmeta + qlen));
+      u64 lk; u32 lm;
+      q_get(qlen, lk, lm);
+      q_set(best, lk, lm);
     }
     return true;
   }
@@ -421,14 +594,16 @@ struct Sim {
   LBFT_HD bool state_available(u32 node, u32 blk) const {
     if (blk == nf(node, NF_LAST_COMMITTED_BLK)) return true;
     if (blk == 0) return false;
-    return bit(blk, B_PEND, node);
+    return blk_get(blk).pend(node);
   }
-  // RecordStoreState::compute_state (record_store.rs:426-454) + CommandExecutor::compute
-  LBFT_HD bool compute_state(u32 node, u32 b) const {
-    u32 prev = blk_prev(b);
+  // RecordStoreState::compute_state (record_store.rs:426-454) + CommandExecutor::compute.
+  // `rb` is the caller's copy of block b's record; its pending mask is updated in place.
+  LBFT_HD bool compute_state(u32 node, u32 b, Blk& rb) const {
+    u32 prev = rb.prev();
     u32 base = prev ? prev : nf(node, NF_INIT_STATE_BLK);
     if (!state_available(node, base)) return false;
-    set_bit(b, B_PEND, node);
+    rb.w[B_PEND] |= 1u << node;
+    blk_put(b, B_PEND, rb.w[B_PEND]);
     return true;
   }
 
@@ -446,12 +621,9 @@ struct Sim {
     nfs(node, NF_ELECTION, 0);
     clear_ballot(node);
   }
-  LBFT_HD void update_commit_3chain_round(u32 node, u32 b) const {  // record_store.rs:221-235
-    u32 p = blk_prev(b);
-    if (!p) return;
-    u32 pp = blk_prev(p);
-    if (!pp) return;
-    u32 r3 = blk_round(b), r2 = blk_round(p), r1 = blk_round(pp);
+  LBFT_HD void update_commit_3chain_round(u32 node, u32 b, const Blk& rb) const {  // record_store.rs:221-235
+    if (!rb.prev() || !rb.pp()) return;
+    u32 r3 = rb.round(), r2 = rb.prev_round(), r1 = rb.pp_round();
     if (r3 == r2 + 1 && r2 == r1 + 1 && r1 > nf(node, NF_HC_ROUND)) {
       nfs(node, NF_HC_ROUND, r1);
       nfs(node, NF_HCC_BLK, b);
@@ -459,29 +631,39 @@ struct Sim {
   }
   // verify_network_record + try_insert_network_record for a QC (record_store.rs:330-389,500-526).
   // Caller has already checked qc.epoch_id == node epoch (node.rs:151-167).
-  LBFT_HD void insert_qc(u32 node, u32 b) const {
-    if (bit(b, B_QC, node)) return;       // "QuorumCertificate was already inserted."
-    if (!bit(b, B_KNOWN, node)) return;   // "The certified block hash of a QC must be verified first."
-    set_bit(b, B_QC, node);               // Q3: stored before the execution check
-    if (!compute_state(node, b)) return;  // bail!("I failed to execute a block with a QC ...")
-    u32 r = blk_round(b);
+  LBFT_HD void insert_qc(u32 node, u32 b, Blk& rb) const {
+    if (rb.qc(node)) return;      // "QuorumCertificate was already inserted."
+    if (!rb.known(node)) return;  // "The certified block hash of a QC must be verified first."
+    rb.w[B_QC] |= 1u << node;     // Q3: stored before the execution check
+    blk_put(b, B_QC, rb.w[B_QC]);
+    if (!compute_state(node, b, rb)) return;  // bail!("I failed to execute a block with a QC ...")
+    u32 r = rb.round();
     if (r > nf(node, NF_HQC_ROUND)) { nfs(node, NF_HQC_ROUND, r); nfs(node, NF_HQC_BLK, b); }
     update_current_round(node, r + 1);
-    update_commit_3chain_round(node, b);
+    update_commit_3chain_round(node, b, rb);
+  }
+  LBFT_HD void insert_qc(u32 node, u32 b) const {
+    Blk rb = blk_get(b);
+    insert_qc(node, b, rb);
   }
   // Block (record_store.rs:263-291,466-476)
+  LBFT_HD void insert_block(u32 node, u32 b, Blk& rb) const {
+    if (rb.known(node)) return;  // "Block was already inserted."
+    u32 p = rb.prev();
+    if (p && !blk_get(p).qc(node)) return;  // "The previous QC (if any) must be verified first."
+    u32 r = rb.round();
+    if (r == nf(node, NF_CUR_ROUND) && leader(r) == rb.author()) nfs(node, NF_PROPOSED_BLK, b);
+    rb.w[B_KNOWN] |= 1u << node;
+    blk_put(b, B_KNOWN, rb.w[B_KNOWN]);
+  }
   LBFT_HD void insert_block(u32 node, u32 b) const {
-    if (bit(b, B_KNOWN, node)) return;  // "Block was already inserted."
-    u32 p = blk_prev(b);
-    if (p && !bit(p, B_QC, node)) return;  // "The previous QC (if any) must be verified first."
-    u32 r = blk_round(b);
-    if (r == nf(node, NF_CUR_ROUND) && leader(r) == blk_author(b)) nfs(node, NF_PROPOSED_BLK, b);
-    set_bit(b, B_KNOWN, node);
+    Blk rb = blk_get(b);
+    insert_block(node, b, rb);
   }
   // Vote (record_store.rs:292-329,477-499).  Caller checked the epoch.
-  LBFT_HD void insert_vote(u32 node, u32 author, u32 b) {
-    if (!bit(b, B_KNOWN, node)) return;
-    if (blk_round(b) != nf(node, NF_CUR_ROUND)) return;
+  LBFT_HD void insert_vote(u32 node, u32 author, u32 b, const Blk& rb) {
+    if (!rb.known(node)) return;
+    if (rb.round() != nf(node, NF_CUR_ROUND)) return;
     u32 a0 = nf(node, NF_BAL0_AUTHORS), a1 = nf(node, NF_BAL1_AUTHORS);
     if (((a0 | a1) >> author) & 1u) return;  // one vote per author
     u32 b0 = nf(node, NF_BAL0_BLK), b1 = nf(node, NF_BAL1_BLK);
@@ -541,19 +723,30 @@ struct Sim {
     u32 b = ++nblocks;
     u32 base = prev_blk ? prev_blk : nf(node, NF_INIT_STATE_BLK);
     u32 depth = (base ? bf(base, B_DEPTH) : 0) + 1;
-    bfs(b, B_ROUND, nf(node, NF_CUR_ROUND));
-    bfs(b, B_LINK, prev_blk | (node << 16));
+    Blk rb;
+    rb.w[B_ROUND] = nf(node, NF_CUR_ROUND);
+    rb.w[B_LINK] = prev_blk | (node << 16);
+    rb.w[B_PREV_ROUND] = 0; rb.w[B_PP] = 0; rb.w[B_PP_ROUND] = 0;
+    if (prev_blk) {  // denormalised ancestry: previous_round / second_previous_round (record_store.rs:588-609)
+      Blk rp = blk_get(prev_blk);
+      rb.w[B_PREV_ROUND] = rp.round(); rb.w[B_PP] = rp.prev(); rb.w[B_PP_ROUND] = rp.prev_round();
+    }
+    rb.w[B_EPOCH] = nf(node, NF_EPOCH);
+    rb.w[B_KNOWN] = 0; rb.w[B_QC] = 0; rb.w[B_PEND] = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 f = 0; f < BC_WORDS; f++) bfs(b, f, rb.w[f]);
     bfs(b, B_TIME, (u32)(i32)local_clock);
     bfs(b, B_CMD, cmd);
     bfs(b, B_DEPTH, depth);
-    bfs(b, B_EPOCH, nf(node, NF_EPOCH));
-    bfs(b, B_KNOWN, 0); bfs(b, B_QC, 0); bfs(b, B_PEND, 0);
-    insert_block(node, b);
+    blk_cache_insert(b, rb);
+    insert_block(node, b, rb);
   }
   // create_vote (record_store.rs:676-700)
-  LBFT_HD bool create_vote(u32 node, u32 b) {
-    if (!compute_state(node, b)) return false;
-    insert_vote(node, node, b);
+  LBFT_HD bool create_vote(u32 node, u32 b, Blk& rb) {
+    if (!compute_state(node, b, rb)) return false;
+    insert_vote(node, node, b, rb);
     return true;
   }
   // check_for_new_quorum_certificate (record_store.rs:702-738)
@@ -561,9 +754,10 @@ struct Sim {
     u32 e = nf(node, NF_ELECTION);
     if ((e & 0xff) != 1) return false;
     u32 b = e >> 8;
-    if (blk_author(b) != node) return false;
+    Blk rb = blk_get(b);
+    if (rb.author() != node) return false;
     nfs(node, NF_ELECTION, 2);
-    insert_qc(node, b);
+    insert_qc(node, b, rb);
     return true;
   }
 
@@ -647,20 +841,28 @@ struct Sim {
   // ---- NodeState::process_commits (node.rs:313-350) + StateFinalizer::commit ----
   LBFT_HD void process_commits(u32 node) {
     u32 after = nf(node, NF_TR_HCR);
-    u32 x = nf(node, NF_HCC_BLK);  // committed_states_after (record_store.rs:557-574)
-    if (x) x = blk_prev(x);
-    if (x) x = blk_prev(x);
-    u32 start = x, k = 0;
-    while (x && blk_round(x) > after) { k++; x = blk_prev(x); }
+    // The walk below starts at the grandparent of the commit-certificate block, whose round is exactly
+    // highest_committed_round (update_commit_3chain_round sets both together): nothing new to commit.
+    if (nf(node, NF_HC_ROUND) <= after) return;
+    // committed_states_after (record_store.rs:557-574): from the grandparent of the commit-certificate
+    // block back to the first block whose round is <= `after`
+    u32 start = blk_get(nf(node, NF_HCC_BLK)).pp(), k = 0;
+    for (u32 x = start; x;) {
+      Blk rx = blk_get(x);
+      if (rx.round() <= after) break;
+      k++;
+      x = rx.prev();
+    }
     for (u32 j = k; j-- > 0;) {  // oldest first
       u32 y = start;
-      for (u32 s = 0; s < j; s++) y = blk_prev(y);
+      for (u32 s = 0; s < j; s++) y = blk_get(y).prev();
+      Blk ry = blk_get(y);
       // SimulatedContext::commit (simulated_context.rs:160-185)
-      if (!bit(y, B_PEND, node)) { fault |= F_COMMIT_UNKNOWN_STATE; return; }
-      u32 prev = blk_prev(y);
+      if (!ry.pend(node)) { fault |= F_COMMIT_UNKNOWN_STATE; return; }
+      u32 prev = ry.prev();
       u32 base = prev ? prev : nf(node, NF_INIT_STATE_BLK);
       if (base != nf(node, NF_LAST_COMMITTED_BLK)) { fault |= F_COMMIT_NOT_SUCCESSOR; return; }
-      clr_bit(y, B_PEND, node);
+      blk_put(y, B_PEND, ry.w[B_PEND] & ~(1u << node));
       nfs(node, NF_LAST_COMMITTED_BLK, y);
       u32 nc = nf(node, NF_NCOMMITS);
       if (nc >= P.lcap) { fault |= F_LOG_OVERFLOW; return; }
@@ -688,6 +890,7 @@ struct Sim {
   LBFT_HD Actions update_node(u32 node, i64 lclock) {
     i64 lqat = (i64)(i32)nf(node, NF_LQAT);
     PmActions pa = update_pacemaker(node, lqat, lclock);
+    LBFT_MARK(6);
     Actions act;
     act.next = pa.next; act.send_to = pa.send_to; act.broadcast = pa.broadcast; act.query_all = pa.query_all;
     // process_pacemaker_actions (node.rs:179-202)
@@ -697,28 +900,31 @@ struct Sim {
       if (pa.timeout_round > lvr) nfs(node, NF_LVR, pa.timeout_round);
     }
     if (pa.propose) propose_block(node, pa.propose_prev, lclock);
+    LBFT_MARK(7);
     // vote
     u32 pb = proposed_block(node);
     if (pb) {
-      u32 br = blk_round(pb);
-      u32 p = blk_prev(pb);
-      u32 prev_round = p ? blk_round(p) : 0;  // previous_round (record_store.rs:588-598)
+      Blk rpb = blk_get(pb);
+      u32 br = rpb.round();
+      u32 prev_round = rpb.prev_round();  // previous_round (record_store.rs:588-598)
       u32 locked = nf(node, NF_LOCKED);
       if (br > nf(node, NF_LVR) && prev_round >= locked) {
         nfs(node, NF_LVR, br);
-        u32 pp = p ? blk_prev(p) : 0;
-        u32 second_prev = pp ? blk_round(pp) : 0;  // second_previous_round (record_store.rs:600-609)
+        u32 second_prev = rpb.pp_round();  // second_previous_round (record_store.rs:600-609)
         if (second_prev > locked) nfs(node, NF_LOCKED, second_prev);
-        if (create_vote(node, pb)) act.send_to = (i32)blk_author(pb);
+        if (create_vote(node, pb, rpb)) act.send_to = (i32)rpb.author();
       }
     }
+    LBFT_MARK(8);
     if (check_for_new_qc(node)) { act.broadcast = true; act.next = lclock; }
+    LBFT_MARK(9);
     process_commits(node);
     bool tq; i64 tnext;
     update_tracker(node, lqat, lclock, tq, tnext);
     act.query_all = act.query_all || tq;
     if (tnext < act.next) act.next = tnext;
     if (act.query_all) nfs(node, NF_LQAT, (u32)(i32)lclock);
+    LBFT_MARK(10);
     return act;
   }
 
@@ -728,7 +934,7 @@ struct Sim {
     // highest_commit_certificate: Q2 makes the previous-epoch lookup return None (base_types.rs:31-37)
     st(sfw(slot, S_CERTS), nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16));
     u32 pb = proposed_block(node);
-    if (pb && blk_author(pb) != node) pb = 0;  // "Do not reshare other leaders' proposals."
+    if (pb && blk_get(pb).author() != node) pb = 0;  // "Do not reshare other leaders' proposals."
     u32 a0 = nf(node, NF_BAL0_AUTHORS), a1 = nf(node, NF_BAL1_AUTHORS);
     u32 vote = 0;  // current_vote(local author) (record_store.rs:762-764)
     if ((a0 >> node) & 1u) vote = nf(node, NF_BAL0_BLK);
@@ -746,36 +952,53 @@ struct Sim {
   }
 
   // ---- DataSyncNode::handle_notification (data_sync.rs:113-177); returns should_sync ----
-  LBFT_HD bool handle_notification(u32 node, u32 sender, u32 slot) {
+  struct Snap { u32 w[S_FIXED_WORDS]; };
+  LBFT_HD Snap load_snapshot(u32 slot) const {
+    Snap sn;
+    const u32* sb = row0 + (size_t)(P.off_snap + slot * P.snap_words) * LBFT_ROW_STRIDE(P);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 f = 0; f < S_FIXED_WORDS; f++) sn.w[f] = sb[(size_t)f * LBFT_ROW_STRIDE(P)];
+    return sn;
+  }
+  LBFT_HD bool handle_notification(u32 node, u32 sender, u32 slot, const Snap& sn) {
     u32 epoch = nf(node, NF_EPOCH);
-    u32 n_epoch = ld(sfw(slot, S_EPOCH));
+    u32 n_epoch = sn.w[S_EPOCH];
     bool should_sync = n_epoch > epoch;
-    u32 certs = ld(sfw(slot, S_CERTS));
+    u32 certs = sn.w[S_CERTS];
     u32 hcc = certs & 0xffffu, hqc = certs >> 16;
     if (hcc) {
-      u32 qe = bf(hcc, B_EPOCH);
-      if (qe == epoch) insert_qc(node, hcc);
-      should_sync |= (qe > epoch) || (qe == epoch && blk_round(hcc) > nf(node, NF_HC_ROUND) + 2);
+      Blk r = blk_get(hcc);
+      u32 qe = r.epoch();
+      if (qe == epoch) insert_qc(node, hcc, r);
+      should_sync |= (qe > epoch) || (qe == epoch && r.round() > nf(node, NF_HC_ROUND) + 2);
     }
+    LBFT_MARK(20);
     if (hqc) {
-      u32 qe = bf(hqc, B_EPOCH);
-      if (qe == epoch) insert_qc(node, hqc);
-      should_sync |= (qe > epoch) || (qe == epoch && blk_round(hqc) > nf(node, NF_HQC_ROUND));
+      Blk r = blk_get(hqc);
+      u32 qe = r.epoch();
+      if (qe == epoch) insert_qc(node, hqc, r);
+      should_sync |= (qe > epoch) || (qe == epoch && r.round() > nf(node, NF_HQC_ROUND));
     }
+    LBFT_MARK(21);
     if (n_epoch == epoch) {
-      u32 pv = ld(sfw(slot, S_PROP_VOTE));
+      u32 pv = sn.w[S_PROP_VOTE];
       u32 pb = pv & 0xffffu, vote = pv >> 16;
       if (pb) insert_block(node, pb);
-      u32 tc_round = ld(sfw(slot, S_TC_ROUND)), to_round = ld(sfw(slot, S_TO_ROUND));
-      for (u32 m = ld(sfw(slot, S_TC_MASK)); m;) {
+      LBFT_MARK(22);
+      u32 tc_round = sn.w[S_TC_ROUND], to_round = sn.w[S_TO_ROUND];
+      for (u32 m = sn.w[S_TC_MASK]; m;) {
         u32 a = ctz32(m); m &= m - 1;
         insert_timeout(node, a, tc_round, ld(sfw(slot, S_FIXED_WORDS + a)));
       }
-      for (u32 m = ld(sfw(slot, S_TO_MASK)); m;) {
+      for (u32 m = sn.w[S_TO_MASK]; m;) {
         u32 a = ctz32(m); m &= m - 1;
         insert_timeout(node, a, to_round, ld(sfw(slot, S_FIXED_WORDS + P.n + a)));
       }
-      if (vote) insert_vote(node, sender, vote);
+      LBFT_MARK(23);
+      if (vote) insert_vote(node, sender, vote, blk_get(vote));
+      LBFT_MARK(24);
     }
     return should_sync;
   }
@@ -803,7 +1026,7 @@ struct Sim {
       if (t_new <= (i64)P.max_clock) { nfs(node, NF_LAST_TIMER_T, (u32)t_new); }
       push_event(t_new, 3, node, 0, 0);
     }
-    // receivers, packed 4 bits each (n <= 16) or walked directly
+    LBFT_MARK(12);
     u32 list[LBFT_MAX_NODES];
     u32 cnt = 0;
     if (act.broadcast) { for (u32 i = 0; i < P.n; i++) if (i != node) list[cnt++] = i; }
@@ -827,6 +1050,7 @@ struct Sim {
       if (refs) st(P.off_snap_ref + (u32)slot, refs);
       else { st(P.off_snap_free + snap_free, (u32)slot); snap_free++; }
     }
+    LBFT_MARK(13);
     if (act.query_all) {
       cnt = 0;
       for (u32 i = 0; i < P.n; i++) if (i != node) list[cnt++] = i;
@@ -839,6 +1063,7 @@ struct Sim {
         push_event(t, 1, node, list[i], 0);
       }
     }
+    LBFT_MARK(14);
   }
 
   // ---- Simulator::new (simulator.rs:200-250) + NodeState::make_initial_state (node.rs:87-114) ----
@@ -846,6 +1071,7 @@ struct Sim {
     for (u32 w = 0; w < I_WORDS; w++) st(w, 0);
     clock = 0; stamp = 0; qlen = 0; nblocks = 0; fault = 0; maxq = 0; maxsnap = 0;
     ev0 = ev1 = ev2 = ev3 = 0;
+    blk_cache_reset();
     snap_free = P.scap;
     for (u32 s = 0; s < P.scap; s++) { st(P.off_snap_free + s, P.scap - 1 - s); st(P.off_snap_ref + s, 0); }
     rng.seed(seed);
@@ -870,40 +1096,62 @@ struct Sim {
       if (P.max_steps && steps >= P.max_steps) return false;
       i32 t; u32 kind, meta;
       if (!pop_event(t, kind, meta)) return true;
+      LBFT_MARK(0);
+      LBFT_COUNT(30);
       steps++;
       if (t > clock) clock = t;
       u32 node = meta & 0xffu, sender = (meta >> 8) & 0xffu, slot = meta >> 16;
-      // One shared call site for update_node + process_node_actions: lanes of a wavefront that
-      // handle different event kinds reconverge here instead of running three inlined copies.
+      // One shared site for the node-row burst (and, for a notification, its snapshot words in the same
+      // burst), one for update_node + process_node_actions: lanes of a wavefront that handle different
+      // event kinds issue their loads together instead of one serialized round trip per kind.
       bool do_update = true, sync = false;
+      begin_node(node);
+      Snap sn;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 f = 0; f < S_FIXED_WORDS; f++) sn.w[f] = 0;
+      if (kind == 0) sn = load_snapshot(slot);
+      LBFT_DRAIN_VMEM();
+      LBFT_MARK(1);
       if (kind == 3) {  // UpdateTimerEvent (simulator.rs:403-415)
         ev3++;
-        if ((u32)clock == nfm(node, NF_LAST_TIMER_T)) {  // folded duplicates of this timer
-          ev3 += nfm(node, NF_TIMER_DUPS);
-          nfms(node, NF_TIMER_DUPS, 0);
-          nfms(node, NF_LAST_TIMER_T, 0xffffffffu);
+        if ((u32)clock == nf(node, NF_LAST_TIMER_T)) {  // folded duplicates of this timer
+          ev3 += nf(node, NF_TIMER_DUPS);
+          nfs(node, NF_TIMER_DUPS, 0);
+          nfs(node, NF_LAST_TIMER_T, 0xffffffffu);
         }
-        if (clock <= (i32)nfm(node, NF_IGNORE_UNTIL)) do_update = false;  // cancelled timer
-        else begin_node(node);
+        if (clock <= (i32)nf(node, NF_IGNORE_UNTIL)) {  // cancelled timer
+          do_update = false;
+          end_node(node);
+        }
+        LBFT_MARK(2);
       } else if (kind == 0) {  // DataSyncNotifyEvent (simulator.rs:416-440)
         ev0++;
-        begin_node(node);
-        sync = handle_notification(node, sender, slot);
+        sync = handle_notification(node, sender, slot, sn);
         snap_release(slot);
+        LBFT_MARK(3);
       } else if (kind == 1) {  // DataSyncRequestEvent (simulator.rs:441-453)
         ev1++;
         // Q1: answered by the requester itself; the response carries nothing insertable
         push_event((i64)clock + sample_delay(), 2, node, sender, 0);
         do_update = false;
+        LBFT_MARK(4);
       } else {  // DataSyncResponseEvent (simulator.rs:454-466): handle_response inserts nothing (Q1)
         ev2++;
-        begin_node(node);
+        LBFT_MARK(5);
       }
       if (do_update) {
         Actions a = node_update(node);
         if (sync) push_event((i64)clock + sample_delay(), 1, node, sender, 0);
+        LBFT_MARK(11);
         process_node_actions(node, a);
+        LBFT_DRAIN_VMEM();
+        LBFT_MARK(14);
         end_node(node);
+        LBFT_MARK(15);
+        LBFT_DRAIN_VMEM();
+        LBFT_MARK(17);
       }
     }
   }

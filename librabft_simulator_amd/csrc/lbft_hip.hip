@@ -30,29 +30,72 @@ static_assert(LBFT_MAX_NODES == LBFT_MAX_NODES_SUPPORTED, "header mismatch");
 __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restrict__ state, const u64* __restrict__ seeds) {
   u32 i = blockIdx.x * p.lpw + threadIdx.x;
   if (threadIdx.x >= p.lpw || i >= p.m) return;
-  Sim s(p, state + i);
+  Sim s(p, state + inst_offset(p, i));
   s.init(seeds[i]);
 }
 
 // Simulator::loop_until for every instance (simulator.rs:380-475).
-__global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_run(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) {
-  // Only the first p.lpw lanes of a wavefront carry an instance: the step is a long chain of dependent
-  // memory accesses, so with few instances per GPU it pays to trade idle lanes for more resident
-  // wavefronts per SIMD (latency hiding) and less intra-wavefront divergence.
-  u32 i = blockIdx.x * p.lpw + threadIdx.x;
-  bool active = threadIdx.x < p.lpw && i < p.m;
+//
+// Workgroup = 4 wavefronts; wavefront w of workgroup g advances instances
+// [(g * 4 + w) * lpw, +lpw).  LDS (dynamic, up to the CU's whole 160 KiB):
+//   [zig_x 257][zig_f 257][exp_tab 256]  u64   read-only tables of the delay sampler, one copy per workgroup
+//   keys  [wave][slot][lane]              u64   event-queue keys (time, 3-kind, stamp), lane-private columns
+//   metas [wave][slot][lane]              u32   (node, sender, snapshot slot)
+// A lane only ever touches its own column (address = slot * lpw + lane), so data-dependent slot
+// indices are bank-conflict free and no workgroup barrier is needed after the table fill.
+#define LBFT_RUN_WAVES 4
+#define LBFT_RUN_BLOCK (64 * LBFT_RUN_WAVES)
+#define LBFT_TABLE_U64 (257 + 257 + 256)
+
+static inline size_t run_lds_bytes(u32 ql, u32 lpw) {
+  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * ql * lpw * 12 + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8;  // + diagnostics
+}
+
+__global__ __launch_bounds__(LBFT_RUN_BLOCK) void lbft_k_run(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) {
+  extern __shared__ u64 lds[];
+  u64* t_zx = lds;
+  u64* t_zf = lds + 257;
+  u64* t_et = lds + 514;
+  for (u32 t = threadIdx.x; t < 257; t += LBFT_RUN_BLOCK) { t_zx[t] = p.zig_x[t]; t_zf[t] = p.zig_f[t]; }
+  for (u32 t = threadIdx.x; t < 256; t += LBFT_RUN_BLOCK) t_et[t] = p.exp_tab[t];
+  __syncthreads();
+  u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  u64* keys = lds + LBFT_TABLE_U64 + (size_t)wave * p.ql * p.lpw + lane;
+  u32* metas = reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)LBFT_RUN_WAVES * p.ql * p.lpw) + (size_t)wave * p.ql * p.lpw + lane;
+  // Only the first p.lpw lanes of a wavefront carry an instance (occupancy vs lane-utilisation knob).
+  u32 i = (blockIdx.x * LBFT_RUN_WAVES + wave) * p.lpw + lane;
+  bool active = lane < p.lpw && i < p.m;
   bool done = true;
   if (active) {
-    Sim s(p, state + i);
+    Sim s(p, state + inst_offset(p, i));
     if (s.ld(I_DONE) == 0) {
+      s.attach_queue(keys, metas, p.lpw, p.ql);
+      s.attach_tables(t_zx, t_zf, t_et);
       s.load_scalars();
+      s.queue_to_lds();
+#if defined(LBFT_PHASE_TIMERS)
+      // per-wavefront accumulators behind the queue columns (8-byte aligned: the meta area is a multiple of 8 words)
+      u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)LBFT_RUN_WAVES * p.ql * p.lpw) +
+                                          (size_t)LBFT_RUN_WAVES * p.ql * p.lpw + (p.ql * p.lpw & 1u ? 1 : 0)) + wave * LBFT_NPHASES;
+      if (lane == 0) { for (int k = 0; k < LBFT_NPHASES; k++) wprof[k] = 0; wprof[31] = __builtin_readcyclecounter(); }
+      s.wprof = wprof;
+      u64 t_begin = __builtin_readcyclecounter();
+#endif
       done = s.run();
+      s.queue_from_lds();
       s.store_scalars(done);
+#if defined(LBFT_PHASE_TIMERS)
+      // every lane of a wavefront sees the wavefront's clock: the first active lane reports
+      if (p.prof && lane == 0) {
+        for (int k = 0; k < 31; k++) atomicAdd(&p.prof[k], (unsigned long long)s.wprof[k]);  // 30 = wavefront loop iterations
+        atomicAdd(&p.prof[31], (unsigned long long)(__builtin_readcyclecounter() - t_begin));  // total cycles
+      }
+#endif
     }
   }
   // one atomic per wavefront: ballot of the lanes that still have pending events
   unsigned long long pending = __ballot(active && !done);
-  if (pending && (threadIdx.x & 63) == (u32)(__ffsll((long long)pending) - 1)) atomicAdd(unfinished, (u32)__popcll(pending));
+  if (pending && lane == (u32)(__ffsll((long long)pending) - 1)) atomicAdd(unfinished, (u32)__popcll(pending));
 }
 
 __device__ __forceinline__ u64 wave_sum(u64 v) {
@@ -74,7 +117,7 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_finalize(Params p, const u3
   u64 c[C_WORDS];
   for (int k = 0; k < C_WORDS; k++) c[k] = 0;
   if (i < p.m) {
-    Sim s(p, const_cast<u32*>(state) + i);
+    Sim s(p, const_cast<u32*>(state) + inst_offset(p, i));
     u64 min_round = ~0ULL, min_commits = ~0ULL;
     for (u32 n = 0; n < p.n; n++) {
       u32 nc = s.nfm(n, NF_NCOMMITS);
@@ -112,12 +155,12 @@ __global__ void lbft_k_gather_node(Params p, const u32* __restrict__ state, u32 
   u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= p.m * p.n) return;
   u32 n = t / p.m, i = t % p.m;  // consecutive lanes -> consecutive instances (coalesced reads)
-  out[(size_t)i * p.n + n] = state[(size_t)(p.off_node + n * p.node_words + field) * p.stride + i];
+  out[(size_t)i * p.n + n] = state[word_offset(p, i, p.off_node + n * p.node_words + field)];
 }
 __global__ void lbft_k_gather_inst(Params p, const u32* __restrict__ state, u32 row, u32* __restrict__ out) {
   u32 i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.m) return;
-  out[i] = state[(size_t)row * p.stride + i];
+  out[i] = state[word_offset(p, i, row)];
 }
 // Materialise committed histories: out[(inst * n + node) * cap + k].
 __global__ void lbft_k_export_histories(Params p, const u32* __restrict__ state, lbft_commit* __restrict__ out, u32 cap,
@@ -125,7 +168,7 @@ __global__ void lbft_k_export_histories(Params p, const u32* __restrict__ state,
   u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_inst * p.n) return;
   u32 n = t / n_inst, i = first_inst + t % n_inst;
-  Sim s(p, const_cast<u32*>(state) + i);
+  Sim s(p, const_cast<u32*>(state) + inst_offset(p, i));
   u32 nc = s.nfm(n, NF_NCOMMITS);
   lbft_commit* o = out + ((size_t)(i - first_inst) * p.n + n) * cap;
   for (u32 k = 0; k < nc && k < cap; k++) {
@@ -199,6 +242,9 @@ struct lbft_batch {
   bool ran = false;
   u32 max_steps = 0;
   u32 lpw = 0;  // 0 = auto
+  int ql = -1;  // LDS queue slots per instance; -1 = auto
+  unsigned long long* d_prof = nullptr;
+  size_t lds_bytes = 0;
   float init_ms = 0, run_ms = 0;
   lbft_counters counters;
   size_t table_bytes = 0;
@@ -246,7 +292,7 @@ static void free_batch(lbft_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   hipFree(b->d_seeds); hipFree(b->d_state); hipFree(b->d_zx); hipFree(b->d_zf); hipFree(b->d_et); hipFree(b->d_dur);
-  hipFree(b->d_leaders); hipFree(b->d_unfinished); hipFree(b->d_states_out); hipFree(b->d_counters); hipFree(b->d_scratch);
+  hipFree(b->d_leaders); hipFree(b->d_prof); hipFree(b->d_unfinished); hipFree(b->d_states_out); hipFree(b->d_counters); hipFree(b->d_scratch);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   if (b->ev2) hipEventDestroy(b->ev2);
@@ -281,7 +327,11 @@ static int upload_tables(lbft_batch* b) {
 extern "C" {
 
 const char* lbft_last_error(void) { return g_err.c_str(); }
-const char* lbft_build_info(void) { return "liblbft_hip gfx950 abi1 lane-per-instance"; }
+#if defined(LBFT_PHASE_TIMERS)
+const char* lbft_build_info(void) { return "liblbft_hip gfx950 abi2 lane-per-instance lds-queue phase-timers"; }
+#else
+const char* lbft_build_info(void) { return "liblbft_hip gfx950 abi2 lane-per-instance lds-queue"; }
+#endif
 
 int lbft_batch_create(const lbft_config* cfg, const uint64_t* seeds, size_t n_instances, int device, lbft_batch** out) {
   if (!out) return LBFT_ERR_INVALID;
@@ -313,6 +363,7 @@ int lbft_batch_create(const lbft_config* cfg, const uint64_t* seeds, size_t n_in
   CREATE_TRY(hipMalloc(&b->d_seeds, n_instances * sizeof(u64)));
   CREATE_TRY(hipMemcpy(b->d_seeds, seeds, n_instances * sizeof(u64), hipMemcpyHostToDevice));
   CREATE_TRY(hipMalloc(&b->d_unfinished, sizeof(u32)));
+  CREATE_TRY(hipMalloc(&b->d_prof, LBFT_NPHASES * sizeof(unsigned long long)));
   CREATE_TRY(hipMalloc(&b->d_states_out, n_instances * cfg->num_nodes * sizeof(u64)));
   CREATE_TRY(hipMalloc(&b->d_counters, C_WORDS * sizeof(unsigned long long)));
   CREATE_TRY(hipMalloc(&b->d_scratch, n_instances * cfg->num_nodes * sizeof(u64)));
@@ -332,6 +383,25 @@ int lbft_batch_set_lanes_per_wavefront(lbft_batch* b, uint32_t lanes) {
   if (!b || lanes > 64) return LBFT_ERR_INVALID;
   b->lpw = lanes;
   return LBFT_OK;
+}
+
+int lbft_batch_set_lds_queue_slots(lbft_batch* b, int32_t slots) {
+  if (!b || slots < -1) return LBFT_ERR_INVALID;
+  b->ql = slots;
+  return LBFT_OK;
+}
+
+int lbft_batch_phase_cycles(const lbft_batch* b, uint64_t* out) {
+  if (!b || !out) return LBFT_ERR_INVALID;
+#if defined(LBFT_PHASE_TIMERS)
+  if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipMemcpy(out, b->d_prof, LBFT_NPHASES * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return LBFT_OK;
+#else
+  g_err = "this build has no phase timers (compile with -DLBFT_PHASE_TIMERS)";
+  return LBFT_ERR_UNSUPPORTED;
+#endif
 }
 
 int lbft_batch_reset(lbft_batch* b) {
@@ -363,27 +433,42 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
   compute_layout(p);
   if (relayout) {
     if (b->d_state) { HIP_TRY(hipFree(b->d_state)); b->d_state = nullptr; }
-    b->state_bytes = (size_t)p.total_words * p.stride * sizeof(u32);
+    b->state_bytes = state_words(p) * sizeof(u32);
     HIP_TRY(hipMalloc(&b->d_state, b->state_bytes));
   }
-  // lanes per wavefront: aim at ~3 resident wavefronts on each of the 1024 SIMDs (the run kernel's
-  // register budget), never fewer than 8 lanes so that row accesses stay >= 32 contiguous bytes
+  // Lanes per wavefront that carry an instance.  The LDS queue front makes residency LDS-bound: one CU holds
+  // 160 KiB / (12 B * ql) instances however they are spread over wavefronts, so prefer full wavefronts
+  // unless the batch is too small to give every SIMD a wavefront.
   u32 lpw = b->lpw;
   if (lpw == 0) {
-    u64 want = (b->m + 3071) / 3072;
-    lpw = want < 8 ? 8 : (want > 64 ? 64 : (u32)want);
+    u64 want = (b->m + 1023) / 1024;  // 256 CUs x 4 SIMDs
+    lpw = want < 16 ? 16 : (want > 64 ? 64 : (u32)((want + 15) / 16 * 16));
   }
   p.lpw = lpw;
+  // LDS queue slots per instance: what one CU's LDS affords when it hosts 64/lpw workgroups
+  u32 wg_per_cu = 64 / lpw ? 64 / lpw : 1;
+  if (wg_per_cu > 4) wg_per_cu = 4;
+  size_t budget = (160u * 1024u) / wg_per_cu;
+  u32 ql_auto = (u32)((budget - run_lds_bytes(0, lpw) - 1024) / (12u * LBFT_RUN_WAVES * lpw));  // 1 KiB slack: allocation granularity
+  u32 ql = b->ql < 0 ? ql_auto : (u32)b->ql;
+  if (ql > qcap) ql = qcap;
+  if (run_lds_bytes(ql, lpw) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
+  p.ql = ql;
+  b->lds_bytes = run_lds_bytes(ql, lpw);
+  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lbft_k_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+  p.prof = b->d_prof;
+  HIP_TRY(hipMemsetAsync(b->d_prof, 0, LBFT_NPHASES * sizeof(unsigned long long), b->stream));
   u32 grid_full = (u32)((b->m + LBFT_BLOCK - 1) / LBFT_BLOCK);
-  u32 grid = (u32)((b->m + lpw - 1) / lpw);
+  u32 grid_init = (u32)((b->m + lpw - 1) / lpw);
+  u32 grid_run = (u32)((b->m + (size_t)LBFT_RUN_WAVES * lpw - 1) / ((size_t)LBFT_RUN_WAVES * lpw));
   HIP_TRY(hipEventRecord(b->ev0, b->stream));
-  lbft_k_init<<<grid, LBFT_BLOCK, 0, b->stream>>>(p, b->d_state, b->d_seeds);
+  lbft_k_init<<<grid_init, LBFT_BLOCK, 0, b->stream>>>(p, b->d_state, b->d_seeds);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev1, b->stream));
   u64 launches = 0;
   for (;;) {
     HIP_TRY(hipMemsetAsync(b->d_unfinished, 0, sizeof(u32), b->stream));
-    lbft_k_run<<<grid, LBFT_BLOCK, 0, b->stream>>>(p, b->d_state, b->d_unfinished);
+    lbft_k_run<<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
     HIP_TRY(hipGetLastError());
     launches++;
     if (p.max_steps == 0) break;  // whole simulation in one launch
@@ -489,7 +574,7 @@ int lbft_batch_committed_history(const lbft_batch* b, size_t inst, uint32_t node
   if (rc != LBFT_OK) return rc;
   HIP_TRY(hipSetDevice(b->device));
   u32 nc = 0;
-  HIP_TRY(hipMemcpy(&nc, b->d_state + (size_t)(b->p.off_node + node * b->p.node_words + NF_NCOMMITS) * b->p.stride + inst, sizeof(u32),
+  HIP_TRY(hipMemcpy(&nc, b->d_state + word_offset(b->p, (u32)inst, b->p.off_node + node * b->p.node_words + NF_NCOMMITS), sizeof(u32),
                     hipMemcpyDeviceToHost));
   *len = nc;
   for (size_t k = 0; k < nc && k < cap && out; k++) out[k] = tmp[(size_t)node * lcap + k];

@@ -193,7 +193,7 @@ class BatchSimulator:
 
     def __init__(self, rng_seeds, num_nodes, network_delay, node_config=None, commands_per_epoch=30000,
                  voting_rights=None, device=0, queue_capacity=0, snapshot_capacity=0, block_capacity=0,
-                 log_capacity=0, max_steps_per_launch=0, lanes_per_wavefront=0):
+                 log_capacity=0, max_steps_per_launch=0, lanes_per_wavefront=0, lds_queue_slots=-1):
         seeds = np.ascontiguousarray(rng_seeds, dtype=np.uint64)
         self.seeds = seeds
         self.num_instances = int(seeds.shape[0])
@@ -208,6 +208,8 @@ class BatchSimulator:
             check(_lib.lib().lbft_batch_set_max_steps(self._h, max_steps_per_launch))
         if lanes_per_wavefront:
             check(_lib.lib().lbft_batch_set_lanes_per_wavefront(self._h, lanes_per_wavefront))
+        if lds_queue_slots != -1:
+            check(_lib.lib().lbft_batch_set_lds_queue_slots(self._h, lds_queue_slots))
 
     @classmethod
     def new(cls, rng_seeds, num_nodes, network_delay, node_config=None, **kw):
@@ -231,6 +233,12 @@ class BatchSimulator:
         a, b = C.c_float(), C.c_float()
         check(_lib.lib().lbft_batch_last_run_ms(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def phase_cycles(self):
+        """Diagnostic builds only (LBFT_PHASE_TIMERS): shader cycles per phase of the event loop."""
+        out = np.zeros(32, dtype=np.uint64)
+        check(_lib.lib().lbft_batch_phase_cycles(self._h, out.ctypes.data))
+        return out
 
     def device_bytes(self):
         return int(_lib.lib().lbft_batch_device_bytes(self._h))

@@ -21,6 +21,7 @@ extern "C" {
 
 typedef struct lbft_hostmodel_caps {
   uint32_t qcap, scap, bcap, lcap;
+  uint32_t ql;  // queue slots held in the emulated LDS front (0 = HBM rows only)
 } lbft_hostmodel_caps;
 
 // Same outputs as lbft_oracle_run_batch, plus per-instance fault words and max queue/snapshot use.
@@ -34,9 +35,10 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   memset(&p, 0, sizeof(p));
   p.n = cfg->num_nodes;
   p.m = (u32)n_instances;
-  p.stride = (u32)n_instances;
+  p.stride = (u32)((n_instances + 63) / 64 * 64);
   p.qcap = caps->qcap; p.scap = caps->scap; p.bcap = caps->bcap; p.lcap = caps->lcap;
   p.max_clock = (i32)max_clock;
+  p.ql = caps->ql;
   p.delay_model = cfg->delay_model;
   p.mu = std::log(cfg->mean / std::sqrt(1.0 + cfg->variance / (cfg->mean * cfg->mean)));
   p.sigma = std::sqrt(std::log(1.0 + cfg->variance / (cfg->mean * cfg->mean)));
@@ -56,15 +58,21 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   p.leader_tab = leaders.data(); p.leader_len = (u32)leaders.size();
   p.exp_tab = ET; p.zig_x = ZX; p.zig_f = ZF;
   compute_layout(p);
-  std::vector<u32> state((size_t)p.total_words * p.stride, 0);
+  std::vector<u32> state(state_words(p), 0);
 
   if (threads == 0) threads = 1;
   auto worker = [&](u32 tid) {
     for (size_t i = tid; i < n_instances; i += threads) {
-      Sim s(p, state.data() + i);
+      Sim s(p, state.data() + inst_offset(p, (u32)i));
       s.init(seeds[i]);
+      // emulate the device's launch structure: the LDS front of the queue is a cache of the HBM rows
+      std::vector<u64> keys(p.ql ? p.ql : 1);
+      std::vector<u32> metas(p.ql ? p.ql : 1);
+      s.attach_queue(keys.data(), metas.data(), 1, p.ql);
       s.load_scalars();
+      s.queue_to_lds();
       bool done = s.run();
+      s.queue_from_lds();
       s.store_scalars(done);
     }
   };
@@ -76,7 +84,7 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   if (counters) memset(counters, 0, sizeof(*counters));
   int rc = 0;
   for (size_t i = 0; i < n_instances; i++) {
-    Sim s(p, state.data() + i);
+    Sim s(p, state.data() + inst_offset(p, (u32)i));
     s.load_scalars();
     if (faults) faults[i] = s.fault;
     if (s.fault) rc = 1;

@@ -25,14 +25,17 @@ CASES = {
 }
 
 
+# ql = event-queue slots held in the (emulated) LDS front: 0 = HBM rows only, 5 = almost everything
+# spills across the LDS/HBM boundary, 48 = the device default (the front covers the high-water mark at n <= 4)
+@pytest.mark.parametrize("ql", [0, 5, 48])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_host_model_equals_oracle(oracle, name):
+def test_host_model_equals_oracle(oracle, name, ql):
     kw, m, max_clock = CASES[name]
     cfg = oracle.make_config(math_mode=1, **kw)
     seeds = np.arange(1000, 1000 + m, dtype=np.uint64) * 7919
     a = oracle.run_batch(cfg, seeds, max_clock, threads=8, history_cap=512)
     b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=8, history_cap=512, qcap=4096, scap=512, bcap=1024,
-                                   lcap=1024)
+                                   lcap=1024, ql=ql)
     assert not b["faults"].any()
     for key in ("commit_counts", "active_rounds", "last_states", "histories"):
         assert (a[key] == b[key]).all(), key
