@@ -27,7 +27,7 @@ extern "C" {
 #define LBFT_ERR_FAULT (-5)       /* the run finished but >= 1 instance raised a sticky fault (capacity overflow or an
                                      invariant on which the reference itself would have panicked); see lbft_batch_faults */
 
-#define LBFT_MAX_NODES_SUPPORTED 32
+#define LBFT_MAX_NODES_SUPPORTED 128
 
 /* Per-instance sticky fault bits (lbft_batch_faults). */
 #define LBFT_FAULT_QUEUE_OVERFLOW (1u << 0)

@@ -34,7 +34,7 @@ typedef int32_t i32;
 typedef uint64_t u64;
 typedef int64_t i64;
 
-#define LBFT_MAX_NODES 32  // masks are 32-bit words in this kernel family
+#define LBFT_MAX_NODES 128  // node / author sets are 1..4 32-bit words (word 0 in the hot rows, the rest in extension rows)
 
 // Sticky per-instance fault bits (readable after the run; never abort the process).
 enum Fault : u32 {
@@ -65,8 +65,11 @@ struct Params {
   u64 cpe;  // commands_per_epoch
   i64 tci;  // target_commit_interval
   double lambda;
-  u32 weights[LBFT_MAX_NODES];
+  const u32* weights;  // voting rights (device table; unit_weights short-cuts it)
+  u32 mw;              // mask words = ceil(n / 32)
+  u32 qheap;           // event queue is a binary heap in the HBM rows (large networks) instead of the LDS-fronted array
   u32 total_votes, quorum;
+  u32 unit_weights;  // every voting right is 1 (the reference's SimulatedContext, simulated_context.rs:209-216)
   u32 dur_len, leader_len;
   const i64* dur_tab;    // dur_tab[k] = (i64)(delta * pow(k, gamma)) computed by the host libm (pacemaker.rs:123)
   const u8* leader_tab;  // leader_tab[r] = PacemakerState::leader(r), filled by lbft_fill_leader_table
@@ -79,6 +82,7 @@ struct Params {
   u32 off_snap, snap_words, off_snap_ref, off_snap_free;
   u32 off_blk, blk_words;
   u32 off_log;
+  u32 off_list;  // n > 16 only: receiver list scratch of process_node_actions
   u32 total_words;
   u32 max_steps;  // events per instance per launch (0 = unlimited)
   u32 lpw;        // lanes of each wavefront that carry an instance (1..64): occupancy vs lane-utilisation knob
@@ -103,21 +107,18 @@ struct Params {
 #endif
 
 // HBM layout: instances are grouped in tiles of 64 (one wavefront's worth); a tile is contiguous and holds
-// its rows word-interleaved: word w of instance i lives at state[(i / 64) * total_words * 64 + w * 64 + i % 64].
-// A wavefront's 64 lanes read row w as one 256-byte segment, and everything a wavefront ever touches sits
-// in one contiguous ~1 MB window (TLB- and DRAM-page-friendly), instead of one row per 256 KB.
-// (-DLBFT_ROW_MAJOR keeps the first layout -- row w of ALL instances contiguous -- for A/B measurements.)
-#if defined(LBFT_ROW_MAJOR)
-#define LBFT_ROW_STRIDE(P) ((P).stride)
-#else
-#define LBFT_ROW_STRIDE(P) 64u
-#endif
+// its rows word-interleaved: word w of instance i lives at byte (i / 64) * total_words * 256 + w * 256 +
+// (i % 64) * 4.  A wavefront's 64 lanes read row w as one 256-byte segment, and everything a wavefront ever
+// touches sits in one contiguous ~1 MB window (TLB- and DRAM-page-friendly).  Inside the run kernel the
+// tile base is wavefront-uniform (an SGPR pair) and a row access is `tile + u32 byte offset`, i.e. the
+// saddr + 32-bit voffset form of global_load/global_store: no 64-bit vector address arithmetic.
+#define LBFT_ROW_BYTES 256u
 
 // Instance-level rows.
 enum InstField : u32 {
   I_CLOCK = 0, I_STAMP, I_RNG0, I_RNG1, I_RNG2, I_RNG3, I_RNG4, I_RNG5, I_RNG6, I_RNG7,
   I_QLEN, I_SNAP_FREE, I_NBLOCKS, I_FAULT, I_EV0, I_EV1, I_EV2, I_EV3, I_DRAWS, I_DONE,
-  I_MAXQ, I_MAXSNAP, I_WORDS
+  I_MAXQ, I_MAXSNAP, I_SNAP_MASK_LO, I_SNAP_MASK_HI, I_WORDS
 };
 
 // Node-level rows (RecordStoreState record_store.rs:93-119, PacemakerState pacemaker.rs:60-77,
@@ -132,21 +133,24 @@ enum NodeField : u32 {
   NF_LVR, NF_LOCKED, NF_LQAT, NF_TR_EPOCH, NF_TR_HCR, NF_TR_LCT,
   NF_NEXT_CMD, NF_LAST_COMMITTED_BLK, NF_NCOMMITS,
   NF_LAST_TIMER_T, NF_TIMER_DUPS,  // duplicate-timer folding (see process_node_actions)
-  NF_FIXED_WORDS  // followed by tc_hcbr[n] and to_hcbr[n]
+  NF_TC_SEL,  // which of the two hcbr[n] buffers holds the timeout certificate (the other: current timeouts)
+  NF_FIXED_WORDS  // followed by hcbr[2][n]: highest_certified_block_round per timeout author
 };
 
 // Block rows.  The first BC_WORDS rows are the "hot record" that the event loop works on (held in a small
 // register-resident cache, see Sim::blk_get): the block's round and links, the rounds of its parent and
 // grandparent (denormalised at proposal time, so the 3-chain commit rule record_store.rs:221-235 and the
 // voting constraints node.rs:256-276 need one record instead of a pointer chase through three), the
-// epoch, and the three per-node knowledge masks.  B_TIME / B_CMD / B_DEPTH are only read when a block is
-// proposed on top of this one, committed, or exported.
+// epoch, the ledger depth and the three per-node knowledge masks.  B_TIME / B_CMD are only read when a
+// committed history is exported or hashed.
 enum BlockField : u32 {
   B_ROUND = 0, B_LINK /* prev | author << 16 */, B_PREV_ROUND, B_PP /* grandparent block id */, B_PP_ROUND, B_EPOCH,
-  B_KNOWN, B_QC, B_PEND, BC_WORDS,
-  B_TIME = BC_WORDS, B_CMD, B_DEPTH, B_WORDS
+  B_DEPTH /* commands in the ledger after this block */, B_KNOWN, B_QC, B_PEND, BC_WORDS,
+  B_TIME = BC_WORDS, B_CMD, B_WORDS
 };
+#ifndef LBFT_BLK_CACHE
 #define LBFT_BLK_CACHE 6  // register-resident block records per instance (FIFO)
+#endif
 
 // Snapshot (notification, data_sync.rs:16-39) rows; followed by tc_hcbr[n], to_hcbr[n].
 enum SnapField : u32 { S_EPOCH = 0, S_CERTS /* hcc | hqc << 16 */, S_PROP_VOTE /* proposed | vote << 16 */, S_TC_ROUND, S_TO_ROUND, S_TC_MASK, S_TO_MASK, S_FIXED_WORDS };
@@ -282,15 +286,10 @@ LBFT_HD u32 compute_leader(const u32* weights, u32 n, u32 total_votes, u64 round
   return 0;  // unreachable
 }
 
-// Word offset of instance i's column (row 0) in the state array.
-#if defined(LBFT_ROW_MAJOR)
-LBFT_HD size_t inst_offset(const Params& p, u32 i) { (void)p; return i; }
-LBFT_HD size_t state_words(const Params& p) { return (size_t)p.total_words * p.stride; }
-#else
-LBFT_HD size_t inst_offset(const Params& p, u32 i) { return (size_t)(i >> 6) * p.total_words * 64u + (i & 63u); }
+// Byte offset of instance i's tile / word offset of a word of instance i in the state array.
+LBFT_HD size_t tile_offset_bytes(const Params& p, u32 i) { return (size_t)(i >> 6) * p.total_words * LBFT_ROW_BYTES; }
 LBFT_HD size_t state_words(const Params& p) { return (size_t)p.total_words * p.stride; }  // stride = m padded to 64
-#endif
-LBFT_HD size_t word_offset(const Params& p, u32 i, u32 w) { return inst_offset(p, i) + (size_t)w * LBFT_ROW_STRIDE(p); }
+LBFT_HD size_t word_offset(const Params& p, u32 i, u32 w) { return tile_offset_bytes(p, i) / 4 + (size_t)w * 64u + (i & 63u); }
 
 struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at most one element
   i64 next;
@@ -300,14 +299,27 @@ struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at
 };
 
 // ------------------------------------------------------------------------------------------------
-// One simulated network.  `row0` points at this instance's column (state + inst).
+// One simulated network: `tile` is the instance's tile, `lane4` the byte offset of its column in a row.
 // ------------------------------------------------------------------------------------------------
-struct Sim {
+// CLS specialises the step for a network-size class so that the headline small-network path carries none of
+// the large-network machinery:
+//   0  n <= 16, array event queue behind the LDS front, receiver list packed in a register, one mask word
+//   1  n <= 32, one mask word; heap / packed list decided at run time
+//   2  n <= 128, multi-word node/author sets (extension rows), heap event queue, receiver list in HBM rows
+//   3  everything decided at run time (init / read-back kernels)
+// sim_class() picks the class a batch runs with.
+template <int CLS>
+struct SimT {
+  LBFT_HD bool wide() const { return CLS == 2 ? true : (CLS == 3 ? P.n > 32 : false); }
+  LBFT_HD bool heap() const { return CLS == 0 ? false : (CLS == 2 ? true : P.qheap != 0); }
+  LBFT_HD bool packed() const { return CLS == 0 ? true : (CLS == 2 ? false : P.n <= 16); }
   const Params& P;
-  u32* row0;
+  char* tile;
+  u32 lane4;
   // instance scalars cached in registers for the duration of a launch
   i32 clock;
   u32 stamp, qlen, snap_free, nblocks, fault, maxq, maxsnap;
+  u64 snap_mask;  // scap <= 64: free snapshot slots as a bit set held in registers (no free-stack round trip)
   u32 ev0, ev1, ev2, ev3;
   Rng rng;
 
@@ -319,16 +331,26 @@ struct Sim {
   u32 qstr, ql;
   // read-only tables (LDS copies on the device)
   const u64 *zig_x, *zig_f, *exp_tab;
+  const u8* leader_lds;   // first leader_lds_len rounds of the leader table
+  const i64* dur_lds;     // first dur_lds_len entries of the duration table
+  u32 leader_lds_len, dur_lds_len;
 #if defined(LBFT_PHASE_TIMERS) && defined(__HIPCC__)
   u64* wprof;  // this wavefront's LDS accumulators
 #endif
 
-  LBFT_HD Sim(const Params& p, u32* r) : P(p), row0(r), qk(nullptr), qm(nullptr), qstr(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab) {}
+  LBFT_HD SimT(const Params& p, u32* state, u32 i) : SimT(p, reinterpret_cast<char*>(state) + tile_offset_bytes(p, i), (i & 63u) * 4u, 0) {}
+  LBFT_HD SimT(const Params& p, char* tile_base, u32 lane_byte_offset, int) : P(p), tile(tile_base), lane4(lane_byte_offset), qk(nullptr), qm(nullptr), qstr(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab),
+        leader_lds(nullptr), dur_lds(nullptr), leader_lds_len(0), dur_lds_len(0) {}
   LBFT_HD void attach_queue(u64* keys, u32* metas, u32 stride, u32 slots) { qk = keys; qm = metas; qstr = stride; ql = slots; }
   LBFT_HD void attach_tables(const u64* zx, const u64* zf, const u64* et) { zig_x = zx; zig_f = zf; exp_tab = et; }
+  LBFT_HD void attach_round_tables(const u8* leaders, u32 nl, const i64* durs, u32 nd) { leader_lds = leaders; leader_lds_len = nl; dur_lds = durs; dur_lds_len = nd; }
 
-  LBFT_HD u32 ld(u32 w) const { return row0[(size_t)w * LBFT_ROW_STRIDE(P)]; }
-  LBFT_HD void st(u32 w, u32 v) const { row0[(size_t)w * LBFT_ROW_STRIDE(P)] = v; }
+  LBFT_HD u32 boff(u32 w) const { return (w << 8) + lane4; }  // tile-relative byte offset of row w (a tile is < 4 GiB)
+  LBFT_HD u32 ld(u32 w) const { return *reinterpret_cast<const u32*>(tile + (size_t)boff(w)); }
+  LBFT_HD void st(u32 w, u32 v) const { *reinterpret_cast<u32*>(tile + (size_t)boff(w)) = v; }
+  // row (w0 + f) given boff(w0): groups of 16 rows share one 32-bit base, the rest is the instruction's immediate
+  LBFT_HD u32 ldf(u32 base, u32 f) const { return *reinterpret_cast<const u32*>(tile + (size_t)(base + (f & ~15u) * LBFT_ROW_BYTES) + (f & 15u) * LBFT_ROW_BYTES); }
+  LBFT_HD void stf(u32 base, u32 f, u32 v) const { *reinterpret_cast<u32*>(tile + (size_t)(base + (f & ~15u) * LBFT_ROW_BYTES) + (f & 15u) * LBFT_ROW_BYTES) = v; }
 
   // ---- field accessors ----
   LBFT_HD u32 nfw(u32 node, u32 f) const { return P.off_node + node * P.node_words + f; }
@@ -348,23 +370,23 @@ struct Sim {
   }
   LBFT_HD void begin_node(u32 node) const {
     // one base pointer, then constant row offsets: the 38 loads become one burst with immediate offsets
-    const u32* nb = row0 + (size_t)(P.off_node + node * P.node_words) * LBFT_ROW_STRIDE(P);
+    u32 nb = boff(P.off_node + node * P.node_words);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (u32 f = 0; f < NF_FIXED_WORDS; f++) cw[f] = nb[(size_t)f * LBFT_ROW_STRIDE(P)];
+    for (u32 f = 0; f < NF_FIXED_WORDS; f++) cw[f] = ldf(nb, f);
     cdirty = 0;
   }
   LBFT_HD void end_node(u32 node) const {
-    u32* nb = row0 + (size_t)(P.off_node + node * P.node_words) * LBFT_ROW_STRIDE(P);
+    u32 nb = boff(P.off_node + node * P.node_words);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (u32 f = 0; f < NF_FIXED_WORDS; f++)
-      if ((cdirty >> f) & 1ULL) nb[(size_t)f * LBFT_ROW_STRIDE(P)] = cw[f];
+      if ((cdirty >> f) & 1ULL) stf(nb, f, cw[f]);
   }
   LBFT_HD u32 bfw(u32 b, u32 f) const { return P.off_blk + (b - 1) * P.blk_words + f; }
-  LBFT_HD u32 bf(u32 b, u32 f) const { return ld(bfw(b, f)); }   // cold fields (B_TIME, B_CMD, B_DEPTH) and read-back
+  LBFT_HD u32 bf(u32 b, u32 f) const { return ld(bfw(b, f)); }   // cold fields (B_TIME, B_CMD) and read-back
   LBFT_HD void bfs(u32 b, u32 f, u32 v) const { st(bfw(b, f), v); }
   LBFT_HD u32 blk_author(u32 b) const { return bf(b, B_LINK) >> 16; }
 
@@ -382,18 +404,25 @@ struct Sim {
     LBFT_HD u32 pp() const { return w[B_PP]; }
     LBFT_HD u32 pp_round() const { return w[B_PP_ROUND]; }
     LBFT_HD u32 epoch() const { return w[B_EPOCH]; }
-    LBFT_HD bool known(u32 node) const { return (w[B_KNOWN] >> node) & 1u; }
-    LBFT_HD bool qc(u32 node) const { return (w[B_QC] >> node) & 1u; }
-    LBFT_HD bool pend(u32 node) const { return (w[B_PEND] >> node) & 1u; }
+    LBFT_HD u32 depth() const { return w[B_DEPTH]; }
   };
   mutable u32 bc_id[LBFT_BLK_CACHE];
   mutable u32 bc_w[LBFT_BLK_CACHE][BC_WORDS];
-  mutable u32 bc_next;
+  mutable u32 bc_next, bc_ref;  // FIFO hand + "recently used" bits (second chance: a hot old block survives)
   LBFT_HD void blk_cache_reset() const {
     for (u32 e = 0; e < LBFT_BLK_CACHE; e++) bc_id[e] = 0;
-    bc_next = 0;
+    bc_next = 0; bc_ref = 0;
   }
   LBFT_HD void blk_cache_insert(u32 b, const Blk& r) const {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 t = 0; t < LBFT_BLK_CACHE; t++) {  // skip (and age) entries used since the hand last passed
+      if ((bc_ref >> bc_next) & 1u) {
+        bc_ref &= ~(1u << bc_next);
+        bc_next = bc_next + 1 == LBFT_BLK_CACHE ? 0 : bc_next + 1;
+      }
+    }
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -421,20 +450,39 @@ struct Sim {
     for (u32 e = 0; e < LBFT_BLK_CACHE; e++) {
       if (bc_id[e] == b) {
         hit = true;
+        bc_ref |= 1u << e;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
         for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = bc_w[e][f];
       }
     }
+    LBFT_COUNT(26);
     if (!hit) {
+      LBFT_COUNT(25);
+      u32 bb = boff(bfw(b, 0));
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = ld(bfw(b, f));  // one burst of independent loads
+      for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = ldf(bb, f);  // one burst of independent loads
       blk_cache_insert(b, r);
     }
     return r;
+  }
+  // Node sets of a block (B_KNOWN / B_QC / B_PEND): nodes 0..31 live in the hot record, nodes >= 32 (n > 32
+  // only) in extension rows behind the cold fields.
+  LBFT_HD u32 bxw(u32 b, u32 f, u32 k) const { return bfw(b, B_WORDS + (f - B_KNOWN) * (P.mw - 1) + k - 1); }
+  LBFT_HD bool bm_test(u32 b, const Blk& rb, u32 f, u32 node) const {
+    if (!wide() || node < 32) return (rb.w[f] >> node) & 1u;
+    return (ld(bxw(b, f, node >> 5)) >> (node & 31u)) & 1u;
+  }
+  LBFT_HD void bm_set(u32 b, Blk& rb, u32 f, u32 node) const {
+    if (!wide() || node < 32) { rb.w[f] |= 1u << node; blk_put(b, f, rb.w[f]); }
+    else { u32 w = bxw(b, f, node >> 5); st(w, ld(w) | (1u << (node & 31u))); }
+  }
+  LBFT_HD void bm_clr(u32 b, Blk& rb, u32 f, u32 node) const {
+    if (!wide() || node < 32) { rb.w[f] &= ~(1u << node); blk_put(b, f, rb.w[f]); }
+    else { u32 w = bxw(b, f, node >> 5); st(w, ld(w) & ~(1u << (node & 31u))); }
   }
   // Write-through update of one mask word of block b (f is B_KNOWN, B_QC or B_PEND).
   LBFT_HD void blk_put(u32 b, u32 f, u32 v) const {
@@ -450,6 +498,8 @@ struct Sim {
       }
   }
   LBFT_HD u32 sfw(u32 slot, u32 f) const { return P.off_snap + slot * P.snap_words + f; }
+  // extension word k >= 1 of a snapshot's TC (which = 0) / current-timeout (which = 1) author set
+  LBFT_HD u32 sxw(u32 slot, u32 which, u32 k) const { return sfw(slot, S_FIXED_WORDS + 2 * P.n + which * (P.mw - 1) + k - 1); }
 
   LBFT_HD void load_scalars() {
     clock = (i32)ld(I_CLOCK); stamp = ld(I_STAMP);
@@ -459,6 +509,7 @@ struct Sim {
     qlen = ld(I_QLEN); snap_free = ld(I_SNAP_FREE); nblocks = ld(I_NBLOCKS); fault = ld(I_FAULT);
     ev0 = ld(I_EV0); ev1 = ld(I_EV1); ev2 = ld(I_EV2); ev3 = ld(I_EV3);
     maxq = ld(I_MAXQ); maxsnap = ld(I_MAXSNAP);
+    snap_mask = ld(I_SNAP_MASK_LO) | ((u64)ld(I_SNAP_MASK_HI) << 32);
     blk_cache_reset();
   }
   LBFT_HD void store_scalars(bool done) {
@@ -469,6 +520,7 @@ struct Sim {
     st(I_QLEN, qlen); st(I_SNAP_FREE, snap_free); st(I_NBLOCKS, nblocks); st(I_FAULT, fault);
     st(I_EV0, ev0); st(I_EV1, ev1); st(I_EV2, ev2); st(I_EV3, ev3);
     st(I_MAXQ, maxq); st(I_MAXSNAP, maxsnap);
+    st(I_SNAP_MASK_LO, (u32)snap_mask); st(I_SNAP_MASK_HI, (u32)(snap_mask >> 32));
     st(I_DONE, done ? 1u : 0u);
   }
 
@@ -536,7 +588,22 @@ struct Sim {
     if (time > (i64)P.max_clock) return false;
     if (my_stamp >= (1u << 30)) { fault |= F_STAMP_OVERFLOW; return false; }
     if (qlen >= P.qcap) { fault |= F_QUEUE_OVERFLOW; return false; }
-    q_set(qlen, ((u64)(u32)time << 32) | ((3u - kind) << 30) | my_stamp, node | (sender << 8) | (slot << 16));
+    u64 key = ((u64)(u32)time << 32) | ((3u - kind) << 30) | my_stamp;
+    u32 meta = node | (sender << 8) | (slot << 16);
+    if (heap()) {  // large networks: binary min-heap in the HBM rows, sift up
+      u32 i = qlen;
+      while (i > 0) {
+        u32 par = (i - 1) >> 1;
+        u64 pk; u32 pm;
+        q_get(par, pk, pm);
+        if (pk < key) break;
+        q_set(i, pk, pm);
+        i = par;
+      }
+      q_set(i, key, meta);
+    } else {
+      q_set(qlen, key, meta);
+    }
     qlen++;
     if (qlen > maxq) maxq = qlen;
     return true;
@@ -544,6 +611,35 @@ struct Sim {
   // Removes the minimum; returns false when the queue is empty.
   LBFT_HD bool pop_event(i32& time, u32& kind, u32& meta) {
     if (qlen == 0) return false;
+    if (heap()) {  // binary min-heap: take the root, sift the last entry down from the top
+      u64 rk; u32 rm;
+      q_get(0, rk, rm);
+      time = (i32)(u32)(rk >> 32);
+      kind = 3u - ((u32)rk >> 30);
+      meta = rm;
+      qlen--;
+      if (qlen) {
+        u64 lk; u32 lm;
+        q_get(qlen, lk, lm);
+        u32 i = 0;
+        for (;;) {
+          u32 c = 2 * i + 1;
+          if (c >= qlen) break;
+          u64 ck; u32 cm;
+          q_get(c, ck, cm);
+          if (c + 1 < qlen) {
+            u64 dk; u32 dm;
+            q_get(c + 1, dk, dm);
+            if (dk < ck) { ck = dk; cm = dm; c = c + 1; }
+          }
+          if (lk < ck) break;
+          q_set(i, ck, cm);
+          i = c;
+        }
+        q_set(i, lk, lm);
+      }
+      return true;
+    }
     u32 best = 0;
     u64 bkey = ~0ULL;
     u32 nl = qlen < ql ? qlen : ql;
@@ -571,7 +667,27 @@ struct Sim {
   }
 
   // ---- snapshot slots (free stack + refcount) ----
+  LBFT_HD u32 ctz64(u64 x) const { return (u32)x ? ctz32((u32)x) : 32u + ctz32((u32)(x >> 32)); }
+  LBFT_HD u32 popc64(u64 x) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (u32)__popcll(x);
+#else
+    return (u32)__builtin_popcountll(x);
+#endif
+  }
+  LBFT_HD void snap_free_slot(u32 slot) {
+    if (P.scap <= 64) snap_mask |= 1ULL << slot;
+    else { st(P.off_snap_free + snap_free, slot); snap_free++; }
+  }
   LBFT_HD i32 snap_alloc() {
+    if (P.scap <= 64) {
+      if (snap_mask == 0) { fault |= F_SNAP_OVERFLOW; return -1; }
+      u32 slot = ctz64(snap_mask);
+      snap_mask &= snap_mask - 1;
+      u32 live = P.scap - popc64(snap_mask);
+      if (live > maxsnap) maxsnap = live;
+      return (i32)slot;
+    }
     if (snap_free == 0) { fault |= F_SNAP_OVERFLOW; return -1; }
     snap_free--;
     u32 live = P.scap - snap_free;
@@ -581,11 +697,14 @@ struct Sim {
   LBFT_HD void snap_release(u32 slot) {
     u32 r = ld(P.off_snap_ref + slot) - 1;
     st(P.off_snap_ref + slot, r);
-    if (r == 0) { st(P.off_snap_free + snap_free, slot); snap_free++; }
+    if (r == 0) snap_free_slot(slot);
   }
+
+  LBFT_HD u32 weight(u32 author) const { return P.unit_weights ? 1u : P.weights[author]; }  // vector load from a small table
 
   // ---- leader / duration ----
   LBFT_HD u32 leader(u32 round) const {
+    if (round < leader_lds_len) return leader_lds[round];
     if (round < P.leader_len) return P.leader_tab[round];
     return compute_leader(P.weights, P.n, P.total_votes, round);
   }
@@ -594,7 +713,8 @@ struct Sim {
   LBFT_HD bool state_available(u32 node, u32 blk) const {
     if (blk == nf(node, NF_LAST_COMMITTED_BLK)) return true;
     if (blk == 0) return false;
-    return blk_get(blk).pend(node);
+    Blk r = blk_get(blk);
+    return bm_test(blk, r, B_PEND, node);
   }
   // RecordStoreState::compute_state (record_store.rs:426-454) + CommandExecutor::compute.
   // `rb` is the caller's copy of block b's record; its pending mask is updated in place.
@@ -602,21 +722,43 @@ struct Sim {
     u32 prev = rb.prev();
     u32 base = prev ? prev : nf(node, NF_INIT_STATE_BLK);
     if (!state_available(node, base)) return false;
-    rb.w[B_PEND] |= 1u << node;
-    blk_put(b, B_PEND, rb.w[B_PEND]);
+    bm_set(b, rb, B_PEND, node);
     return true;
+  }
+
+  // ---- author sets of a node (NF_TC_MASK, NF_TO_MASK, NF_BAL0_AUTHORS, NF_BAL1_AUTHORS): authors 0..31 in
+  // the cached fixed rows, authors >= 32 (n > 32 only) in extension rows behind the hcbr buffers ----
+  LBFT_HD u32 am_idx(u32 f) const { return f == NF_TC_MASK ? 0u : f == NF_TO_MASK ? 1u : f == NF_BAL0_AUTHORS ? 2u : 3u; }
+  LBFT_HD u32 amxw(u32 node, u32 f, u32 k) const { return nfw(node, NF_FIXED_WORDS + 2 * P.n + am_idx(f) * (P.mw - 1) + k - 1); }
+  LBFT_HD u32 am_word(u32 node, u32 f, u32 k) const { return k == 0 ? nf(node, f) : ld(amxw(node, f, k)); }
+  LBFT_HD void am_set_word(u32 node, u32 f, u32 k, u32 v) const { if (k == 0) nfs(node, f, v); else st(amxw(node, f, k), v); }
+  LBFT_HD bool am_test(u32 node, u32 f, u32 a) const {
+    if (!wide() || a < 32) return (nf(node, f) >> a) & 1u;
+    return (ld(amxw(node, f, a >> 5)) >> (a & 31u)) & 1u;
+  }
+  LBFT_HD void am_set(u32 node, u32 f, u32 a) const {
+    if (!wide() || a < 32) nfs(node, f, nf(node, f) | (1u << a));
+    else { u32 w = amxw(node, f, a >> 5); st(w, ld(w) | (1u << (a & 31u))); }
+  }
+  LBFT_HD void am_clear(u32 node, u32 f) const {
+    nfs(node, f, 0);
+    for (u32 k = 1; wide() && k < P.mw; k++) st(amxw(node, f, k), 0);
+  }
+  LBFT_HD void am_copy(u32 node, u32 dst, u32 src) const {
+    nfs(node, dst, nf(node, src));
+    for (u32 k = 1; wide() && k < P.mw; k++) st(amxw(node, dst, k), ld(amxw(node, src, k)));
   }
 
   // ---- RecordStoreState ----
   LBFT_HD void clear_ballot(u32 node) const {
-    nfs(node, NF_BAL0_BLK, 0); nfs(node, NF_BAL0_WEIGHT, 0); nfs(node, NF_BAL0_AUTHORS, 0);
-    nfs(node, NF_BAL1_BLK, 0); nfs(node, NF_BAL1_WEIGHT, 0); nfs(node, NF_BAL1_AUTHORS, 0);
+    nfs(node, NF_BAL0_BLK, 0); nfs(node, NF_BAL0_WEIGHT, 0); am_clear(node, NF_BAL0_AUTHORS);
+    nfs(node, NF_BAL1_BLK, 0); nfs(node, NF_BAL1_WEIGHT, 0); am_clear(node, NF_BAL1_AUTHORS);
   }
   LBFT_HD void update_current_round(u32 node, u32 round) const {  // record_store.rs:207-219
     if (round <= nf(node, NF_CUR_ROUND)) return;
     nfs(node, NF_CUR_ROUND, round);
     nfs(node, NF_PROPOSED_BLK, 0);
-    nfs(node, NF_TO_MASK, 0);
+    am_clear(node, NF_TO_MASK);
     nfs(node, NF_TO_WEIGHT, 0);
     nfs(node, NF_ELECTION, 0);
     clear_ballot(node);
@@ -632,10 +774,9 @@ struct Sim {
   // verify_network_record + try_insert_network_record for a QC (record_store.rs:330-389,500-526).
   // Caller has already checked qc.epoch_id == node epoch (node.rs:151-167).
   LBFT_HD void insert_qc(u32 node, u32 b, Blk& rb) const {
-    if (rb.qc(node)) return;      // "QuorumCertificate was already inserted."
-    if (!rb.known(node)) return;  // "The certified block hash of a QC must be verified first."
-    rb.w[B_QC] |= 1u << node;     // Q3: stored before the execution check
-    blk_put(b, B_QC, rb.w[B_QC]);
+    if (bm_test(b, rb, B_QC, node)) return;      // "QuorumCertificate was already inserted."
+    if (!bm_test(b, rb, B_KNOWN, node)) return;  // "The certified block hash of a QC must be verified first."
+    bm_set(b, rb, B_QC, node);                   // Q3: stored before the execution check
     if (!compute_state(node, b, rb)) return;  // bail!("I failed to execute a block with a QC ...")
     u32 r = rb.round();
     if (r > nf(node, NF_HQC_ROUND)) { nfs(node, NF_HQC_ROUND, r); nfs(node, NF_HQC_BLK, b); }
@@ -648,13 +789,15 @@ struct Sim {
   }
   // Block (record_store.rs:263-291,466-476)
   LBFT_HD void insert_block(u32 node, u32 b, Blk& rb) const {
-    if (rb.known(node)) return;  // "Block was already inserted."
+    if (bm_test(b, rb, B_KNOWN, node)) return;  // "Block was already inserted."
     u32 p = rb.prev();
-    if (p && !blk_get(p).qc(node)) return;  // "The previous QC (if any) must be verified first."
+    if (p) {  // "The previous QC (if any) must be verified first."
+      Blk rp = blk_get(p);
+      if (!bm_test(p, rp, B_QC, node)) return;
+    }
     u32 r = rb.round();
     if (r == nf(node, NF_CUR_ROUND) && leader(r) == rb.author()) nfs(node, NF_PROPOSED_BLK, b);
-    rb.w[B_KNOWN] |= 1u << node;
-    blk_put(b, B_KNOWN, rb.w[B_KNOWN]);
+    bm_set(b, rb, B_KNOWN, node);
   }
   LBFT_HD void insert_block(u32 node, u32 b) const {
     Blk rb = blk_get(b);
@@ -662,27 +805,26 @@ struct Sim {
   }
   // Vote (record_store.rs:292-329,477-499).  Caller checked the epoch.
   LBFT_HD void insert_vote(u32 node, u32 author, u32 b, const Blk& rb) {
-    if (!rb.known(node)) return;
+    if (!bm_test(b, rb, B_KNOWN, node)) return;
     if (rb.round() != nf(node, NF_CUR_ROUND)) return;
-    u32 a0 = nf(node, NF_BAL0_AUTHORS), a1 = nf(node, NF_BAL1_AUTHORS);
-    if (((a0 | a1) >> author) & 1u) return;  // one vote per author
+    if (am_test(node, NF_BAL0_AUTHORS, author) || am_test(node, NF_BAL1_AUTHORS, author)) return;  // one vote per author
     u32 b0 = nf(node, NF_BAL0_BLK), b1 = nf(node, NF_BAL1_BLK);
     bool ongoing = (nf(node, NF_ELECTION) & 0xff) == 0;
     // two ballot entries (block, weight, authors); field indices stay compile-time constants so that
     // the node cache remains in registers
     if (b0 == b || b0 == 0) {
       nfs(node, NF_BAL0_BLK, b);
-      nfs(node, NF_BAL0_AUTHORS, a0 | (1u << author));
+      am_set(node, NF_BAL0_AUTHORS, author);
       if (ongoing) {
-        u32 w = nf(node, NF_BAL0_WEIGHT) + P.weights[author];
+        u32 w = nf(node, NF_BAL0_WEIGHT) + weight(author);
         nfs(node, NF_BAL0_WEIGHT, w);
         if (w >= P.quorum) nfs(node, NF_ELECTION, 1u | (b << 8));
       }
     } else if (b1 == b || b1 == 0) {
       nfs(node, NF_BAL1_BLK, b);
-      nfs(node, NF_BAL1_AUTHORS, a1 | (1u << author));
+      am_set(node, NF_BAL1_AUTHORS, author);
       if (ongoing) {
-        u32 w = nf(node, NF_BAL1_WEIGHT) + P.weights[author];
+        u32 w = nf(node, NF_BAL1_WEIGHT) + weight(author);
         nfs(node, NF_BAL1_WEIGHT, w);
         if (w >= P.quorum) nfs(node, NF_ELECTION, 1u | (b << 8));
       }
@@ -695,18 +837,38 @@ struct Sim {
     if (hcbr > nf(node, NF_HQC_ROUND)) return;
     u32 cur = nf(node, NF_CUR_ROUND);
     if (round != cur) return;
-    u32 mask = nf(node, NF_TO_MASK);
-    if ((mask >> author) & 1u) return;
-    mask |= 1u << author;
-    nfs(node, NF_TO_MASK, mask);
-    nfms(node, NF_FIXED_WORDS + P.n + author, hcbr);
-    u32 w = nf(node, NF_TO_WEIGHT) + P.weights[author];
+    if (am_test(node, NF_TO_MASK, author)) return;
+    am_set(node, NF_TO_MASK, author);
+    u32 tc_sel = nf(node, NF_TC_SEL);
+    nfms(node, NF_FIXED_WORDS + (1u - tc_sel) * P.n + author, hcbr);
+    u32 w = nf(node, NF_TO_WEIGHT) + weight(author);
     nfs(node, NF_TO_WEIGHT, w);
     if (w >= P.quorum) {
-      nfs(node, NF_TC_MASK, mask);
-      for (u32 a = 0; a < P.n; a++) nfms(node, NF_FIXED_WORDS + a, nfm(node, NF_FIXED_WORDS + P.n + a));
+      // the current timeouts become the timeout certificate (record_store.rs:532-534): swap the buffers
+      // instead of copying n words; the other buffer's stale entries are masked by the now-empty TO mask
+      am_copy(node, NF_TC_MASK, NF_TO_MASK);
+      nfs(node, NF_TC_SEL, 1u - tc_sel);
       nfs(node, NF_HTC_ROUND, cur);
       update_current_round(node, cur + 1);
+    }
+  }
+  // The timeouts of a notification (data_sync.rs:150-163), in author order; the hcbr words of up to four
+  // authors are fetched in one burst before they are inserted.
+  LBFT_HD void insert_timeouts(u32 node, u32 slot, u32 first_word, u32 mask, u32 round, u32 author0 = 0) const {
+    while (mask) {
+      u32 a[4], h[4], k = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 j = 0; j < 4; j++) {
+        a[j] = 0; h[j] = 0;
+        if (mask) { a[j] = author0 + ctz32(mask); mask &= mask - 1; h[j] = ld(sfw(slot, first_word + a[j])); k = j + 1; }
+      }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 j = 0; j < 4; j++)
+        if (j < k) insert_timeout(node, a[j], round, h[j]);
     }
   }
   // RecordStore::proposed_block (record_store.rs:611-634): block id or 0
@@ -722,14 +884,14 @@ struct Sim {
     if (nblocks >= P.bcap || nblocks >= 0xfffeu) { fault |= F_BLOCK_OVERFLOW; return; }
     u32 b = ++nblocks;
     u32 base = prev_blk ? prev_blk : nf(node, NF_INIT_STATE_BLK);
-    u32 depth = (base ? bf(base, B_DEPTH) : 0) + 1;
     Blk rb;
     rb.w[B_ROUND] = nf(node, NF_CUR_ROUND);
     rb.w[B_LINK] = prev_blk | (node << 16);
-    rb.w[B_PREV_ROUND] = 0; rb.w[B_PP] = 0; rb.w[B_PP_ROUND] = 0;
-    if (prev_blk) {  // denormalised ancestry: previous_round / second_previous_round (record_store.rs:588-609)
-      Blk rp = blk_get(prev_blk);
-      rb.w[B_PREV_ROUND] = rp.round(); rb.w[B_PP] = rp.prev(); rb.w[B_PP_ROUND] = rp.prev_round();
+    rb.w[B_PREV_ROUND] = 0; rb.w[B_PP] = 0; rb.w[B_PP_ROUND] = 0; rb.w[B_DEPTH] = 1;
+    if (base) {  // denormalised ancestry: previous_round / second_previous_round (record_store.rs:588-609)
+      Blk rp = blk_get(base);
+      rb.w[B_DEPTH] = rp.depth() + 1;
+      if (prev_blk) { rb.w[B_PREV_ROUND] = rp.round(); rb.w[B_PP] = rp.prev(); rb.w[B_PP_ROUND] = rp.prev_round(); }
     }
     rb.w[B_EPOCH] = nf(node, NF_EPOCH);
     rb.w[B_KNOWN] = 0; rb.w[B_QC] = 0; rb.w[B_PEND] = 0;
@@ -739,7 +901,7 @@ struct Sim {
     for (u32 f = 0; f < BC_WORDS; f++) bfs(b, f, rb.w[f]);
     bfs(b, B_TIME, (u32)(i32)local_clock);
     bfs(b, B_CMD, cmd);
-    bfs(b, B_DEPTH, depth);
+    for (u32 k = 0; wide() && k < 3 * (P.mw - 1); k++) bfs(b, B_WORDS + k, 0);
     blk_cache_insert(b, rb);
     insert_block(node, b, rb);
   }
@@ -770,6 +932,7 @@ struct Sim {
     if (round <= hccr) { fault |= F_INTERNAL; return 0; }
     u32 k = round - hccr;
     if (k >= P.dur_len) { fault |= F_DURATION_TABLE; k = P.dur_len - 1; }
+    if (k < dur_lds_len) return dur_lds[k];
     return P.dur_tab[k];
   }
   LBFT_HD PmActions update_pacemaker(u32 node, i64 lqat, i64 lclock) {
@@ -801,7 +964,7 @@ struct Sim {
     }
     // has_timeout(local_author, active_round) (record_store.rs:651-653); `ar` is the recomputed
     // active round exactly as in the reference (pacemaker.rs:183)
-    bool has_timeout = (ar == nf(node, NF_CUR_ROUND)) && ((nf(node, NF_TO_MASK) >> node) & 1u);
+    bool has_timeout = (ar == nf(node, NF_CUR_ROUND)) && am_test(node, NF_TO_MASK, node);
     if (!has_timeout) {
       i64 deadline = (i64)((u64)start + (u64)dur);
       if (lclock >= deadline) { a.create_timeout = true; a.timeout_round = ar; a.broadcast = true; }
@@ -858,26 +1021,27 @@ struct Sim {
       for (u32 s = 0; s < j; s++) y = blk_get(y).prev();
       Blk ry = blk_get(y);
       // SimulatedContext::commit (simulated_context.rs:160-185)
-      if (!ry.pend(node)) { fault |= F_COMMIT_UNKNOWN_STATE; return; }
+      if (!bm_test(y, ry, B_PEND, node)) { fault |= F_COMMIT_UNKNOWN_STATE; return; }
       u32 prev = ry.prev();
       u32 base = prev ? prev : nf(node, NF_INIT_STATE_BLK);
       if (base != nf(node, NF_LAST_COMMITTED_BLK)) { fault |= F_COMMIT_NOT_SUCCESSOR; return; }
-      blk_put(y, B_PEND, ry.w[B_PEND] & ~(1u << node));
+      bm_clr(y, ry, B_PEND, node);
       nfs(node, NF_LAST_COMMITTED_BLK, y);
       u32 nc = nf(node, NF_NCOMMITS);
       if (nc >= P.lcap) { fault |= F_LOG_OVERFLOW; return; }
       st(P.off_log + node * P.lcap + nc, y);
       nfs(node, NF_NCOMMITS, nc + 1);
       // read_epoch_id (simulated_context.rs:199-207)
-      u64 new_epoch = (u64)bf(y, B_DEPTH) / P.cpe;
-      if (new_epoch > (u64)nf(node, NF_EPOCH)) {
+      // epoch = depth / commands_per_epoch; the (software) 64-bit division only runs when a boundary is crossed
+      if ((u64)ry.depth() >= ((u64)nf(node, NF_EPOCH) + 1) * P.cpe) {
+        u64 new_epoch = (u64)ry.depth() / P.cpe;
         // fresh RecordStoreState for the new epoch (node.rs:331-348, record_store.rs:169-198)
         nfs(node, NF_EPOCH, (u32)new_epoch);
         nfs(node, NF_INIT_STATE_BLK, y);
         nfs(node, NF_PROPOSED_BLK, 0);
         nfs(node, NF_HQC_ROUND, 0); nfs(node, NF_HQC_BLK, 0); nfs(node, NF_HTC_ROUND, 0);
         nfs(node, NF_CUR_ROUND, 1); nfs(node, NF_HC_ROUND, 0); nfs(node, NF_HCC_BLK, 0);
-        nfs(node, NF_TC_MASK, 0); nfs(node, NF_TO_MASK, 0); nfs(node, NF_TO_WEIGHT, 0);
+        am_clear(node, NF_TC_MASK); am_clear(node, NF_TO_MASK); nfs(node, NF_TO_WEIGHT, 0);
         nfs(node, NF_ELECTION, 0);
         clear_ballot(node);
         nfs(node, NF_LVR, 0); nfs(node, NF_LOCKED, 0);
@@ -935,10 +1099,9 @@ struct Sim {
     st(sfw(slot, S_CERTS), nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16));
     u32 pb = proposed_block(node);
     if (pb && blk_get(pb).author() != node) pb = 0;  // "Do not reshare other leaders' proposals."
-    u32 a0 = nf(node, NF_BAL0_AUTHORS), a1 = nf(node, NF_BAL1_AUTHORS);
     u32 vote = 0;  // current_vote(local author) (record_store.rs:762-764)
-    if ((a0 >> node) & 1u) vote = nf(node, NF_BAL0_BLK);
-    else if ((a1 >> node) & 1u) vote = nf(node, NF_BAL1_BLK);
+    if (am_test(node, NF_BAL0_AUTHORS, node)) vote = nf(node, NF_BAL0_BLK);
+    else if (am_test(node, NF_BAL1_AUTHORS, node)) vote = nf(node, NF_BAL1_BLK);
     st(sfw(slot, S_PROP_VOTE), pb | (vote << 16));
     u32 htc = nf(node, NF_HTC_ROUND);
     u32 tcm = htc ? nf(node, NF_TC_MASK) : 0;
@@ -947,19 +1110,27 @@ struct Sim {
     st(sfw(slot, S_TO_ROUND), nf(node, NF_CUR_ROUND));
     st(sfw(slot, S_TC_MASK), tcm);
     st(sfw(slot, S_TO_MASK), tom);
-    for (u32 m = tcm; m;) { u32 a = ctz32(m); m &= m - 1; st(sfw(slot, S_FIXED_WORDS + a), nfm(node, NF_FIXED_WORDS + a)); }
-    for (u32 m = tom; m;) { u32 a = ctz32(m); m &= m - 1; st(sfw(slot, S_FIXED_WORDS + P.n + a), nfm(node, NF_FIXED_WORDS + P.n + a)); }
+    u32 tc_sel = nf(node, NF_TC_SEL);
+    for (u32 m = tcm; m;) { u32 a = ctz32(m); m &= m - 1; st(sfw(slot, S_FIXED_WORDS + a), nfm(node, NF_FIXED_WORDS + tc_sel * P.n + a)); }
+    for (u32 m = tom; m;) { u32 a = ctz32(m); m &= m - 1; st(sfw(slot, S_FIXED_WORDS + P.n + a), nfm(node, NF_FIXED_WORDS + (1u - tc_sel) * P.n + a)); }
+    for (u32 k = 1; wide() && k < P.mw; k++) {  // authors >= 32 (n > 32 only): extension words of the two sets + their hcbr entries
+      u32 tk = htc ? am_word(node, NF_TC_MASK, k) : 0, ok = am_word(node, NF_TO_MASK, k);
+      st(sxw(slot, 0, k), tk);
+      st(sxw(slot, 1, k), ok);
+      for (u32 m = tk; m;) { u32 a = 32 * k + ctz32(m); m &= m - 1; st(sfw(slot, S_FIXED_WORDS + a), nfm(node, NF_FIXED_WORDS + tc_sel * P.n + a)); }
+      for (u32 m = ok; m;) { u32 a = 32 * k + ctz32(m); m &= m - 1; st(sfw(slot, S_FIXED_WORDS + P.n + a), nfm(node, NF_FIXED_WORDS + (1u - tc_sel) * P.n + a)); }
+    }
   }
 
   // ---- DataSyncNode::handle_notification (data_sync.rs:113-177); returns should_sync ----
   struct Snap { u32 w[S_FIXED_WORDS]; };
   LBFT_HD Snap load_snapshot(u32 slot) const {
     Snap sn;
-    const u32* sb = row0 + (size_t)(P.off_snap + slot * P.snap_words) * LBFT_ROW_STRIDE(P);
+    u32 sb = boff(P.off_snap + slot * P.snap_words);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (u32 f = 0; f < S_FIXED_WORDS; f++) sn.w[f] = sb[(size_t)f * LBFT_ROW_STRIDE(P)];
+    for (u32 f = 0; f < S_FIXED_WORDS; f++) sn.w[f] = ldf(sb, f);
     return sn;
   }
   LBFT_HD bool handle_notification(u32 node, u32 sender, u32 slot, const Snap& sn) {
@@ -988,14 +1159,10 @@ struct Sim {
       if (pb) insert_block(node, pb);
       LBFT_MARK(22);
       u32 tc_round = sn.w[S_TC_ROUND], to_round = sn.w[S_TO_ROUND];
-      for (u32 m = sn.w[S_TC_MASK]; m;) {
-        u32 a = ctz32(m); m &= m - 1;
-        insert_timeout(node, a, tc_round, ld(sfw(slot, S_FIXED_WORDS + a)));
-      }
-      for (u32 m = sn.w[S_TO_MASK]; m;) {
-        u32 a = ctz32(m); m &= m - 1;
-        insert_timeout(node, a, to_round, ld(sfw(slot, S_FIXED_WORDS + P.n + a)));
-      }
+      insert_timeouts(node, slot, S_FIXED_WORDS, sn.w[S_TC_MASK], tc_round);
+      for (u32 k = 1; wide() && k < P.mw; k++) insert_timeouts(node, slot, S_FIXED_WORDS, ld(sxw(slot, 0, k)), tc_round, 32 * k);
+      insert_timeouts(node, slot, S_FIXED_WORDS + P.n, sn.w[S_TO_MASK], to_round);
+      for (u32 k = 1; wide() && k < P.mw; k++) insert_timeouts(node, slot, S_FIXED_WORDS + P.n, ld(sxw(slot, 1, k)), to_round, 32 * k);
       LBFT_MARK(23);
       if (vote) insert_vote(node, sender, vote, blk_get(vote));
       LBFT_MARK(24);
@@ -1005,6 +1172,42 @@ struct Sim {
 
   // ---- SimulatedNode::update (simulator.rs:176-179) ----
   LBFT_HD Actions node_update(u32 node) { return update_node(node, (i64)clock - (i64)(i32)nf(node, NF_STARTUP)); }
+
+  // ---- receiver / sender lists of process_node_actions (simulator.rs:326-343,356-370) ----
+  // n <= 16: sixteen 4-bit entries in one 64-bit register (a dynamically indexed array would be a
+  // 32-way select chain per access); larger networks keep the list in a per-instance HBM row region.
+  u64 plist;
+  LBFT_HD u32 peer(u32 i) const {
+    if (packed()) return (u32)(plist >> (4 * i)) & 15u;
+    return ld(P.off_list + i);
+  }
+  LBFT_HD void peers_one(u32 a) {
+    if (packed()) plist = a; else st(P.off_list, a);
+  }
+  LBFT_HD u32 peers_all_but(u32 node) {  // all other nodes in index order
+    if (packed()) {
+      const u64 ident = 0xfedcba9876543210ULL;
+      u64 low = node ? (ident & ((1ULL << (4 * node)) - 1)) : 0;
+      u64 high = node < 15 ? ((ident >> (4 * (node + 1))) << (4 * node)) : 0;
+      plist = low | high;
+    } else {
+      u32 c = 0;
+      for (u32 i = 0; i < P.n; i++) if (i != node) st(P.off_list + c++, i);
+    }
+    return P.n - 1;
+  }
+  LBFT_HD void peers_shuffle(u32 cnt) {  // rand 0.8 SliceRandom::shuffle (no draws when cnt < 2)
+    for (u32 i = cnt; i-- > 1;) {
+      u32 j = rng.gen_range_u32(i + 1);
+      if (packed()) {
+        u64 x = ((plist >> (4 * i)) ^ (plist >> (4 * j))) & 15ULL;
+        plist ^= (x << (4 * i)) | (x << (4 * j));
+      } else {
+        u32 a = ld(P.off_list + i), b = ld(P.off_list + j);
+        st(P.off_list + i, b); st(P.off_list + j, a);
+      }
+    }
+  }
 
   // ---- Simulator::process_node_actions (simulator.rs:296-378) ----
   LBFT_HD void process_node_actions(u32 node, const Actions& act) {
@@ -1027,14 +1230,10 @@ struct Sim {
       push_event(t_new, 3, node, 0, 0);
     }
     LBFT_MARK(12);
-    u32 list[LBFT_MAX_NODES];
     u32 cnt = 0;
-    if (act.broadcast) { for (u32 i = 0; i < P.n; i++) if (i != node) list[cnt++] = i; }
-    else if (act.send_to >= 0 && (u32)act.send_to != node) list[cnt++] = (u32)act.send_to;
-    for (u32 i = cnt; i-- > 1;) {  // SliceRandom::shuffle
-      u32 j = rng.gen_range_u32(i + 1);
-      u32 t = list[i]; list[i] = list[j]; list[j] = t;
-    }
+    if (act.broadcast) cnt = peers_all_but(node);
+    else if (act.send_to >= 0 && (u32)act.send_to != node) { peers_one((u32)act.send_to); cnt = 1; }
+    peers_shuffle(cnt);  // SliceRandom::shuffle
     i32 slot = -1;
     u32 refs = 0;
     for (u32 i = 0; i < cnt; i++) {
@@ -1043,24 +1242,20 @@ struct Sim {
         slot = snap_alloc();
         if (slot < 0) slot = -2; else write_snapshot(node, (u32)slot);
       }
-      if (slot >= 0) { if (push_event(t, 0, list[i], node, (u32)slot)) refs++; }
+      if (slot >= 0) { if (push_event(t, 0, peer(i), node, (u32)slot)) refs++; }
       else stamp++;  // dropped event still consumes a creation stamp
     }
     if (slot >= 0) {
       if (refs) st(P.off_snap_ref + (u32)slot, refs);
-      else { st(P.off_snap_free + snap_free, (u32)slot); snap_free++; }
+      else snap_free_slot((u32)slot);
     }
     LBFT_MARK(13);
     if (act.query_all) {
-      cnt = 0;
-      for (u32 i = 0; i < P.n; i++) if (i != node) list[cnt++] = i;
-      for (u32 i = cnt; i-- > 1;) {
-        u32 j = rng.gen_range_u32(i + 1);
-        u32 t = list[i]; list[i] = list[j]; list[j] = t;
-      }
+      cnt = peers_all_but(node);
+      peers_shuffle(cnt);
       for (u32 i = 0; i < cnt; i++) {
         i64 t = (i64)clock + sample_delay();
-        push_event(t, 1, node, list[i], 0);
+        push_event(t, 1, node, peer(i), 0);
       }
     }
     LBFT_MARK(14);
@@ -1073,6 +1268,7 @@ struct Sim {
     ev0 = ev1 = ev2 = ev3 = 0;
     blk_cache_reset();
     snap_free = P.scap;
+    snap_mask = P.scap >= 64 ? ~0ULL : ((1ULL << P.scap) - 1);
     for (u32 s = 0; s < P.scap; s++) { st(P.off_snap_free + s, P.scap - 1 - s); st(P.off_snap_ref + s, 0); }
     rng.seed(seed);
     for (u32 node = 0; node < P.n; node++) {
@@ -1157,20 +1353,26 @@ struct Sim {
   }
 };
 
+typedef SimT<3> Sim;
+// The class lbft_k_run (and the host model) executes a batch with.
+inline int sim_class(const Params& p) { return p.n > 32 ? 2 : ((p.n <= 16 && !p.qheap) ? 0 : 1); }
+
 // Row layout for a batch; fills the offset fields of `p` and returns words per instance.
 inline u32 compute_layout(Params& p) {
   u32 w = I_WORDS;
-  p.off_node = w; p.node_words = NF_FIXED_WORDS + 2 * p.n; w += p.n * p.node_words;
+  p.mw = (p.n + 31) / 32;
+  p.off_node = w; p.node_words = NF_FIXED_WORDS + 2 * p.n + 4 * (p.mw - 1); w += p.n * p.node_words;
   p.off_qhi = w; w += p.qcap;
   p.off_qlo = w; w += p.qcap;
   p.off_qmeta = w; w += p.qcap;
-  p.snap_words = S_FIXED_WORDS + 2 * p.n;
+  p.snap_words = S_FIXED_WORDS + 2 * p.n + 2 * (p.mw - 1);
   p.off_snap = w; w += p.scap * p.snap_words;
   p.off_snap_ref = w; w += p.scap;
   p.off_snap_free = w; w += p.scap;
-  p.blk_words = B_WORDS;
+  p.blk_words = B_WORDS + 3 * (p.mw - 1);
   p.off_blk = w; w += p.bcap * p.blk_words;
   p.off_log = w; w += p.n * p.lcap;
+  p.off_list = w; w += p.n > 16 ? p.n : 0;
   p.total_words = w;
   return w;
 }

@@ -30,7 +30,7 @@ static_assert(LBFT_MAX_NODES == LBFT_MAX_NODES_SUPPORTED, "header mismatch");
 __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restrict__ state, const u64* __restrict__ seeds) {
   u32 i = blockIdx.x * p.lpw + threadIdx.x;
   if (threadIdx.x >= p.lpw || i >= p.m) return;
-  Sim s(p, state + inst_offset(p, i));
+  Sim s(p, state, i);
   s.init(seeds[i]);
 }
 
@@ -39,18 +39,22 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restr
 // Workgroup = 4 wavefronts; wavefront w of workgroup g advances instances
 // [(g * 4 + w) * lpw, +lpw).  LDS (dynamic, up to the CU's whole 160 KiB):
 //   [zig_x 257][zig_f 257][exp_tab 256]  u64   read-only tables of the delay sampler, one copy per workgroup
+//   [dur 128] i64, [leader 1024] u8            pacemaker duration / leader tables (first rounds)
 //   keys  [wave][slot][lane]              u64   event-queue keys (time, 3-kind, stamp), lane-private columns
 //   metas [wave][slot][lane]              u32   (node, sender, snapshot slot)
 // A lane only ever touches its own column (address = slot * lpw + lane), so data-dependent slot
 // indices are bank-conflict free and no workgroup barrier is needed after the table fill.
 #define LBFT_RUN_WAVES 4
 #define LBFT_RUN_BLOCK (64 * LBFT_RUN_WAVES)
-#define LBFT_TABLE_U64 (257 + 257 + 256)
+#define LBFT_LDS_LEADERS 1024  // rounds of the leader table kept in LDS (bytes)
+#define LBFT_LDS_DURS 128      // entries of the duration table kept in LDS (i64)
+#define LBFT_TABLE_U64 (257 + 257 + 256 + LBFT_LDS_DURS + LBFT_LDS_LEADERS / 8)
 
 static inline size_t run_lds_bytes(u32 ql, u32 lpw) {
   return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * ql * lpw * 12 + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8;  // + diagnostics
 }
 
+template <int CLS>
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) void lbft_k_run(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) {
   extern __shared__ u64 lds[];
   u64* t_zx = lds;
@@ -58,6 +62,12 @@ __global__ __launch_bounds__(LBFT_RUN_BLOCK) void lbft_k_run(Params p, u32* __re
   u64* t_et = lds + 514;
   for (u32 t = threadIdx.x; t < 257; t += LBFT_RUN_BLOCK) { t_zx[t] = p.zig_x[t]; t_zf[t] = p.zig_f[t]; }
   for (u32 t = threadIdx.x; t < 256; t += LBFT_RUN_BLOCK) t_et[t] = p.exp_tab[t];
+  i64* t_dur = reinterpret_cast<i64*>(lds + 770);
+  u8* t_leader = reinterpret_cast<u8*>(lds + 770 + LBFT_LDS_DURS);
+  u32 n_dur = p.dur_len < LBFT_LDS_DURS ? p.dur_len : LBFT_LDS_DURS;
+  u32 n_leader = p.leader_len < LBFT_LDS_LEADERS ? p.leader_len : LBFT_LDS_LEADERS;
+  for (u32 t = threadIdx.x; t < n_dur; t += LBFT_RUN_BLOCK) t_dur[t] = p.dur_tab[t];
+  for (u32 t = threadIdx.x; t < n_leader; t += LBFT_RUN_BLOCK) t_leader[t] = p.leader_tab[t];
   __syncthreads();
   u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   u64* keys = lds + LBFT_TABLE_U64 + (size_t)wave * p.ql * p.lpw + lane;
@@ -66,11 +76,16 @@ __global__ __launch_bounds__(LBFT_RUN_BLOCK) void lbft_k_run(Params p, u32* __re
   u32 i = (blockIdx.x * LBFT_RUN_WAVES + wave) * p.lpw + lane;
   bool active = lane < p.lpw && i < p.m;
   bool done = true;
+  // lpw divides 64, so a wavefront's instances share one tile: its base is wavefront-uniform (SGPRs) and
+  // every row access is saddr + 32-bit voffset
+  u32 tile_idx = __builtin_amdgcn_readfirstlane(((blockIdx.x * LBFT_RUN_WAVES + wave) * p.lpw) >> 6);
+  char* tile = reinterpret_cast<char*>(state) + (size_t)tile_idx * p.total_words * LBFT_ROW_BYTES;
   if (active) {
-    Sim s(p, state + inst_offset(p, i));
+    SimT<CLS> s(p, tile, (i & 63u) * 4u, 0);
     if (s.ld(I_DONE) == 0) {
       s.attach_queue(keys, metas, p.lpw, p.ql);
       s.attach_tables(t_zx, t_zf, t_et);
+      s.attach_round_tables(t_leader, n_leader, t_dur, n_dur);
       s.load_scalars();
       s.queue_to_lds();
 #if defined(LBFT_PHASE_TIMERS)
@@ -117,7 +132,7 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_finalize(Params p, const u3
   u64 c[C_WORDS];
   for (int k = 0; k < C_WORDS; k++) c[k] = 0;
   if (i < p.m) {
-    Sim s(p, const_cast<u32*>(state) + inst_offset(p, i));
+    Sim s(p, const_cast<u32*>(state), i);
     u64 min_round = ~0ULL, min_commits = ~0ULL;
     for (u32 n = 0; n < p.n; n++) {
       u32 nc = s.nfm(n, NF_NCOMMITS);
@@ -168,7 +183,7 @@ __global__ void lbft_k_export_histories(Params p, const u32* __restrict__ state,
   u32 t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n_inst * p.n) return;
   u32 n = t / n_inst, i = first_inst + t % n_inst;
-  Sim s(p, const_cast<u32*>(state) + inst_offset(p, i));
+  Sim s(p, const_cast<u32*>(state), i);
   u32 nc = s.nfm(n, NF_NCOMMITS);
   lbft_commit* o = out + ((size_t)(i - first_inst) * p.n + n) * cap;
   for (u32 k = 0; k < nc && k < cap; k++) {
@@ -188,7 +203,7 @@ __global__ void lbft_k_fill_leaders(Params p, u8* __restrict__ out, u32 len) {
 __global__ void lbft_k_sample_delays(Params p, u64 seed, i64* __restrict__ out, u32 n) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   u32 dummy[I_WORDS];
-  Sim s(p, dummy);
+  Sim s(p, dummy, 0);
   s.rng.seed(seed);
   for (u32 k = 0; k < n; k++) out[k] = s.sample_delay();
 }
@@ -234,6 +249,8 @@ struct lbft_batch {
   u64 *d_zx = nullptr, *d_zf = nullptr, *d_et = nullptr;
   i64* d_dur = nullptr;
   u8* d_leaders = nullptr;
+  u32* d_weights = nullptr;
+  std::vector<u32> weights;
   u32* d_unfinished = nullptr;
   u64* d_states_out = nullptr;
   unsigned long long* d_counters = nullptr;
@@ -250,7 +267,7 @@ struct lbft_batch {
   size_t table_bytes = 0;
 };
 
-static int fill_params(const lbft_config* cfg, size_t m, Params& p) {
+static int fill_params(const lbft_config* cfg, size_t m, Params& p, std::vector<u32>& weights) {
   memset(&p, 0, sizeof(p));
   p.n = cfg->num_nodes;
   p.m = (u32)m;
@@ -265,13 +282,17 @@ static int fill_params(const lbft_config* cfg, size_t m, Params& p) {
   p.tci = cfg->target_commit_interval;
   p.lambda = cfg->lambda;
   p.total_votes = 0;
+  weights.assign(p.n, 1);
+  p.unit_weights = 1;
   for (u32 i = 0; i < p.n; i++) {
     u64 w = cfg->voting_rights ? cfg->voting_rights[i] : 1;
     if (w > 0x00ffffffu) return LBFT_ERR_INVALID;
-    p.weights[i] = (u32)w;
+    weights[i] = (u32)w;
     p.total_votes += (u32)w;
+    if (w != 1) p.unit_weights = 0;
   }
   if (p.total_votes == 0) return LBFT_ERR_INVALID;
+  p.mw = (p.n + 31) / 32;
   p.quorum = 2 * p.total_votes / 3 + 1;  // quorum_threshold (configuration.rs:52-56)
   return LBFT_OK;
 }
@@ -292,7 +313,7 @@ static void free_batch(lbft_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   hipFree(b->d_seeds); hipFree(b->d_state); hipFree(b->d_zx); hipFree(b->d_zf); hipFree(b->d_et); hipFree(b->d_dur);
-  hipFree(b->d_leaders); hipFree(b->d_prof); hipFree(b->d_unfinished); hipFree(b->d_states_out); hipFree(b->d_counters); hipFree(b->d_scratch);
+  hipFree(b->d_leaders); hipFree(b->d_weights); hipFree(b->d_prof); hipFree(b->d_unfinished); hipFree(b->d_states_out); hipFree(b->d_counters); hipFree(b->d_scratch);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   if (b->ev2) hipEventDestroy(b->ev2);
@@ -312,6 +333,9 @@ static int upload_tables(lbft_batch* b) {
   for (size_t k = 0; k < dur.size(); k++) dur[k] = f64_to_i64_sat((double)b->cfg.delta * std::pow((double)k, b->cfg.gamma));
   HIP_TRY(hipMalloc(&b->d_dur, dur.size() * sizeof(i64)));
   HIP_TRY(hipMemcpy(b->d_dur, dur.data(), dur.size() * sizeof(i64), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc(&b->d_weights, b->weights.size() * sizeof(u32)));
+  HIP_TRY(hipMemcpy(b->d_weights, b->weights.data(), b->weights.size() * sizeof(u32), hipMemcpyHostToDevice));
+  b->p.weights = b->d_weights;
   HIP_TRY(hipMalloc(&b->d_leaders, LBFT_LEADER_TABLE_LEN));
   b->p.dur_tab = b->d_dur; b->p.dur_len = LBFT_DUR_TABLE_LEN;
   b->p.leader_tab = b->d_leaders; b->p.leader_len = 0;  // table not valid while it is being filled
@@ -349,7 +373,7 @@ int lbft_batch_create(const lbft_config* cfg, const uint64_t* seeds, size_t n_in
   b->cfg.voting_rights = b->rights.empty() ? nullptr : b->rights.data();
   b->m = n_instances;
   b->device = device;
-  rc = fill_params(&b->cfg, n_instances, b->p);
+  rc = fill_params(&b->cfg, n_instances, b->p, b->weights);
   if (rc != LBFT_OK) { delete b; g_err = "bad voting rights"; return rc; }
 #define CREATE_TRY(expr)                                                   \
   do {                                                                     \
@@ -380,7 +404,7 @@ int lbft_batch_set_max_steps(lbft_batch* b, uint32_t max_steps) {
 }
 
 int lbft_batch_set_lanes_per_wavefront(lbft_batch* b, uint32_t lanes) {
-  if (!b || lanes > 64) return LBFT_ERR_INVALID;
+  if (!b || lanes > 64 || (lanes && 64 % lanes != 0)) return LBFT_ERR_INVALID;  // a wavefront's instances must share one tile
   b->lpw = lanes;
   return LBFT_OK;
 }
@@ -419,7 +443,9 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
   const lbft_config& c = b->cfg;
   u32 n = c.num_nodes;
   // Capacities (0 = auto).  The queue only ever holds events with time <= max_clock.
-  u32 qcap = c.queue_capacity ? c.queue_capacity : (16 * n * n < 128 ? 128 : 16 * n * n);
+  // (large networks: ~n^2 messages in flight per round; the heap keeps push/pop logarithmic)
+  u32 qauto = n <= 16 ? 16 * n * n : 8 * n * n;
+  u32 qcap = c.queue_capacity ? c.queue_capacity : (qauto < 128 ? 128 : qauto);
   u32 scap = c.snapshot_capacity ? c.snapshot_capacity : (8 * n < 32 ? 32 : 8 * n);
   // one block per round; a 1- or 2-node network can finish a round per time unit
   u64 bauto = n <= 2 ? (u64)max_clock + 64 : (u64)max_clock / 10 + 64;
@@ -442,7 +468,7 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
   u32 lpw = b->lpw;
   if (lpw == 0) {
     u64 want = (b->m + 1023) / 1024;  // 256 CUs x 4 SIMDs
-    lpw = want < 16 ? 16 : (want > 64 ? 64 : (u32)((want + 15) / 16 * 16));
+    lpw = want <= 16 ? 16 : (want <= 32 ? 32 : 64);
   }
   p.lpw = lpw;
   // LDS queue slots per instance: what one CU's LDS affords when it hosts 64/lpw workgroups
@@ -454,8 +480,14 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
   if (ql > qcap) ql = qcap;
   if (run_lds_bytes(ql, lpw) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
   p.ql = ql;
+  // networks above 4 nodes keep hundreds to tens of thousands of pending events: binary heap (its top levels
+  // are the LDS-resident slots) instead of the linear scan
+  p.qheap = (qcap > 256 || n > 32) ? 1u : 0u;
   b->lds_bytes = run_lds_bytes(ql, lpw);
-  HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lbft_k_run), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+  int cls = sim_class(p);
+  const void* run_fn = cls == 0 ? reinterpret_cast<const void*>(lbft_k_run<0>)
+                     : cls == 1 ? reinterpret_cast<const void*>(lbft_k_run<1>) : reinterpret_cast<const void*>(lbft_k_run<2>);
+  HIP_TRY(hipFuncSetAttribute(run_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
   p.prof = b->d_prof;
   HIP_TRY(hipMemsetAsync(b->d_prof, 0, LBFT_NPHASES * sizeof(unsigned long long), b->stream));
   u32 grid_full = (u32)((b->m + LBFT_BLOCK - 1) / LBFT_BLOCK);
@@ -468,7 +500,9 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
   u64 launches = 0;
   for (;;) {
     HIP_TRY(hipMemsetAsync(b->d_unfinished, 0, sizeof(u32), b->stream));
-    lbft_k_run<<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+    if (cls == 0) lbft_k_run<0><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+    else if (cls == 1) lbft_k_run<1><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+    else lbft_k_run<2><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
     HIP_TRY(hipGetLastError());
     launches++;
     if (p.max_steps == 0) break;  // whole simulation in one launch

@@ -22,6 +22,8 @@ extern "C" {
 typedef struct lbft_hostmodel_caps {
   uint32_t qcap, scap, bcap, lcap;
   uint32_t ql;  // queue slots held in the emulated LDS front (0 = HBM rows only)
+  uint32_t qheap;  // 1 = binary-heap event queue (the device's large-network mode)
+  uint32_t force_generic;  // 1 = run the step as the run-time-generic class SimT<3> instead of the specialised one
 } lbft_hostmodel_caps;
 
 // Same outputs as lbft_oracle_run_batch, plus per-instance fault words and max queue/snapshot use.
@@ -39,6 +41,7 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   p.qcap = caps->qcap; p.scap = caps->scap; p.bcap = caps->bcap; p.lcap = caps->lcap;
   p.max_clock = (i32)max_clock;
   p.ql = caps->ql;
+  p.qheap = caps->qheap;
   p.delay_model = cfg->delay_model;
   p.mu = std::log(cfg->mean / std::sqrt(1.0 + cfg->variance / (cfg->mean * cfg->mean)));
   p.sigma = std::sqrt(std::log(1.0 + cfg->variance / (cfg->mean * cfg->mean)));
@@ -48,8 +51,12 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   p.tci = cfg->target_commit_interval;
   p.lambda = cfg->lambda;
   p.total_votes = 0;
-  for (u32 i = 0; i < p.n; i++) { p.weights[i] = cfg->voting_rights ? (u32)cfg->voting_rights[i] : 1; p.total_votes += p.weights[i]; }
+  std::vector<u32> weights(p.n);
+  for (u32 i = 0; i < p.n; i++) { weights[i] = cfg->voting_rights ? (u32)cfg->voting_rights[i] : 1; p.total_votes += weights[i]; }
+  p.weights = weights.data();
   p.quorum = 2 * p.total_votes / 3 + 1;
+  p.unit_weights = 1;
+  for (u32 i = 0; i < p.n; i++) if (p.weights[i] != 1) p.unit_weights = 0;
   std::vector<i64> dur(4096);
   for (size_t k = 0; k < dur.size(); k++) dur[k] = f64_to_i64_sat((double)cfg->delta * std::pow((double)k, cfg->gamma));
   std::vector<u8> leaders(4096);
@@ -61,19 +68,27 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   std::vector<u32> state(state_words(p), 0);
 
   if (threads == 0) threads = 1;
+  if (p.n > 32) p.qheap = 1;  // as the device host code does
+  // the step runs as the size class the device would pick (SimT<0..2>); init and read-back use the generic class
+  auto run_one = [&](auto& s, size_t i) {
+    std::vector<u64> keys(p.ql ? p.ql : 1);
+    std::vector<u32> metas(p.ql ? p.ql : 1);
+    s.attach_queue(keys.data(), metas.data(), 1, p.ql);
+    s.load_scalars();
+    s.queue_to_lds();
+    bool done = s.run();
+    s.queue_from_lds();
+    s.store_scalars(done);
+  };
+  int cls = caps->force_generic ? 3 : sim_class(p);
   auto worker = [&](u32 tid) {
     for (size_t i = tid; i < n_instances; i += threads) {
-      Sim s(p, state.data() + inst_offset(p, (u32)i));
-      s.init(seeds[i]);
+      { Sim s0(p, state.data(), (u32)i); s0.init(seeds[i]); }
       // emulate the device's launch structure: the LDS front of the queue is a cache of the HBM rows
-      std::vector<u64> keys(p.ql ? p.ql : 1);
-      std::vector<u32> metas(p.ql ? p.ql : 1);
-      s.attach_queue(keys.data(), metas.data(), 1, p.ql);
-      s.load_scalars();
-      s.queue_to_lds();
-      bool done = s.run();
-      s.queue_from_lds();
-      s.store_scalars(done);
+      if (cls == 0) { SimT<0> s(p, state.data(), (u32)i); run_one(s, i); }
+      else if (cls == 1) { SimT<1> s(p, state.data(), (u32)i); run_one(s, i); }
+      else if (cls == 2) { SimT<2> s(p, state.data(), (u32)i); run_one(s, i); }
+      else { Sim s(p, state.data(), (u32)i); run_one(s, i); }
     }
   };
   std::vector<std::thread> ts;
@@ -84,7 +99,7 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   if (counters) memset(counters, 0, sizeof(*counters));
   int rc = 0;
   for (size_t i = 0; i < n_instances; i++) {
-    Sim s(p, state.data() + inst_offset(p, (u32)i));
+    Sim s(p, state.data(), (u32)i);
     s.load_scalars();
     if (faults) faults[i] = s.fault;
     if (s.fault) rc = 1;

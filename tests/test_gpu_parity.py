@@ -69,6 +69,13 @@ CASES = {
     "n1": (dict(num_nodes=1), 5, 300),
     "n2_ragged_batch": (dict(num_nodes=2), 67, 1000),
     "n16": (dict(num_nodes=16), 16, 400),
+    # > 16 nodes: receiver lists in HBM rows; > 32: multi-word node/author sets; heap event queue (configs 4 / 5 shapes)
+    "n20": (dict(num_nodes=20), 8, 300),
+    "n33": (dict(num_nodes=33), 4, 300),
+    "n64_long_tail": (dict(num_nodes=64, mean=10.0, variance=400.0), 4, 300),
+    "n100_weighted": (dict(num_nodes=100, voting_rights=[1 + (i % 4) for i in range(100)]), 2, 200),
+    "n36_timeouts": (dict(num_nodes=36, mean=10.0, variance=900.0, delta=5), 4, 400),
+    "n8_timeouts": (dict(num_nodes=8, mean=10.0, variance=400.0), 64, 1500),
     "epoch_change_cpe50": (dict(num_nodes=4, commands_per_epoch=50), 128, 3000),
     "weighted": (dict(num_nodes=5, voting_rights=[5, 1, 1, 2, 3]), 128, 1000),
     "long_tail": (dict(num_nodes=4, mean=10.0, variance=400.0), 256, 2000),

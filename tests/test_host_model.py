@@ -27,14 +27,15 @@ CASES = {
 
 # ql = event-queue slots held in the (emulated) LDS front: 0 = HBM rows only, 5 = almost everything
 # spills across the LDS/HBM boundary, 48 = the device default (the front covers the high-water mark at n <= 4)
-@pytest.mark.parametrize("ql", [0, 5, 48])
+# scap = notification snapshot slots: <= 64 uses the register-resident free mask, larger the HBM free stack
+@pytest.mark.parametrize("ql,scap", [(0, 512), (5, 64), (48, 512)])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_host_model_equals_oracle(oracle, name, ql):
+def test_host_model_equals_oracle(oracle, name, ql, scap):
     kw, m, max_clock = CASES[name]
     cfg = oracle.make_config(math_mode=1, **kw)
     seeds = np.arange(1000, 1000 + m, dtype=np.uint64) * 7919
     a = oracle.run_batch(cfg, seeds, max_clock, threads=8, history_cap=512)
-    b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=8, history_cap=512, qcap=4096, scap=512, bcap=1024,
+    b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=8, history_cap=512, qcap=4096, scap=scap, bcap=1024,
                                    lcap=1024, ql=ql)
     assert not b["faults"].any()
     for key in ("commit_counts", "active_rounds", "last_states", "histories"):
@@ -43,6 +44,52 @@ def test_host_model_equals_oracle(oracle, name, ql):
     for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
         assert ca[key] == cb[key], key
     assert ca["response_inserts"] == 0  # Q1: the premise of payload-free requests/responses
+
+
+# Networks above 32 nodes: multi-word author / node sets (extension rows), receiver lists in HBM rows and the
+# binary-heap event queue (BASELINE.json configs 4 and 5 are 64 and 100 nodes).
+LARGE = {
+    "n20_list_rows": (dict(num_nodes=20), 4, 300, 0),
+    "n33_two_mask_words": (dict(num_nodes=33), 2, 300, 1),
+    "n40_heap": (dict(num_nodes=40), 2, 250, 1),
+    "n64_long_tail": (dict(num_nodes=64, mean=10.0, variance=400.0), 1, 300, 1),
+    "n100_weighted": (dict(num_nodes=100, voting_rights=[1 + (i % 4) for i in range(100)]), 1, 200, 1),
+    "n4_heap_mode": (dict(num_nodes=4), 64, 1000, 1),
+    "n8_heap_mode_timeouts": (dict(num_nodes=8, mean=10.0, variance=400.0), 16, 1500, 1),
+    "n36_timeouts": (dict(num_nodes=36, mean=10.0, variance=900.0, delta=5), 2, 400, 1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(LARGE))
+def test_host_model_large_networks(oracle, name):
+    kw, m, max_clock, qheap = LARGE[name]
+    cfg = oracle.make_config(math_mode=1, **kw)
+    n = kw["num_nodes"]
+    seeds = np.arange(7, 7 + m, dtype=np.uint64) * 31337
+    a = oracle.run_batch(cfg, seeds, max_clock, threads=8, history_cap=128)
+    b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=8, history_cap=128, qcap=max(4096, 8 * n * n), scap=16 * n,
+                                   bcap=512, lcap=512, ql=7 if n in (8, 40) else 0, qheap=qheap)
+    assert not b["faults"].any()
+    for key in ("commit_counts", "active_rounds", "last_states", "histories"):
+        assert (a[key] == b[key]).all(), key
+    ca, cb = a["counters"], b["counters"]
+    for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
+        assert ca[key] == cb[key], key
+    assert ca["response_inserts"] == 0
+
+
+def test_generic_class_equals_specialised(oracle):
+    """SimT<3> (everything decided at run time: what the init / read-back kernels instantiate) == SimT<0..2>."""
+    for kw, m, max_clock, qheap in (LARGE["n4_heap_mode"], LARGE["n33_two_mask_words"], (dict(num_nodes=4), 64, 1000, 0)):
+        cfg = oracle.make_config(math_mode=1, **kw)
+        seeds = np.arange(1, m + 1, dtype=np.uint64)
+        n = kw["num_nodes"]
+        caps = dict(qcap=max(4096, 8 * n * n), scap=16 * n, bcap=512, lcap=512, ql=9, qheap=qheap, history_cap=64)
+        a = oracle.hostmodel_run_batch(cfg, seeds, max_clock, force_generic=0, **caps)
+        b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, force_generic=1, **caps)
+        for key in ("commit_counts", "active_rounds", "last_states", "histories"):
+            assert (a[key] == b[key]).all(), key
+        assert a["counters"] == b["counters"]
 
 
 def test_capacity_overflow_raises_fault_not_garbage(oracle):

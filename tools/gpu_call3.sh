@@ -11,5 +11,5 @@ import json
 for line in open("gpurun_out/sweep.jsonl"):
     d = json.loads(line)
     print({k: d.get(k) for k in ("lib", "lpw", "ql", "kernel_ms", "events_per_s", "faulted", "error", "cycles_per_wave_step")})
-    if "phases" in d: print(d["phases"])
+    if "phases" in d: print(d["phases"]); print(d.get("counts"))
 PY

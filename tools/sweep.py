@@ -13,6 +13,7 @@ PHASES = {0: "pop", 1: "node_load", 2: "timer_pre", 3: "snap_release", 4: "reque
           7: "timeout_propose", 8: "vote", 9: "new_qc", 10: "commits_tracker", 11: "sync_push", 12: "pna_timer",
           13: "pna_notify", 14: "pna_query", 15: "end_node", 17: "store_drain", 20: "hn_hcc", 21: "hn_hqc", 22: "hn_block",
           23: "hn_timeouts", 24: "hn_vote"}
+COUNTS = {25: "blk_miss_sites_per_step", 26: "blk_get_sites_per_step"}
 
 
 def one(args):
@@ -35,8 +36,9 @@ def one(args):
            "events_per_s": sum(c["events"]) / (min(ms[1:]) * 1e-3), "faulted": c["faulted_instances"], "max_queue": c["max_queue"]}
     try:
         pc = sim.phase_cycles()
-        tot = float(sum(int(pc[k]) for k in range(30))) or 1.0
-        out["phases"] = {PHASES.get(k, str(k)): round(int(pc[k]) / tot, 4) for k in range(30) if int(pc[k])}
+        tot = float(sum(int(pc[k]) for k in range(30) if k not in COUNTS)) or 1.0
+        out["phases"] = {PHASES.get(k, str(k)): round(int(pc[k]) / tot, 4) for k in range(30) if int(pc[k]) and k not in COUNTS}
+        out["counts"] = {v: round(int(pc[k]) / max(int(pc[30]), 1), 3) for k, v in COUNTS.items()}
         out["cycles_per_wave_step"] = int(pc[31]) / max(int(pc[30]), 1)
         out["wave_steps"] = int(pc[30])
     except Exception:
