@@ -57,7 +57,7 @@ def test_argument_validation_needs_no_gpu(hiplib):
     cfg.quirks = 1
     assert L.lbft_batch_create(ctypes.byref(cfg), seeds.ctypes.data, 4, 0, ctypes.byref(h)) == hiplib.LBFT_ERR_UNSUPPORTED
     cfg.quirks = 0
-    cfg.num_nodes = 33
+    cfg.num_nodes = 129  # LBFT_MAX_NODES_SUPPORTED is 128
     assert L.lbft_batch_create(ctypes.byref(cfg), seeds.ctypes.data, 4, 0, ctypes.byref(h)) == hiplib.LBFT_ERR_UNSUPPORTED
     assert L.lbft_batch_run_until(None, 10) == hiplib.LBFT_ERR_INVALID
 
