@@ -35,16 +35,29 @@ def parse():
     return ap.parse_args()
 
 
-def algorithmic_bytes_per_event(nodes, counters):
-    """SURVEY.md 8(d) with this build's struct sizes (DESIGN.md "Algorithmic bytes"):
-    2*S_node + S_evt*(1 + p) + S_notif*(w + r)."""
+def algorithmic_bytes_per_event(layout, counters):
+    """SURVEY.md 8(d) with this build's struct sizes (DESIGN.md "Roofline"), taken from the library itself
+    (lbft_batch_layout): 2*S_node + S_evt*(1 + p) + S_notif*(w + r)."""
     ev = sum(counters["events"])
-    s_node = (36 + 2 * nodes) * 4   # NF_FIXED_WORDS + tc_hcbr[n] + to_hcbr[n], 4-byte rows
-    s_evt = 12                      # key hi, key lo, meta
-    s_notif = (7 + 2 * nodes) * 4   # S_FIXED_WORDS + hcbr arrays
+    s_node, s_evt, s_notif = layout["node_bytes"], layout["event_bytes"], layout["snapshot_bytes"]
     p = counters["events_scheduled"] / max(ev, 1)
     r = counters["events"][0] / max(ev, 1)
     return 2 * s_node + s_evt * (1 + p) + s_notif * (r + r)
+
+
+def measured_traffic_gb():
+    """HBM bytes per launch of lbft_k_run from the PMC passes (FETCH_SIZE / WRITE_SIZE, collected in their own
+    rocprofv3 runs of this same command by tools/gpu_profile.sh and committed under profiles/).  FETCH_SIZE is
+    doubled as MI355X_MICROARCH.md prescribes for gfx950 (it tallies 128-byte requests as 64 bytes); the value is
+    therefore an upper bound for narrow accesses.  None when no profile of the current kernel is committed."""
+    path = os.path.join(ROOT, "profiles", "current", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return {"fetch_kb_raw": t["FETCH_SIZE"], "write_kb_raw": t["WRITE_SIZE"],
+                "gb_corrected": (2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024 / 1e9, "profile": t.get("profile")}
+    except Exception:
+        return None
 
 
 def cpu_baseline(args, nodes, max_clock):
@@ -124,7 +137,9 @@ def main():
     if rank == 0:
         per_step = elapsed / args.steps
         k_ms = float(np.mean(kernel_ms))
-        bpe = algorithmic_bytes_per_event(args.nodes, c)
+        layout = sim.layout()
+        bpe = algorithmic_bytes_per_event(layout, c)
+        traffic = measured_traffic_gb() if (args.instances, args.nodes, args.max_clock) == (65536, 4, 1000) else None
         local_events = sum(c["events"])
         achieved = local_events * bpe / (k_ms * 1e-3) / 1e9
         out = {
@@ -138,8 +153,10 @@ def main():
             "committed_blocks_per_s": commits / per_step, "events_per_s": events / per_step,
             "faulted_instances": faulted,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "lbft_k_run", "kernel_ms": k_ms, "algorithmic_bytes_per_event": bpe,
-                         "events_per_launch": local_events},
+                         "traffic": traffic["gb_corrected"] if traffic else None, "traffic_unit": "GB per launch",
+                         "traffic_detail": traffic, "kernel": "lbft_k_run", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_event": bpe, "algorithmic_gb_per_launch": local_events * bpe / 1e9,
+                         "events_per_launch": local_events, "layout": layout},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.nodes, args.max_clock)

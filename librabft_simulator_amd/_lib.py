@@ -75,7 +75,7 @@ ABI_SYMBOLS = [
     "lbft_batch_last_committed_states", "lbft_batch_startup_times", "lbft_batch_epochs", "lbft_batch_counters",
     "lbft_batch_faults", "lbft_batch_destroy", "lbft_batch_stream", "lbft_batch_last_run_ms",
     "lbft_batch_device_bytes", "lbft_batch_set_max_steps", "lbft_batch_set_lanes_per_wavefront",
-    "lbft_batch_set_lds_queue_slots", "lbft_batch_phase_cycles", "lbft_device_leaders", "lbft_device_sample_delays",
+    "lbft_batch_set_lds_queue_slots", "lbft_batch_phase_cycles", "lbft_batch_layout", "lbft_device_leaders", "lbft_device_sample_delays",
     "lbft_device_exp_log", "lbft_last_error", "lbft_build_info",
 ]
 
@@ -129,6 +129,8 @@ def lib():
     L.lbft_batch_set_lanes_per_wavefront.restype = C.c_int
     L.lbft_batch_set_lds_queue_slots.argtypes = [vp, C.c_int32]
     L.lbft_batch_set_lds_queue_slots.restype = C.c_int
+    L.lbft_batch_layout.argtypes = [vp, vp]
+    L.lbft_batch_layout.restype = C.c_int
     L.lbft_batch_phase_cycles.argtypes = [vp, vp]
     L.lbft_batch_phase_cycles.restype = C.c_int
     L.lbft_device_leaders.argtypes = [C.c_int, vp, C.c_uint32, vp, C.c_uint32]

@@ -428,6 +428,21 @@ int lbft_batch_phase_cycles(const lbft_batch* b, uint64_t* out) {
 #endif
 }
 
+int lbft_batch_layout(const lbft_batch* b, uint32_t* out) {
+  if (!b || !out) return LBFT_ERR_INVALID;
+  if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
+  const Params& p = b->p;
+  out[0] = p.node_words * 4;  // bytes of one node's rows (fixed rows + hcbr buffers + extension words)
+  out[1] = 12;                // bytes of one queued event (64-bit key + meta word)
+  out[2] = p.snap_words * 4;  // bytes of one notification snapshot
+  out[3] = p.blk_words * 4;   // bytes of one block record
+  out[4] = p.total_words * 4; // HBM bytes per instance
+  out[5] = p.ql;              // event-queue slots per instance resident in LDS
+  out[6] = p.lpw;             // lanes per wavefront carrying an instance
+  out[7] = (uint32_t)sim_class(p) | (p.qheap << 8);
+  return LBFT_OK;
+}
+
 int lbft_batch_reset(lbft_batch* b) {
   if (!b) return LBFT_ERR_INVALID;
   b->ran = false;

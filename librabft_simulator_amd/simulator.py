@@ -240,6 +240,14 @@ class BatchSimulator:
         check(_lib.lib().lbft_batch_phase_cycles(self._h, out.ctypes.data))
         return out
 
+    def layout(self):
+        """Struct sizes behind the roofline arithmetic (see include/lbft.h lbft_batch_layout)."""
+        out = np.zeros(8, dtype=np.uint32)
+        check(_lib.lib().lbft_batch_layout(self._h, out.ctypes.data))
+        keys = ("node_bytes", "event_bytes", "snapshot_bytes", "block_bytes", "instance_bytes", "lds_queue_slots",
+                "lanes_per_wavefront", "kernel_class")
+        return dict(zip(keys, (int(v) for v in out)))
+
     def device_bytes(self):
         return int(_lib.lib().lbft_batch_device_bytes(self._h))
 
