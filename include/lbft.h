@@ -142,6 +142,39 @@ int lbft_batch_phase_cycles(const lbft_batch* b, uint64_t* out);
 /* Tuning: how many of a wavefront's 64 lanes carry an instance (0 = auto from the batch size). Results do not depend on it. */
 int lbft_batch_set_lanes_per_wavefront(lbft_batch* b, uint32_t lanes);
 
+/* ---- Node-level interface: the reference's trait surface for ONE node of ONE instance, without the event loop
+ * (bft-lib/src/interfaces.rs:12-86), so that record-store / pacemaker scenarios can be replayed step by step
+ * (librabft-v2/src/unit_tests/record_store_tests.rs) and a host-side driver other than the batch simulator (the
+ * role bft-driver/src/core.rs:125-198 plays for the real network) can own time and message delivery.  Each call
+ * launches a one-lane kernel on the batch's stream and blocks.  Usage: lbft_batch_create, lbft_batch_manual_begin,
+ * then any sequence of lbft_node_* calls; lbft_batch_manual_finalize makes the batch-level read-back calls
+ * (commit counts, histories, States) available. ---- */
+typedef struct lbft_actions { /* NodeUpdateActions (interfaces.rs:12-21) */
+  int64_t next_scheduled_update; /* NodeTime; INT64_MAX = never */
+  uint64_t should_send[2];       /* bit set of authors */
+  uint32_t should_broadcast, should_query_all;
+} lbft_actions;
+typedef struct lbft_node_view { /* RecordStoreState / PacemakerState / NodeState scalars (record_store.rs:93-119, pacemaker.rs:60-77, node.rs:28-45) */
+  uint64_t epoch_id, current_round, highest_quorum_certificate_round, highest_timeout_certificate_round,
+      highest_committed_round, active_round, latest_voted_round, locked_round, commit_count;
+  uint32_t active_leader; /* UINT32_MAX = None */
+  uint32_t election;      /* 0 ongoing, 1 won, 2 closed (record_store.rs:125-134) */
+  uint32_t num_current_timeouts, num_current_votes, has_proposed_block, has_timeout_certificate;
+} lbft_node_view;
+/* NodeState::make_initial_state for every node of every instance (node.rs:87-114), no events are processed. */
+int lbft_batch_manual_begin(lbft_batch* b, int64_t max_clock);
+int lbft_batch_manual_finalize(lbft_batch* b);
+/* ConsensusNode::update_node(&mut self, &mut Context, clock: NodeTime) -> NodeUpdateActions (interfaces.rs:37-49, node.rs:240-304) */
+int lbft_node_update(lbft_batch* b, size_t inst, uint32_t node, int64_t node_time, lbft_actions* out);
+/* DataSyncNode::create_notification (interfaces.rs:62-64, data_sync.rs:82-111): *handle names the notification
+ * until lbft_node_release_notification; it may be delivered to any number of receivers. */
+int lbft_node_create_notification(lbft_batch* b, size_t inst, uint32_t node, uint32_t* handle);
+/* DataSyncNode::handle_notification (interfaces.rs:72-76, data_sync.rs:113-177); *should_sync != 0 when the
+ * reference would return Some(Request). */
+int lbft_node_handle_notification(lbft_batch* b, size_t inst, uint32_t receiver, uint32_t sender, uint32_t handle, uint32_t* should_sync);
+int lbft_node_release_notification(lbft_batch* b, size_t inst, uint32_t handle);
+int lbft_node_view_get(lbft_batch* b, size_t inst, uint32_t node, lbft_node_view* out);
+
 /* Stand-alone device checks of the third-party arithmetic (tests): each runs a tiny kernel.
  *   leaders: out[r] = PacemakerState::leader(round r) (pacemaker.rs:100-109) for r < n_rounds
  *   delays:  n samples of RandomDelay (simulator.rs:110-118) from Xoshiro256**(seed)

@@ -66,6 +66,29 @@ class LbftCounters(C.Structure):
         return d
 
 
+class LbftActions(C.Structure):
+    """NodeUpdateActions (bft-lib/src/interfaces.rs:12-21)."""
+    _fields_ = [("next_scheduled_update", C.c_int64), ("should_send", C.c_uint64 * 2), ("should_broadcast", C.c_uint32),
+                ("should_query_all", C.c_uint32)]
+
+    def as_dict(self):
+        bits = int(self.should_send[0]) | (int(self.should_send[1]) << 64)
+        return {"next_scheduled_update": int(self.next_scheduled_update),
+                "should_send": [a for a in range(128) if (bits >> a) & 1],
+                "should_broadcast": bool(self.should_broadcast), "should_query_all": bool(self.should_query_all)}
+
+
+class LbftNodeView(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("epoch_id", "current_round", "highest_quorum_certificate_round",
+                                           "highest_timeout_certificate_round", "highest_committed_round", "active_round",
+                                           "latest_voted_round", "locked_round", "commit_count")] + \
+               [(n, C.c_uint32) for n in ("active_leader", "election", "num_current_timeouts", "num_current_votes",
+                                           "has_proposed_block", "has_timeout_certificate")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
 COMMIT_DTYPE = np.dtype([("proposer", "<u8"), ("index", "<u8"), ("time", "<i8")])
 
 # every symbol include/lbft.h declares (tests check that the library exports all of them)
@@ -75,7 +98,9 @@ ABI_SYMBOLS = [
     "lbft_batch_last_committed_states", "lbft_batch_startup_times", "lbft_batch_epochs", "lbft_batch_counters",
     "lbft_batch_faults", "lbft_batch_destroy", "lbft_batch_stream", "lbft_batch_last_run_ms",
     "lbft_batch_device_bytes", "lbft_batch_set_max_steps", "lbft_batch_set_lanes_per_wavefront",
-    "lbft_batch_set_lds_queue_slots", "lbft_batch_phase_cycles", "lbft_batch_layout", "lbft_device_leaders", "lbft_device_sample_delays",
+    "lbft_batch_set_lds_queue_slots", "lbft_batch_phase_cycles", "lbft_batch_layout",
+    "lbft_batch_manual_begin", "lbft_batch_manual_finalize", "lbft_node_update", "lbft_node_create_notification",
+    "lbft_node_handle_notification", "lbft_node_release_notification", "lbft_node_view_get", "lbft_device_leaders", "lbft_device_sample_delays",
     "lbft_device_exp_log", "lbft_last_error", "lbft_build_info",
 ]
 
@@ -129,6 +154,20 @@ def lib():
     L.lbft_batch_set_lanes_per_wavefront.restype = C.c_int
     L.lbft_batch_set_lds_queue_slots.argtypes = [vp, C.c_int32]
     L.lbft_batch_set_lds_queue_slots.restype = C.c_int
+    L.lbft_batch_manual_begin.argtypes = [vp, C.c_int64]
+    L.lbft_batch_manual_begin.restype = C.c_int
+    L.lbft_batch_manual_finalize.argtypes = [vp]
+    L.lbft_batch_manual_finalize.restype = C.c_int
+    L.lbft_node_update.argtypes = [vp, C.c_size_t, C.c_uint32, C.c_int64, C.POINTER(LbftActions)]
+    L.lbft_node_update.restype = C.c_int
+    L.lbft_node_create_notification.argtypes = [vp, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.lbft_node_create_notification.restype = C.c_int
+    L.lbft_node_handle_notification.argtypes = [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.lbft_node_handle_notification.restype = C.c_int
+    L.lbft_node_release_notification.argtypes = [vp, C.c_size_t, C.c_uint32]
+    L.lbft_node_release_notification.restype = C.c_int
+    L.lbft_node_view_get.argtypes = [vp, C.c_size_t, C.c_uint32, C.POINTER(LbftNodeView)]
+    L.lbft_node_view_get.restype = C.c_int
     L.lbft_batch_layout.argtypes = [vp, vp]
     L.lbft_batch_layout.restype = C.c_int
     L.lbft_batch_phase_cycles.argtypes = [vp, vp]

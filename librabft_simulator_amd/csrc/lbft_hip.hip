@@ -196,6 +196,55 @@ __global__ void lbft_k_export_histories(Params p, const u32* __restrict__ state,
   }
 }
 
+// Node-level interface (include/lbft.h lbft_node_*): one lane applies one trait call to one node.
+enum NodeOp : u32 { OP_UPDATE = 0, OP_CREATE_NOTIFICATION, OP_HANDLE_NOTIFICATION, OP_RELEASE_NOTIFICATION, OP_VIEW };
+__global__ void lbft_k_node_op(Params p, u32* __restrict__ state, u32 op, u32 inst, u32 node, u32 arg0, u32 arg1, i64 node_time,
+                               unsigned long long* __restrict__ out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Sim s(p, state, inst);
+  s.load_scalars();
+  if (op == OP_UPDATE) {
+    s.begin_node(node);
+    Actions a = s.update_node(node, node_time);
+    s.end_node(node);
+    out[0] = (unsigned long long)a.next;
+    out[1] = out[2] = 0;
+    if (a.send_to >= 0) out[1 + (a.send_to >> 6)] = 1ULL << (a.send_to & 63);
+    out[3] = a.broadcast ? 1 : 0;
+    out[4] = a.query_all ? 1 : 0;
+  } else if (op == OP_CREATE_NOTIFICATION) {
+    s.begin_node(node);
+    i32 slot = s.snap_alloc();
+    if (slot >= 0) { s.write_snapshot(node, (u32)slot); s.st(p.off_snap_ref + (u32)slot, 1); }
+    out[0] = (unsigned long long)(long long)slot;
+  } else if (op == OP_HANDLE_NOTIFICATION) {
+    s.begin_node(node);
+    auto sn = s.load_snapshot(arg1);
+    bool sync = s.handle_notification(node, arg0, arg1, sn);
+    s.end_node(node);
+    out[0] = sync ? 1 : 0;
+  } else if (op == OP_RELEASE_NOTIFICATION) {
+    s.snap_release(arg1);
+  } else {  // OP_VIEW
+    s.begin_node(node);
+    out[0] = s.nf(node, NF_EPOCH); out[1] = s.nf(node, NF_CUR_ROUND); out[2] = s.nf(node, NF_HQC_ROUND);
+    out[3] = s.nf(node, NF_HTC_ROUND); out[4] = s.nf(node, NF_HC_ROUND); out[5] = s.nf(node, NF_PM_ROUND);
+    out[6] = s.nf(node, NF_LVR); out[7] = s.nf(node, NF_LOCKED); out[8] = s.nf(node, NF_NCOMMITS);
+    u32 leader = s.nf(node, NF_PM_LEADER);
+    out[9] = leader == LBFT_NO_LEADER ? 0xffffffffULL : leader;
+    out[10] = s.nf(node, NF_ELECTION) & 0xff;
+    u32 nt = 0, nv = 0;
+    for (u32 k = 0; k < p.mw; k++) {
+      nt += (u32)__popc(s.am_word(node, NF_TO_MASK, k));
+      nv += (u32)__popc(s.am_word(node, NF_BAL0_AUTHORS, k)) + (u32)__popc(s.am_word(node, NF_BAL1_AUTHORS, k));
+    }
+    out[11] = nt; out[12] = nv;
+    out[13] = s.nf(node, NF_PROPOSED_BLK) ? 1 : 0;
+    out[14] = s.nf(node, NF_HTC_ROUND) ? 1 : 0;
+  }
+  s.store_scalars(s.ld(I_DONE) != 0);
+}
+
 __global__ void lbft_k_fill_leaders(Params p, u8* __restrict__ out, u32 len) {
   u32 r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < len) out[r] = (u8)compute_leader(p.weights, p.n, p.total_votes, r);
@@ -257,6 +306,7 @@ struct lbft_batch {
   u32* d_scratch = nullptr;  // m * n words for gathers
   Params p;
   bool ran = false;
+  bool manual = false;  // node-level interface active (lbft_batch_manual_begin)
   u32 max_steps = 0;
   u32 lpw = 0;  // 0 = auto
   int ql = -1;  // LDS queue slots per instance; -1 = auto
@@ -266,6 +316,9 @@ struct lbft_batch {
   lbft_counters counters;
   size_t table_bytes = 0;
 };
+
+static int prepare_run(lbft_batch* b, int64_t max_clock);
+static int finalize_run(lbft_batch* b, u32 grid_full, u64 launches);
 
 static int fill_params(const lbft_config* cfg, size_t m, Params& p, std::vector<u32>& weights) {
   memset(&p, 0, sizeof(p));
@@ -390,7 +443,7 @@ int lbft_batch_create(const lbft_config* cfg, const uint64_t* seeds, size_t n_in
   CREATE_TRY(hipMalloc(&b->d_prof, LBFT_NPHASES * sizeof(unsigned long long)));
   CREATE_TRY(hipMalloc(&b->d_states_out, n_instances * cfg->num_nodes * sizeof(u64)));
   CREATE_TRY(hipMalloc(&b->d_counters, C_WORDS * sizeof(unsigned long long)));
-  CREATE_TRY(hipMalloc(&b->d_scratch, n_instances * cfg->num_nodes * sizeof(u64)));
+  CREATE_TRY(hipMalloc(&b->d_scratch, n_instances * cfg->num_nodes * sizeof(u64) + 256));  // + the node-level calls' result words
   rc = upload_tables(b);
   if (rc != LBFT_OK) { free_batch(b); return rc; }
   *out = b;
@@ -406,6 +459,86 @@ int lbft_batch_set_max_steps(lbft_batch* b, uint32_t max_steps) {
 int lbft_batch_set_lanes_per_wavefront(lbft_batch* b, uint32_t lanes) {
   if (!b || lanes > 64 || (lanes && 64 % lanes != 0)) return LBFT_ERR_INVALID;  // a wavefront's instances must share one tile
   b->lpw = lanes;
+  return LBFT_OK;
+}
+
+int lbft_batch_manual_begin(lbft_batch* b, int64_t max_clock) {
+  if (!b) return LBFT_ERR_INVALID;
+  if (b->ran) { g_err = "batch already ran; call lbft_batch_reset first"; return LBFT_ERR_STATE; }
+  int rc = prepare_run(b, max_clock);
+  if (rc != LBFT_OK) return rc;
+  u32 grid_init = (u32)((b->m + b->p.lpw - 1) / b->p.lpw);
+  lbft_k_init<<<grid_init, LBFT_BLOCK, 0, b->stream>>>(b->p, b->d_state, b->d_seeds);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  b->manual = true;
+  return LBFT_OK;
+}
+
+int lbft_batch_manual_finalize(lbft_batch* b) {
+  if (!b) return LBFT_ERR_INVALID;
+  if (!b->manual) { g_err = "lbft_batch_manual_begin first"; return LBFT_ERR_STATE; }
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipEventRecord(b->ev0, b->stream));
+  HIP_TRY(hipEventRecord(b->ev1, b->stream));
+  HIP_TRY(hipEventRecord(b->ev2, b->stream));
+  return finalize_run(b, (u32)((b->m + LBFT_BLOCK - 1) / LBFT_BLOCK), 0);
+}
+
+static int node_op(lbft_batch* b, u32 op, size_t inst, u32 node, u32 arg0, u32 arg1, i64 node_time, unsigned long long* host_out, int n_out) {
+  if (!b || inst >= b->m || node >= b->p.n) return LBFT_ERR_INVALID;
+  if (!b->manual) { g_err = "lbft_batch_manual_begin first"; return LBFT_ERR_STATE; }
+  HIP_TRY(hipSetDevice(b->device));
+  unsigned long long* d_out = reinterpret_cast<unsigned long long*>(b->d_scratch);  // 16 result words
+  lbft_k_node_op<<<1, 64, 0, b->stream>>>(b->p, b->d_state, op, (u32)inst, node, arg0, arg1, node_time, d_out);
+  HIP_TRY(hipGetLastError());
+  if (n_out) HIP_TRY(hipMemcpyAsync(host_out, d_out, n_out * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return LBFT_OK;
+}
+
+int lbft_node_update(lbft_batch* b, size_t inst, uint32_t node, int64_t node_time, lbft_actions* out) {
+  if (!out) return LBFT_ERR_INVALID;
+  unsigned long long h[5];
+  int rc = node_op(b, OP_UPDATE, inst, node, 0, 0, node_time, h, 5);
+  if (rc != LBFT_OK) return rc;
+  out->next_scheduled_update = (int64_t)h[0];
+  out->should_send[0] = h[1]; out->should_send[1] = h[2];
+  out->should_broadcast = (uint32_t)h[3]; out->should_query_all = (uint32_t)h[4];
+  return LBFT_OK;
+}
+int lbft_node_create_notification(lbft_batch* b, size_t inst, uint32_t node, uint32_t* handle) {
+  if (!handle) return LBFT_ERR_INVALID;
+  unsigned long long h[1];
+  int rc = node_op(b, OP_CREATE_NOTIFICATION, inst, node, 0, 0, 0, h, 1);
+  if (rc != LBFT_OK) return rc;
+  if ((long long)h[0] < 0) { g_err = "no free notification snapshot (snapshot_capacity)"; return LBFT_ERR_FAULT; }
+  *handle = (uint32_t)h[0];
+  return LBFT_OK;
+}
+int lbft_node_handle_notification(lbft_batch* b, size_t inst, uint32_t receiver, uint32_t sender, uint32_t handle, uint32_t* should_sync) {
+  if (b && (sender >= b->p.n || handle >= b->p.scap)) return LBFT_ERR_INVALID;
+  unsigned long long h[1];
+  int rc = node_op(b, OP_HANDLE_NOTIFICATION, inst, receiver, sender, handle, 0, h, 1);
+  if (rc != LBFT_OK) return rc;
+  if (should_sync) *should_sync = (uint32_t)h[0];
+  return LBFT_OK;
+}
+int lbft_node_release_notification(lbft_batch* b, size_t inst, uint32_t handle) {
+  if (b && handle >= b->p.scap) return LBFT_ERR_INVALID;
+  return node_op(b, OP_RELEASE_NOTIFICATION, inst, 0, 0, handle, 0, nullptr, 0);
+}
+int lbft_node_view_get(lbft_batch* b, size_t inst, uint32_t node, lbft_node_view* out) {
+  if (!out) return LBFT_ERR_INVALID;
+  unsigned long long h[15];
+  int rc = node_op(b, OP_VIEW, inst, node, 0, 0, 0, h, 15);
+  if (rc != LBFT_OK) return rc;
+  out->epoch_id = h[0]; out->current_round = h[1]; out->highest_quorum_certificate_round = h[2];
+  out->highest_timeout_certificate_round = h[3]; out->highest_committed_round = h[4]; out->active_round = h[5];
+  out->latest_voted_round = h[6]; out->locked_round = h[7]; out->commit_count = h[8];
+  out->active_leader = (uint32_t)h[9]; out->election = (uint32_t)h[10];
+  out->num_current_timeouts = (uint32_t)h[11]; out->num_current_votes = (uint32_t)h[12];
+  out->has_proposed_block = (uint32_t)h[13]; out->has_timeout_certificate = (uint32_t)h[14];
   return LBFT_OK;
 }
 
@@ -446,12 +579,12 @@ int lbft_batch_layout(const lbft_batch* b, uint32_t* out) {
 int lbft_batch_reset(lbft_batch* b) {
   if (!b) return LBFT_ERR_INVALID;
   b->ran = false;
+  b->manual = false;
   return LBFT_OK;
 }
 
-int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
-  if (!b) return LBFT_ERR_INVALID;
-  if (b->ran) { g_err = "batch already ran; call lbft_batch_reset first"; return LBFT_ERR_STATE; }
+// Capacities, HBM layout, launch geometry (shared by lbft_batch_run_until and lbft_batch_manual_begin).
+static int prepare_run(lbft_batch* b, int64_t max_clock) {
   if (max_clock < 0 || max_clock >= 0x7ffffffeLL) { g_err = "max_clock out of range"; return LBFT_ERR_INVALID; }
   HIP_TRY(hipSetDevice(b->device));
   Params& p = b->p;
@@ -499,11 +632,21 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
   // are the LDS-resident slots) instead of the linear scan
   p.qheap = (qcap > 256 || n > 32) ? 1u : 0u;
   b->lds_bytes = run_lds_bytes(ql, lpw);
+  p.prof = b->d_prof;
+  return LBFT_OK;
+}
+
+int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
+  if (!b) return LBFT_ERR_INVALID;
+  if (b->ran) { g_err = "batch already ran; call lbft_batch_reset first"; return LBFT_ERR_STATE; }
+  int prc = prepare_run(b, max_clock);
+  if (prc != LBFT_OK) return prc;
+  Params& p = b->p;
+  u32 lpw = p.lpw;
   int cls = sim_class(p);
   const void* run_fn = cls == 0 ? reinterpret_cast<const void*>(lbft_k_run<0>)
                      : cls == 1 ? reinterpret_cast<const void*>(lbft_k_run<1>) : reinterpret_cast<const void*>(lbft_k_run<2>);
   HIP_TRY(hipFuncSetAttribute(run_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
-  p.prof = b->d_prof;
   HIP_TRY(hipMemsetAsync(b->d_prof, 0, LBFT_NPHASES * sizeof(unsigned long long), b->stream));
   u32 grid_full = (u32)((b->m + LBFT_BLOCK - 1) / LBFT_BLOCK);
   u32 grid_init = (u32)((b->m + lpw - 1) / lpw);
@@ -527,6 +670,11 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
     if (unfinished == 0) break;
   }
   HIP_TRY(hipEventRecord(b->ev2, b->stream));
+  return finalize_run(b, grid_full, launches);
+}
+
+static int finalize_run(lbft_batch* b, u32 grid_full, u64 launches) {
+  Params& p = b->p;
   HIP_TRY(hipMemsetAsync(b->d_counters, 0, C_WORDS * sizeof(unsigned long long), b->stream));
   lbft_k_finalize<<<grid_full, LBFT_BLOCK, 0, b->stream>>>(p, b->d_state, b->d_states_out, b->d_counters);
   HIP_TRY(hipGetLastError());

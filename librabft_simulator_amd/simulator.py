@@ -18,7 +18,7 @@ from collections import namedtuple
 import numpy as np
 
 from . import _lib
-from ._lib import COMMIT_DTYPE, LbftConfig, LbftCounters, LbftError, check
+from ._lib import COMMIT_DTYPE, LbftActions, LbftConfig, LbftCounters, LbftError, LbftNodeView, check
 
 Command = namedtuple("Command", ["proposer", "index"])  # simulated_context.rs:31-35
 Author = int
@@ -223,6 +223,20 @@ class BatchSimulator:
         check(_lib.lib().lbft_batch_run_until(self._h, int(max_clock)), allow_fault=allow_faults)
         return BatchResult(self)
 
+    def manual(self, max_clock=1000):
+        """Node-level mode: initial node states only (NodeState::make_initial_state), no event loop.  Returns
+        ``nodes[instance][author]`` -> NodeHandle."""
+        check(_lib.lib().lbft_batch_manual_begin(self._h, int(max_clock)))
+        return [[NodeHandle(self, i, n) for n in range(self.num_nodes)] for i in range(self.num_instances)]
+
+    def release_notification(self, instance, notification):
+        check(_lib.lib().lbft_node_release_notification(self._h, int(instance), notification[1]))
+
+    def manual_finalize(self):
+        """Makes commit counts / histories / States of a node-level session readable (BatchResult)."""
+        check(_lib.lib().lbft_batch_manual_finalize(self._h), allow_fault=True)
+        return BatchResult(self)
+
     def reset(self):
         check(_lib.lib().lbft_batch_reset(self._h))
 
@@ -261,6 +275,40 @@ class BatchSimulator:
             self.close()
         except Exception:
             pass
+
+
+class NodeHandle:
+    """One node of one instance behind the reference's trait surface (bft-lib/src/interfaces.rs): ``ConsensusNode::
+    update_node`` and ``DataSyncNode::{create_notification, handle_notification}``, each executed on the GPU by
+    ``lbft_node_*``.  Obtained from ``BatchSimulator.manual(...)``; the caller owns time and message delivery (the role
+    of ``Simulator::loop_until`` or of bft-driver's ``CoreDriver``)."""
+
+    def __init__(self, sim, instance, node):
+        self._sim, self.instance, self.author = sim, int(instance), int(node)
+
+    def update_node(self, clock):
+        """ConsensusNode::update_node(clock: NodeTime) -> NodeUpdateActions (librabft-v2/src/node.rs:240-304)."""
+        a = LbftActions()
+        check(_lib.lib().lbft_node_update(self._sim._h, self.instance, self.author, int(clock), C.byref(a)))
+        return a.as_dict()
+
+    def create_notification(self):
+        """DataSyncNode::create_notification (librabft-v2/src/data_sync.rs:82-111) -> opaque handle."""
+        h = C.c_uint32()
+        check(_lib.lib().lbft_node_create_notification(self._sim._h, self.instance, self.author, C.byref(h)))
+        return (self.author, int(h.value))
+
+    def handle_notification(self, notification):
+        """DataSyncNode::handle_notification (data_sync.rs:113-177); True when the reference returns Some(request)."""
+        sender, handle = notification
+        sync = C.c_uint32()
+        check(_lib.lib().lbft_node_handle_notification(self._sim._h, self.instance, self.author, sender, handle, C.byref(sync)))
+        return bool(sync.value)
+
+    def view(self):
+        v = LbftNodeView()
+        check(_lib.lib().lbft_node_view_get(self._sim._h, self.instance, self.author, C.byref(v)))
+        return v.as_dict()
 
 
 class Simulator:

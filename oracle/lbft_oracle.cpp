@@ -1117,6 +1117,7 @@ struct lbft_oracle_sim {
   Xoshiro rng;
   lbft_oracle_counters counters{};
   std::string error;
+  std::vector<std::shared_ptr<Notification>> manual_notifications;  // node-level interface
 
   lbft_oracle_sim(const lbft_oracle_config& c, u64 seed) : cfg(c), rng(seed) {  // Simulator::new :200-250
     rights.assign(c.num_nodes, 1);
@@ -1287,6 +1288,57 @@ size_t lbft_oracle_committed_history(const lbft_oracle_sim* sim, uint32_t node, 
 }
 uint64_t lbft_oracle_last_committed_state(const lbft_oracle_sim* sim, uint32_t node) {
   return sim->nodes[node].context.last_committed_state();
+}
+int lbft_oracle_node_update(lbft_oracle_sim* sim, uint32_t node, int64_t node_time, lbft_oracle_actions* out) {
+  if (!sim || !out || node >= sim->nodes.size()) return -1;
+  try {
+    SimNode& n = sim->nodes[node];
+    NodeUpdateActions a = n.node.update_node(n.context, node_time);
+    out->next_scheduled_update = a.next_scheduled_update;
+    out->should_send[0] = out->should_send[1] = 0;
+    for (Author r : a.should_send) out->should_send[r >> 6] |= 1ULL << (r & 63);
+    out->should_broadcast = a.should_broadcast;
+    out->should_query_all = a.should_query_all;
+    return 0;
+  } catch (const Panic& p) { sim->error = p.msg; return -2; }
+}
+int lbft_oracle_node_create_notification(lbft_oracle_sim* sim, uint32_t node) {
+  if (!sim || node >= sim->nodes.size()) return -1;
+  try {
+    SimNode& n = sim->nodes[node];
+    sim->manual_notifications.push_back(std::make_shared<Notification>(n.node.create_notification(n.context)));
+    return (int)sim->manual_notifications.size() - 1;
+  } catch (const Panic& p) { sim->error = p.msg; return -2; }
+}
+int lbft_oracle_node_handle_notification(lbft_oracle_sim* sim, uint32_t receiver, int handle, uint32_t* should_sync) {
+  if (!sim || receiver >= sim->nodes.size() || handle < 0 || (size_t)handle >= sim->manual_notifications.size()) return -1;
+  try {
+    SimNode& n = sim->nodes[receiver];
+    std::optional<Request> r = n.node.handle_notification(n.context, *sim->manual_notifications[handle]);
+    if (should_sync) *should_sync = r ? 1 : 0;
+    return 0;
+  } catch (const Panic& p) { sim->error = p.msg; return -2; }
+}
+int lbft_oracle_node_view_get(const lbft_oracle_sim* sim, uint32_t node, lbft_oracle_node_view* out) {
+  if (!sim || !out || node >= sim->nodes.size()) return -1;
+  const SimNode& n = sim->nodes[node];
+  const RecordStore& rs = *n.node.record_store;
+  out->epoch_id = n.node.epoch_id;
+  out->current_round = rs.current_round;
+  out->highest_quorum_certificate_round = rs.highest_quorum_certificate_round;
+  out->highest_timeout_certificate_round = rs.highest_timeout_certificate_round;
+  out->highest_committed_round = rs.highest_committed_round;
+  out->active_round = n.node.pacemaker.active_round;
+  out->latest_voted_round = n.node.latest_voted_round;
+  out->locked_round = n.node.locked_round;
+  out->commit_count = n.context.last_committed.history.size();
+  out->active_leader = n.node.pacemaker.active_leader ? (uint32_t)*n.node.pacemaker.active_leader : UINT32_MAX;
+  out->election = (uint32_t)rs.election;
+  out->num_current_timeouts = (uint32_t)rs.current_timeouts.size();
+  out->num_current_votes = (uint32_t)rs.current_votes.size();
+  out->has_proposed_block = rs.current_proposed_block ? 1 : 0;
+  out->has_timeout_certificate = rs.highest_timeout_certificate ? 1 : 0;
+  return 0;
 }
 uint64_t lbft_oracle_active_round(const lbft_oracle_sim* sim, uint32_t node) {
   return sim->nodes[node].node.pacemaker.active_round;

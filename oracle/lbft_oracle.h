@@ -86,6 +86,29 @@ int lbft_oracle_run_batch(const lbft_oracle_config* cfg, const uint64_t* seeds, 
                           uint64_t* active_rounds, uint64_t* last_states, lbft_oracle_commit* histories,
                           size_t history_cap, lbft_oracle_counters* counters);
 
+/* ---- node-level interface: the reference's trait surface (bft-lib/src/interfaces.rs:12-86) on the nodes of one
+ * simulator, without the event loop, so that record-store / pacemaker scenarios (librabft-v2/src/unit_tests/
+ * record_store_tests.rs) can be replayed step by step and compared with the device's lbft_node_* calls. ---- */
+typedef struct lbft_oracle_actions { /* NodeUpdateActions (interfaces.rs:12-21) */
+  int64_t next_scheduled_update;
+  uint64_t should_send[2]; /* bit set of authors */
+  uint32_t should_broadcast, should_query_all;
+} lbft_oracle_actions;
+typedef struct lbft_oracle_node_view {
+  uint64_t epoch_id, current_round, highest_quorum_certificate_round, highest_timeout_certificate_round,
+      highest_committed_round, active_round, latest_voted_round, locked_round, commit_count;
+  uint32_t active_leader; /* UINT32_MAX = None */
+  uint32_t election;      /* 0 ongoing, 1 won, 2 closed (record_store.rs:125-134) */
+  uint32_t num_current_timeouts, num_current_votes, has_proposed_block, has_timeout_certificate;
+} lbft_oracle_node_view;
+/* ConsensusNode::update_node(clock = NodeTime) (node.rs:240-304) */
+int lbft_oracle_node_update(lbft_oracle_sim* sim, uint32_t node, int64_t node_time, lbft_oracle_actions* out);
+/* DataSyncNode::create_notification (data_sync.rs:82-111); returns a handle >= 0 */
+int lbft_oracle_node_create_notification(lbft_oracle_sim* sim, uint32_t node);
+/* DataSyncNode::handle_notification (data_sync.rs:113-177); *should_sync = a request was produced */
+int lbft_oracle_node_handle_notification(lbft_oracle_sim* sim, uint32_t receiver, int handle, uint32_t* should_sync);
+int lbft_oracle_node_view_get(const lbft_oracle_sim* sim, uint32_t node, lbft_oracle_node_view* out);
+
 /* Known-answer helpers for the third-party arithmetic (tests/test_oracle_kat.py). */
 uint64_t lbft_oracle_siphash13(const uint8_t* bytes, size_t n);
 void lbft_oracle_xoshiro_first(uint64_t seed, uint64_t* out, size_t n);

@@ -57,6 +57,28 @@ class OracleCounters(C.Structure):
 
 COMMIT_DTYPE = np.dtype([("proposer", "<u8"), ("index", "<u8"), ("time", "<i8")])
 
+class OracleActions(C.Structure):
+    _fields_ = [("next_scheduled_update", C.c_int64), ("should_send", C.c_uint64 * 2), ("should_broadcast", C.c_uint32),
+                ("should_query_all", C.c_uint32)]
+
+    def as_dict(self):
+        bits = int(self.should_send[0]) | (int(self.should_send[1]) << 64)
+        return {"next_scheduled_update": int(self.next_scheduled_update),
+                "should_send": [a for a in range(128) if (bits >> a) & 1],
+                "should_broadcast": bool(self.should_broadcast), "should_query_all": bool(self.should_query_all)}
+
+
+class OracleNodeView(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("epoch_id", "current_round", "highest_quorum_certificate_round",
+                                           "highest_timeout_certificate_round", "highest_committed_round", "active_round",
+                                           "latest_voted_round", "locked_round", "commit_count")] + \
+               [(n, C.c_uint32) for n in ("active_leader", "election", "num_current_timeouts", "num_current_votes",
+                                           "has_proposed_block", "has_timeout_certificate")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
 _lib = None
 
 
@@ -97,6 +119,14 @@ def lib():
             C.POINTER(OracleConfig), vp, C.c_size_t, C.c_int64, C.c_uint32, vp, vp, vp, vp, C.c_size_t,
             C.POINTER(OracleCounters)]
         L.lbft_oracle_run_batch.restype = C.c_int
+        L.lbft_oracle_node_update.argtypes = [vp, C.c_uint32, C.c_int64, C.POINTER(OracleActions)]
+        L.lbft_oracle_node_update.restype = C.c_int
+        L.lbft_oracle_node_create_notification.argtypes = [vp, C.c_uint32]
+        L.lbft_oracle_node_create_notification.restype = C.c_int
+        L.lbft_oracle_node_handle_notification.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
+        L.lbft_oracle_node_handle_notification.restype = C.c_int
+        L.lbft_oracle_node_view_get.argtypes = [vp, C.c_uint32, C.POINTER(OracleNodeView)]
+        L.lbft_oracle_node_view_get.restype = C.c_int
         L.lbft_oracle_siphash13.argtypes = [C.c_char_p, C.c_size_t]
         L.lbft_oracle_siphash13.restype = C.c_uint64
         L.lbft_oracle_xoshiro_first.argtypes = [C.c_uint64, vp, C.c_size_t]
@@ -185,6 +215,32 @@ class OracleSim:
         c = OracleCounters()
         lib().lbft_oracle_counters_get(self.h, C.byref(c))
         return c.as_dict()
+
+    # ---- node-level interface (the reference's traits on one node; no event loop) ----
+    def node_update(self, node, clock):
+        a = OracleActions()
+        rc = lib().lbft_oracle_node_update(self.h, node, clock, C.byref(a))
+        if rc != 0:
+            raise RuntimeError("oracle node_update failed: %d %s" % (rc, lib().lbft_oracle_last_error(self.h).decode()))
+        return a.as_dict()
+
+    def node_create_notification(self, node):
+        h = lib().lbft_oracle_node_create_notification(self.h, node)
+        if h < 0:
+            raise RuntimeError("oracle create_notification failed: %d" % h)
+        return h
+
+    def node_handle_notification(self, receiver, handle):
+        sync = C.c_uint32()
+        rc = lib().lbft_oracle_node_handle_notification(self.h, receiver, handle, C.byref(sync))
+        if rc != 0:
+            raise RuntimeError("oracle handle_notification failed: %d %s" % (rc, lib().lbft_oracle_last_error(self.h).decode()))
+        return bool(sync.value)
+
+    def node_view(self, node):
+        v = OracleNodeView()
+        lib().lbft_oracle_node_view_get(self.h, node, C.byref(v))
+        return v.as_dict()
 
     def close(self):
         if self.h:

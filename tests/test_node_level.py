@@ -1,0 +1,209 @@
+"""Node-level interface: the reference's trait surface (bft-lib/src/interfaces.rs:12-86) for single nodes, without
+the event loop.
+
+CPU part: the record-store / pacemaker scenarios of the reference's unit tests
+(librabft-v2/src/unit_tests/record_store_tests.rs) replayed on the ORACLE through update_node /
+create_notification / handle_notification, asserting what those tests assert (one vote per author, QC at quorum,
+timeouts -> TC -> next round, no commit on non-contiguous rounds, 3-chain commit).  The reference builds records by
+hand in a SharedRecordStore fixture; here they are produced by the nodes themselves, which pins the same rules.
+
+GPU part (-m gpu): the identical scripted sessions on the device (lbft_node_* through the C ABI) must return the same
+NodeUpdateActions and the same node views as the oracle after every single call.
+"""
+import numpy as np
+import pytest
+
+
+class OracleDriver:
+    def __init__(self, oracle, n, **kw):
+        self.sim = oracle.OracleSim(oracle.make_config(num_nodes=n, math_mode=1, **kw), 1)
+        self.n = n
+
+    def update(self, node, clock):
+        return self.sim.node_update(node, clock)
+
+    def notify(self, sender):
+        return self.sim.node_create_notification(sender)
+
+    def deliver(self, receiver, notification):
+        return self.sim.node_handle_notification(receiver, notification)
+
+    def view(self, node):
+        return self.sim.node_view(node)
+
+    def release(self, notification):
+        pass
+
+
+class DeviceDriver:
+    def __init__(self, amd, n, **kw):
+        nc = amd.NodeConfig(kw.get("target_commit_interval", 100000), kw.get("delta", 20), kw.get("gamma", 2.0), kw.get("lambda_", 0.5))
+        self.sim = amd.BatchSimulator.new(np.array([1, 2], dtype=np.uint64), n, amd.RandomDelay.new(10.0, 4.0), nc,
+                                          commands_per_epoch=kw.get("commands_per_epoch", 30000),
+                                          voting_rights=kw.get("voting_rights"), snapshot_capacity=64)
+        self.nodes = self.sim.manual(100000)[1]  # instance 1 (instance 0 stays untouched)
+        self.n = n
+
+    def update(self, node, clock):
+        return self.nodes[node].update_node(clock)
+
+    def notify(self, sender):
+        return self.nodes[sender].create_notification()
+
+    def deliver(self, receiver, notification):
+        return self.nodes[receiver].handle_notification(notification)
+
+    def view(self, node):
+        return self.nodes[node].view()
+
+    def release(self, notification):
+        self.sim.release_notification(1, notification)
+
+
+def full_exchange(d, clock, trace, rounds=1):
+    """Every node updates at `clock`; each node whose actions ask for it sends its notification to the named
+    receivers (broadcast = everybody else) and those update again -- repeated until nothing is sent."""
+    pending = list(range(d.n))
+    for _ in range(200):
+        if not pending:
+            break
+        nxt = []
+        for node in pending:
+            a = d.update(node, clock)
+            trace.append(("update", node, clock, a, d.view(node)))
+            receivers = [r for r in range(d.n) if r != node] if a["should_broadcast"] else [r for r in a["should_send"] if r != node]
+            if receivers:
+                note = d.notify(node)
+                for r in receivers:
+                    sync = d.deliver(r, note)
+                    trace.append(("deliver", node, r, sync, d.view(r)))
+                    if r not in nxt:
+                        nxt.append(r)
+                d.release(note)
+            if a["next_scheduled_update"] <= clock and node not in nxt:
+                nxt.append(node)
+        pending = nxt
+    return trace
+
+
+def scenario_healthy_rounds(d):
+    """Rounds advance through proposals, votes and QCs; commits follow the 3-chain rule."""
+    trace = []
+    for clock in range(0, 12):
+        full_exchange(d, clock, trace)
+    return trace
+
+
+def scenario_timeouts(d, finish=True):
+    """Nobody hears the leader: every node times out, timeouts are exchanged, a TC forms and the round advances."""
+    trace = []
+    for node in range(d.n):                       # enter round 1, but deliver nothing
+        trace.append(("update", node, 0, d.update(node, 0), d.view(node)))
+    v0 = d.view(0)
+    deadline = 10 ** 6
+    for node in range(d.n):
+        a = d.update(node, 1)
+        trace.append(("update", node, 1, a, d.view(node)))
+        deadline = min(deadline, a["next_scheduled_update"])
+    notes = []
+    for node in range(d.n):                       # at the deadline every node creates its timeout and broadcasts
+        a = d.update(node, deadline)
+        trace.append(("timeout", node, deadline, a, d.view(node)))
+        notes.append(d.notify(node))
+    for sender in range(d.n):
+        for r in range(d.n):
+            if r != sender:
+                trace.append(("deliver", sender, r, d.deliver(r, notes[sender]), d.view(r)))
+    for note in notes:
+        d.release(note)
+    for node in range(d.n if finish else 0):      # (the new leader's proposal is not delivered)
+        trace.append(("update", node, deadline + 1, d.update(node, deadline + 1), d.view(node)))
+    return trace, v0, deadline
+
+
+def test_oracle_healthy_rounds_commit_rule(oracle):
+    # record_store_tests.rs:148-165 (QC at quorum), :236-292 (3-chain commit), :123-146 (one vote per author)
+    d = OracleDriver(oracle, 4)
+    trace = scenario_healthy_rounds(d)
+    views = [d.view(n) for n in range(4)]
+    assert all(v["highest_quorum_certificate_round"] >= 4 for v in views)
+    # 3-chain: with contiguous rounds r, r+1, r+2 certified, round r commits: committed = hqc - 2
+    assert all(v["highest_committed_round"] == v["highest_quorum_certificate_round"] - 2 for v in views)
+    assert all(v["commit_count"] == v["highest_committed_round"] for v in views)
+    # votes held for the current round never exceed one per author
+    assert all(t[4]["num_current_votes"] <= 4 for t in trace)
+    # a QC appears exactly when the leader holds a quorum (3 of 4) of votes: election leaves "ongoing"
+    won = [t for t in trace if t[0] == "deliver" and t[4]["election"] != 0]
+    assert won and all(t[4]["num_current_votes"] >= 3 for t in won)
+    # locked round / latest voted round follow node.rs:256-276
+    assert all(v["locked_round"] <= v["latest_voted_round"] for v in views)
+
+
+def test_oracle_timeouts_form_tc_and_advance_round(oracle):
+    # record_store_tests.rs:167-217: timeouts accumulate weight, the TC forms at quorum and moves to round + 1
+    d = OracleDriver(oracle, 4)
+    trace, v0, deadline = scenario_timeouts(d)
+    assert v0["active_round"] == 1 and deadline == 20  # delta * 1^gamma
+    for node in range(4):
+        v = d.view(node)
+        assert v["highest_timeout_certificate_round"] == 1 and v["has_timeout_certificate"] == 1
+        assert v["current_round"] == 2 and v["active_round"] == 2
+        assert v["highest_quorum_certificate_round"] == 0 and v["highest_committed_round"] == 0  # no QC => no commit
+        assert v["num_current_timeouts"] == 0  # cleared on the round change (record_store.rs:207-219)
+    # before the third timeout arrived no node had a TC
+    partial = [t for t in trace if t[0] == "deliver" and t[4]["num_current_timeouts"] == 2]
+    assert partial and all(t[4]["has_timeout_certificate"] == 0 for t in partial)
+
+
+def scenario_timeout_then_healthy(d):
+    trace, _, deadline = scenario_timeouts(d, finish=False)
+    for clock in range(deadline + 1, deadline + 5):
+        full_exchange(d, clock, trace)
+    return trace
+
+
+def test_oracle_commit_needs_three_contiguous_certified_rounds(oracle):
+    # record_store_tests.rs:219-234 / :236-292: round 1 times out (never certified), so the first commit is round 2
+    # and it happens only once rounds 2, 3 and 4 are certified; highest_committed_round always trails the QC by 2.
+    d = OracleDriver(oracle, 4)
+    trace = scenario_timeout_then_healthy(d)
+    views = [t[4] for t in trace]
+    assert max(v["highest_quorum_certificate_round"] for v in views) >= 6
+    for v in views:
+        if v["highest_quorum_certificate_round"] < 4:
+            assert v["highest_committed_round"] == 0 and v["commit_count"] == 0
+        else:
+            assert v["highest_committed_round"] == v["highest_quorum_certificate_round"] - 2
+            # round 1 produced no block to commit; the ledger follows on the node's next update_node (node.rs:313-350)
+            assert v["commit_count"] <= v["highest_committed_round"] - 1
+    for node in range(4):
+        d.update(node, 10 ** 4)
+        v = d.view(node)
+        assert v["commit_count"] == v["highest_committed_round"] - 1
+
+
+SESSIONS = {
+    "healthy_4": (4, {}, lambda d: scenario_healthy_rounds(d)),
+    "healthy_7_weighted": (7, dict(voting_rights=[3, 1, 1, 2, 1, 1, 2]), lambda d: scenario_healthy_rounds(d)),
+    "timeouts_4": (4, {}, lambda d: scenario_timeouts(d)[0]),
+    "timeout_then_healthy_4": (4, {}, lambda d: scenario_timeout_then_healthy(d)),
+    "timeouts_5_fast_pacemaker": (5, dict(delta=3, gamma=1.5, lambda_=0.25), lambda d: scenario_timeouts(d)[0]),
+    "healthy_40_nodes": (40, {}, lambda d: full_exchange(d, 0, []) + full_exchange(d, 1, [])),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(SESSIONS))
+def test_device_node_level_equals_oracle(oracle, name):
+    import librabft_simulator_amd as amd
+    n, kw, script = SESSIONS[name]
+    a = script(OracleDriver(oracle, n, **kw))
+    dev = DeviceDriver(amd, n, **kw)
+    b = script(dev)
+    assert len(a) == len(b) and len(a) > 10
+    for x, y in zip(a, b):
+        assert x == y, (x, y)
+    # the node-level session left instance 0 untouched and its results are readable through the batch calls
+    res = dev.sim.manual_finalize()
+    assert res.commit_counts[0].sum() == 0
+    assert [int(c) for c in res.commit_counts[1]] == [dev.view(i)["commit_count"] for i in range(n)]
