@@ -40,6 +40,7 @@ extern "C" {
 #define LBFT_FAULT_COMMIT_NOT_SUCCESSOR (1u << 7) /* simulated_context.rs:172-174 would panic */
 #define LBFT_FAULT_STAMP_OVERFLOW (1u << 8)
 #define LBFT_FAULT_INTERNAL (1u << 9)
+#define LBFT_FAULT_TRACE_OVERFLOW (1u << 11)
 
 /* Simulation parameters: the arguments of Simulator::new (bft-lib/src/simulator.rs:200-208),
  * RandomDelay::new (:99-106), SimulatedContext::new (bft-lib/src/simulated_context.rs:86-96) and
@@ -141,6 +142,15 @@ int lbft_batch_set_lds_queue_slots(lbft_batch* b, int32_t slots);
 int lbft_batch_phase_cycles(const lbft_batch* b, uint64_t* out);
 /* Tuning: how many of a wavefront's 64 lanes carry an instance (0 = auto from the batch size). Results do not depend on it. */
 int lbft_batch_set_lanes_per_wavefront(lbft_batch* b, uint32_t lanes);
+
+/* DataWriter of the reference (`--create_csv`; bft-lib/src/data_writer.rs, called per popped event from
+ * simulator.rs:393-396): records, per node, the GlobalTime of the first popped event at which the node was seen in
+ * each round, and counts the non-timer events.  Enable before lbft_batch_run_until (max_rounds = rows kept per
+ * node; going past it raises LBFT_FAULT_TRACE_OVERFLOW for that instance).  lbft_batch_round_switches returns the
+ * cells of round_switches.txt for one instance: out[round * num_nodes + node], INT64_MIN = empty cell, rows for
+ * round < min(*max_round, cap_rounds); *messages = the value of number_of_messages.txt. */
+int lbft_batch_enable_round_trace(lbft_batch* b, uint32_t max_rounds);
+int lbft_batch_round_switches(const lbft_batch* b, size_t inst, int64_t* out, size_t cap_rounds, uint64_t* max_round, uint64_t* messages);
 
 /* ---- Node-level interface: the reference's trait surface for ONE node of ONE instance, without the event loop
  * (bft-lib/src/interfaces.rs:12-86), so that record-store / pacemaker scenarios can be replayed step by step

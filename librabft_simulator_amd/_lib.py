@@ -19,7 +19,7 @@ LBFT_ERR_FAULT = -5
 FAULT_NAMES = {
     1 << 0: "queue_overflow", 1 << 1: "snapshot_overflow", 1 << 2: "block_overflow", 1 << 3: "log_overflow",
     1 << 4: "ballot_overflow", 1 << 5: "duration_table", 1 << 6: "commit_unknown_state",
-    1 << 7: "commit_not_successor", 1 << 8: "stamp_overflow", 1 << 9: "internal",
+    1 << 7: "commit_not_successor", 1 << 8: "stamp_overflow", 1 << 9: "internal", 1 << 11: "trace_overflow",
 }
 
 
@@ -99,7 +99,7 @@ ABI_SYMBOLS = [
     "lbft_batch_faults", "lbft_batch_destroy", "lbft_batch_stream", "lbft_batch_last_run_ms",
     "lbft_batch_device_bytes", "lbft_batch_set_max_steps", "lbft_batch_set_lanes_per_wavefront",
     "lbft_batch_set_lds_queue_slots", "lbft_batch_phase_cycles", "lbft_batch_layout",
-    "lbft_batch_manual_begin", "lbft_batch_manual_finalize", "lbft_node_update", "lbft_node_create_notification",
+    "lbft_batch_enable_round_trace", "lbft_batch_round_switches", "lbft_batch_manual_begin", "lbft_batch_manual_finalize", "lbft_node_update", "lbft_node_create_notification",
     "lbft_node_handle_notification", "lbft_node_release_notification", "lbft_node_view_get", "lbft_device_leaders", "lbft_device_sample_delays",
     "lbft_device_exp_log", "lbft_last_error", "lbft_build_info",
 ]
@@ -154,6 +154,10 @@ def lib():
     L.lbft_batch_set_lanes_per_wavefront.restype = C.c_int
     L.lbft_batch_set_lds_queue_slots.argtypes = [vp, C.c_int32]
     L.lbft_batch_set_lds_queue_slots.restype = C.c_int
+    L.lbft_batch_enable_round_trace.argtypes = [vp, C.c_uint32]
+    L.lbft_batch_enable_round_trace.restype = C.c_int
+    L.lbft_batch_round_switches.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.lbft_batch_round_switches.restype = C.c_int
     L.lbft_batch_manual_begin.argtypes = [vp, C.c_int64]
     L.lbft_batch_manual_begin.restype = C.c_int
     L.lbft_batch_manual_finalize.argtypes = [vp]

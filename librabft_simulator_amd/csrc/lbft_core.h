@@ -49,6 +49,7 @@ enum Fault : u32 {
   F_STAMP_OVERFLOW = 1u << 8,
   F_INTERNAL = 1u << 9,
   F_STEP_LIMIT = 1u << 10,
+  F_TRACE_OVERFLOW = 1u << 11,  // a node went past round_trace_capacity (round-switch trace only)
 };
 
 // Batch-uniform parameters (kernel argument).
@@ -83,6 +84,7 @@ struct Params {
   u32 off_blk, blk_words;
   u32 off_log;
   u32 off_list;  // n > 16 only: receiver list scratch of process_node_actions
+  u32 off_trace, rcap;  // round-switch trace (DataWriter, data_writer.rs): first_time[n][rcap] then max_round[n]; rcap == 0: off
   u32 total_words;
   u32 max_steps;  // events per instance per launch (0 = unlimited)
   u32 lpw;        // lanes of each wavefront that carry an instance (1..64): occupancy vs lane-utilisation knob
@@ -118,7 +120,7 @@ struct Params {
 enum InstField : u32 {
   I_CLOCK = 0, I_STAMP, I_RNG0, I_RNG1, I_RNG2, I_RNG3, I_RNG4, I_RNG5, I_RNG6, I_RNG7,
   I_QLEN, I_SNAP_FREE, I_NBLOCKS, I_FAULT, I_EV0, I_EV1, I_EV2, I_EV3, I_DRAWS, I_DONE,
-  I_MAXQ, I_MAXSNAP, I_SNAP_MASK_LO, I_SNAP_MASK_HI, I_WORDS
+  I_MAXQ, I_MAXSNAP, I_SNAP_MASK_LO, I_SNAP_MASK_HI, I_LAST_NODE, I_VD_TIME, I_VD_STAMP, I_WORDS
 };
 
 // Node-level rows (RecordStoreState record_store.rs:93-119, PacemakerState pacemaker.rs:60-77,
@@ -133,6 +135,7 @@ enum NodeField : u32 {
   NF_LVR, NF_LOCKED, NF_LQAT, NF_TR_EPOCH, NF_TR_HCR, NF_TR_LCT,
   NF_NEXT_CMD, NF_LAST_COMMITTED_BLK, NF_NCOMMITS,
   NF_LAST_TIMER_T, NF_TIMER_DUPS,  // duplicate-timer folding (see process_node_actions)
+  NF_DUP_STAMP,  // creation stamp of the most recently folded duplicate timer (round-switch trace)
   NF_TC_SEL,  // which of the two hcbr[n] buffers holds the timeout certificate (the other: current timeouts)
   NF_FIXED_WORDS  // followed by hcbr[2][n]: highest_certified_block_round per timeout author
 };
@@ -319,6 +322,10 @@ struct SimT {
   // instance scalars cached in registers for the duration of a launch
   i32 clock;
   u32 stamp, qlen, snap_free, nblocks, fault, maxq, maxsnap;
+  u32 ev_stamp;   // creation stamp of the event being processed
+  u32 last_node;  // node of the previous event (round-switch trace)
+  // round-switch trace: folded duplicate timers of time vd_time still "pop" in the reference until stamp vd_stamp
+  u32 vd_time, vd_stamp;
   u64 snap_mask;  // scap <= 64: free snapshot slots as a bit set held in registers (no free-stack round trip)
   u32 ev0, ev1, ev2, ev3;
   Rng rng;
@@ -510,6 +517,7 @@ struct SimT {
     ev0 = ld(I_EV0); ev1 = ld(I_EV1); ev2 = ld(I_EV2); ev3 = ld(I_EV3);
     maxq = ld(I_MAXQ); maxsnap = ld(I_MAXSNAP);
     snap_mask = ld(I_SNAP_MASK_LO) | ((u64)ld(I_SNAP_MASK_HI) << 32);
+    last_node = ld(I_LAST_NODE); vd_time = ld(I_VD_TIME); vd_stamp = ld(I_VD_STAMP);
     blk_cache_reset();
   }
   LBFT_HD void store_scalars(bool done) {
@@ -521,6 +529,7 @@ struct SimT {
     st(I_EV0, ev0); st(I_EV1, ev1); st(I_EV2, ev2); st(I_EV3, ev3);
     st(I_MAXQ, maxq); st(I_MAXSNAP, maxsnap);
     st(I_SNAP_MASK_LO, (u32)snap_mask); st(I_SNAP_MASK_HI, (u32)(snap_mask >> 32));
+    st(I_LAST_NODE, last_node); st(I_VD_TIME, vd_time); st(I_VD_STAMP, vd_stamp);
     st(I_DONE, done ? 1u : 0u);
   }
 
@@ -583,8 +592,10 @@ struct SimT {
       st(P.off_qhi + k, (u32)(key >> 32)); st(P.off_qlo + k, (u32)key); st(P.off_qmeta + k, qm[k * qstr]);
     }
   }
-  LBFT_HD bool push_event(i64 time, u32 kind, u32 node, u32 sender, u32 slot) {
-    u32 my_stamp = stamp++;
+  // `reuse_stamp` != ~0u: the event takes that (already handed out, otherwise unused) creation stamp.
+  LBFT_HD bool push_event(i64 time, u32 kind, u32 node, u32 sender, u32 slot, u32 reuse_stamp = ~0u) {
+    u32 my_stamp = reuse_stamp;
+    if (reuse_stamp == ~0u) my_stamp = stamp++;
     if (time > (i64)P.max_clock) return false;
     if (my_stamp >= (1u << 30)) { fault |= F_STAMP_OVERFLOW; return false; }
     if (qlen >= P.qcap) { fault |= F_QUEUE_OVERFLOW; return false; }
@@ -616,6 +627,7 @@ struct SimT {
       q_get(0, rk, rm);
       time = (i32)(u32)(rk >> 32);
       kind = 3u - ((u32)rk >> 30);
+      ev_stamp = (u32)rk & 0x3fffffffu;
       meta = rm;
       qlen--;
       if (qlen) {
@@ -656,6 +668,7 @@ struct SimT {
     }
     time = (i32)(u32)(bkey >> 32);
     kind = 3u - ((u32)bkey >> 30);
+    ev_stamp = (u32)bkey & 0x3fffffffu;
     meta = best < ql ? qm[best * qstr] : ld(P.off_qmeta + best);
     qlen--;
     if (best != qlen) {
@@ -1224,9 +1237,23 @@ struct SimT {
     // same time (it is still pending: that time is > clock), only count the duplicate.
     if (t_new <= (i64)P.max_clock && (u32)t_new == nf(node, NF_LAST_TIMER_T)) {
       nfs(node, NF_TIMER_DUPS, nf(node, NF_TIMER_DUPS) + 1);
+      nfs(node, NF_DUP_STAMP, stamp);
       stamp++;
     } else {
-      if (t_new <= (i64)P.max_clock) { nfs(node, NF_LAST_TIMER_T, (u32)t_new); }
+      if (t_new <= (i64)P.max_clock) {
+        // The tracked timer time moves on.  When the round-switch trace is on (it needs every pop at its own time;
+        // otherwise they are simply counted with the next tracked timer of this node, which leaves all event totals
+        // unchanged), duplicates still folded into the previous one are materialised as
+        // ONE counted no-op event at their own time, carrying the creation stamp of the last of them (it pops
+        // after its original, hence cancelled), so that event counts and the round-switch trace stay attributed
+        // to the right time and queue position.
+        u32 dups = nf(node, NF_TIMER_DUPS);
+        if (dups && P.rcap) {
+          push_event((i64)(i32)nf(node, NF_LAST_TIMER_T), 3, node, 0, dups - 1, nf(node, NF_DUP_STAMP));
+          nfs(node, NF_TIMER_DUPS, 0);
+        }
+        nfs(node, NF_LAST_TIMER_T, (u32)t_new);
+      }
       push_event(t_new, 3, node, 0, 0);
     }
     LBFT_MARK(12);
@@ -1269,6 +1296,11 @@ struct SimT {
     blk_cache_reset();
     snap_free = P.scap;
     snap_mask = P.scap >= 64 ? ~0ULL : ((1ULL << P.scap) - 1);
+    last_node = 0; vd_time = 0xffffffffu; vd_stamp = 0;
+    if (P.rcap) {
+      for (u32 k = 0; k < P.n * P.rcap; k++) st(P.off_trace + k, 0xffffffffu);
+      for (u32 k = 0; k < P.n; k++) st(P.off_trace + P.n * P.rcap + k, 0);
+    }
     for (u32 s = 0; s < P.scap; s++) { st(P.off_snap_free + s, P.scap - 1 - s); st(P.off_snap_ref + s, 0); }
     rng.seed(seed);
     for (u32 node = 0; node < P.n; node++) {
@@ -1285,6 +1317,19 @@ struct SimT {
     store_scalars(false);
   }
 
+  // ---- DataWriter::update_round_number (data_writer.rs:34-50), called by loop_until for every popped event with
+  // the event's own scheduled time (simulator.rs:393-396).  Only the node of the previous event can have entered
+  // a new round since the last call, so one node is examined instead of all. ----
+  LBFT_HD void trace_round_switch(u32 node, i32 event_time) {
+    u32 ar = nfm(node, NF_PM_ROUND);
+    u32 mw = P.off_trace + P.n * P.rcap + node;
+    if (ar > ld(mw)) {
+      st(mw, ar);
+      if (ar < P.rcap) st(P.off_trace + node * P.rcap + ar, (u32)event_time);
+      else fault |= F_TRACE_OVERFLOW;
+    }
+  }
+
   // ---- Simulator::loop_until (simulator.rs:380-475); returns true when the queue drained ----
   LBFT_HD bool run() {
     u32 steps = 0;
@@ -1295,8 +1340,11 @@ struct SimT {
       LBFT_MARK(0);
       LBFT_COUNT(30);
       steps++;
+      if (P.rcap) trace_round_switch(last_node, t);
+      i32 t_event = t;
       if (t > clock) clock = t;
       u32 node = meta & 0xffu, sender = (meta >> 8) & 0xffu, slot = meta >> 16;
+      last_node = node;
       // One shared site for the node-row burst (and, for a notification, its snapshot words in the same
       // burst), one for update_node + process_node_actions: lanes of a wavefront that handle different
       // event kinds issue their loads together instead of one serialized round trip per kind.
@@ -1311,8 +1359,13 @@ struct SimT {
       LBFT_DRAIN_VMEM();
       LBFT_MARK(1);
       if (kind == 3) {  // UpdateTimerEvent (simulator.rs:403-415)
-        ev3++;
+        ev3 += 1 + slot;  // slot > 0: a materialised group of folded duplicates (see process_node_actions)
         if ((u32)clock == nf(node, NF_LAST_TIMER_T)) {  // folded duplicates of this timer
+          if (nf(node, NF_TIMER_DUPS) != 0) {  // their pops follow, interleaved by stamp with the other timers of this time
+            u32 ds = nf(node, NF_DUP_STAMP) + 1;
+            vd_stamp = (vd_time == (u32)clock && vd_stamp > ds) ? vd_stamp : ds;
+            vd_time = (u32)clock;
+          }
           ev3 += nf(node, NF_TIMER_DUPS);
           nfs(node, NF_TIMER_DUPS, 0);
           nfs(node, NF_LAST_TIMER_T, 0xffffffffu);
@@ -1349,6 +1402,8 @@ struct SimT {
         LBFT_DRAIN_VMEM();
         LBFT_MARK(17);
       }
+      // folded duplicate timers of this scheduled time still pop after this timer in the reference
+      if (P.rcap && kind == 3 && (u32)t_event == vd_time && ev_stamp < vd_stamp) trace_round_switch(node, t_event);
     }
   }
 };
@@ -1373,6 +1428,7 @@ inline u32 compute_layout(Params& p) {
   p.off_blk = w; w += p.bcap * p.blk_words;
   p.off_log = w; w += p.n * p.lcap;
   p.off_list = w; w += p.n > 16 ? p.n : 0;
+  p.off_trace = w; w += p.rcap ? p.n * p.rcap + p.n : 0;
   p.total_words = w;
   return w;
 }

@@ -310,6 +310,7 @@ struct lbft_batch {
   u32 max_steps = 0;
   u32 lpw = 0;  // 0 = auto
   int ql = -1;  // LDS queue slots per instance; -1 = auto
+  u32 rcap = 0; // round-switch trace capacity (rounds per node); 0 = off
   unsigned long long* d_prof = nullptr;
   size_t lds_bytes = 0;
   float init_ms = 0, run_ms = 0;
@@ -542,6 +543,40 @@ int lbft_node_view_get(lbft_batch* b, size_t inst, uint32_t node, lbft_node_view
   return LBFT_OK;
 }
 
+int lbft_batch_enable_round_trace(lbft_batch* b, uint32_t max_rounds) {
+  if (!b) return LBFT_ERR_INVALID;
+  if (b->ran || b->manual) { g_err = "enable the round trace before running the batch"; return LBFT_ERR_STATE; }
+  b->rcap = max_rounds;
+  return LBFT_OK;
+}
+
+// out[round * num_nodes + node] = GlobalTime at which `node` was first seen in `round` by the reference's DataWriter
+// (bft-lib/src/data_writer.rs:34-50), INT64_MIN = empty cell; rows for round < min(max_round, cap_rounds).
+int lbft_batch_round_switches(const lbft_batch* b, size_t inst, int64_t* out, size_t cap_rounds, uint64_t* max_round, uint64_t* messages) {
+  if (!b || !out || !max_round || inst >= b->m) return LBFT_ERR_INVALID;
+  if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
+  if (b->p.rcap == 0) { g_err = "lbft_batch_enable_round_trace was not called"; return LBFT_ERR_STATE; }
+  HIP_TRY(hipSetDevice(b->device));
+  const Params& p = b->p;
+  u32 words = p.n * p.rcap + p.n;
+  std::vector<u32> h(words + 3);
+  // strided rows of one instance: word w lives at word_offset(p, inst, w); copy as a 2-D memcpy (4 bytes x words, pitch 256)
+  HIP_TRY(hipMemcpy2D(h.data(), sizeof(u32), b->d_state + word_offset(p, (u32)inst, p.off_trace), LBFT_ROW_BYTES, sizeof(u32), words,
+                      hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy2D(h.data() + words, sizeof(u32), b->d_state + word_offset(p, (u32)inst, I_EV0), LBFT_ROW_BYTES, sizeof(u32), 3,
+                      hipMemcpyDeviceToHost));
+  u32 mr = 0;
+  for (u32 k = 0; k < p.n; k++) mr = h[p.n * p.rcap + k] > mr ? h[p.n * p.rcap + k] : mr;
+  *max_round = mr;
+  for (u32 r = 0; r < mr && r < cap_rounds && r < p.rcap; r++)
+    for (u32 k = 0; k < p.n; k++) {
+      u32 t = h[k * p.rcap + r];
+      out[(size_t)r * p.n + k] = t == 0xffffffffu ? INT64_MIN : (int64_t)(i32)t;
+    }
+  if (messages) *messages = (uint64_t)h[words] + h[words + 1] + h[words + 2];  // DataWriter::add_message_counter: every non-timer event
+  return LBFT_OK;
+}
+
 int lbft_batch_set_lds_queue_slots(lbft_batch* b, int32_t slots) {
   if (!b || slots < -1) return LBFT_ERR_INVALID;
   b->ql = slots;
@@ -600,8 +635,8 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   u32 bcap = c.block_capacity ? c.block_capacity : (u32)(bauto > 65534 ? 65534 : bauto);
   if (bcap > 65534 || scap > 65535 || n > 255) { g_err = "capacity out of range"; return LBFT_ERR_INVALID; }
   u32 lcap = c.log_capacity ? c.log_capacity : bcap;
-  bool relayout = !(p.qcap == qcap && p.scap == scap && p.bcap == bcap && p.lcap == lcap && b->d_state);
-  p.qcap = qcap; p.scap = scap; p.bcap = bcap; p.lcap = lcap;
+  bool relayout = !(p.qcap == qcap && p.scap == scap && p.bcap == bcap && p.lcap == lcap && p.rcap == b->rcap && b->d_state);
+  p.qcap = qcap; p.scap = scap; p.bcap = bcap; p.lcap = lcap; p.rcap = b->rcap;
   p.max_clock = (i32)max_clock;
   p.max_steps = b->max_steps;
   compute_layout(p);

@@ -95,6 +95,21 @@ def make_config(num_nodes, network_delay, node_config, commands_per_epoch=30000,
     return cfg
 
 
+def write_data_files(path, rows, messages, num_nodes):
+    """DataWriter::write_to_file (bft-lib/src/data_writer.rs:62-97): ``round_switches.txt`` (header ``node i``, one
+    row per round below the highest round reached, empty cells for rounds a node never entered) and
+    ``number_of_messages.txt`` in directory ``path`` (created if missing, as DataWriter::new does)."""
+    import os
+    if not os.path.exists(path):
+        os.mkdir(path)
+    with open(os.path.join(path, "round_switches.txt"), "w") as f:
+        f.write(",".join("node %d" % i for i in range(num_nodes)) + "\n")
+        for row in rows:
+            f.write(",".join("" if v is None else str(v) for v in row) + "\n")
+    with open(os.path.join(path, "number_of_messages.txt"), "w") as f:
+        f.write("%d\n" % messages)
+
+
 class BatchResult:
     """Results of ``BatchSimulator.loop_until`` (lazy device read-back through the C ABI)."""
 
@@ -168,6 +183,18 @@ class BatchResult:
         check(_lib.lib().lbft_batch_committed_history(self._sim._h, instance, node, out.ctypes.data, n, C.byref(ln)))
         return out[:n]
 
+    def round_switches(self, instance=0, cap_rounds=None):
+        """DataWriter output of one instance (bft-lib/src/data_writer.rs): (rows, number_of_messages) where
+        rows[round][node] is the GlobalTime at which the node was first seen in that round or None (empty cell)."""
+        cap = int(cap_rounds or 1 << 16)
+        n = self._sim.num_nodes
+        mr, msgs = C.c_uint64(), C.c_uint64()
+        out = np.full((min(cap, 1 << 16), n), np.iinfo(np.int64).min, dtype=np.int64)
+        check(_lib.lib().lbft_batch_round_switches(self._sim._h, int(instance), out.ctypes.data, out.shape[0], C.byref(mr), C.byref(msgs)))
+        lo = np.iinfo(np.int64).min
+        rows = [[None if v == lo else int(v) for v in out[r]] for r in range(min(int(mr.value), out.shape[0]))]
+        return rows, int(msgs.value)
+
     def contexts(self, instance=0):
         """The ``Vec<&Context>`` that ``Simulator::loop_until`` returns, for one instance."""
         return [SimulatedContextView(self, instance, n) for n in range(self._sim.num_nodes)]
@@ -215,13 +242,20 @@ class BatchSimulator:
     def new(cls, rng_seeds, num_nodes, network_delay, node_config=None, **kw):
         return cls(rng_seeds, num_nodes, network_delay, node_config, **kw)
 
-    def loop_until(self, max_clock, csv_path=None, allow_faults=False):
-        """Simulator::loop_until for every instance.  ``csv_path`` (the reference's round-switch CSV,
-        bft-lib/src/data_writer.rs) is not part of the hot path and must be None."""
-        if csv_path is not None:
-            raise NotImplementedError("the round-switch CSV writer is outside the accelerated hot path (SURVEY.md 8f)")
+    def loop_until(self, max_clock, csv_path=None, allow_faults=False, round_trace=None):
+        """Simulator::loop_until for every instance.  ``csv_path`` is the reference's ``Option<String>`` data-files
+        directory (bft-lib/src/simulator.rs:380-381, data_writer.rs): when given, the round-switch trace is recorded on
+        the device and ``round_switches.txt`` / ``number_of_messages.txt`` of instance 0 are written there in the
+        reference's CSV format.  ``round_trace=N`` only records (N rounds per node) for ``BatchResult.round_switches``."""
+        if csv_path is not None and round_trace is None:
+            round_trace = max(int(max_clock) // 5 + 64, 64)
+        if round_trace:
+            check(_lib.lib().lbft_batch_enable_round_trace(self._h, int(round_trace)))
         check(_lib.lib().lbft_batch_run_until(self._h, int(max_clock)), allow_fault=allow_faults)
-        return BatchResult(self)
+        res = BatchResult(self)
+        if csv_path is not None:
+            write_data_files(csv_path, *res.round_switches(0), self.num_nodes)
+        return res
 
     def manual(self, max_clock=1000):
         """Node-level mode: initial node states only (NodeState::make_initial_state), no event loop.  Returns

@@ -24,6 +24,7 @@ typedef struct lbft_hostmodel_caps {
   uint32_t ql;  // queue slots held in the emulated LDS front (0 = HBM rows only)
   uint32_t qheap;  // 1 = binary-heap event queue (the device's large-network mode)
   uint32_t force_generic;  // 1 = run the step as the run-time-generic class SimT<3> instead of the specialised one
+  uint32_t rcap;           // > 0: round-switch trace (DataWriter) with this many rounds per node
 } lbft_hostmodel_caps;
 
 // Same outputs as lbft_oracle_run_batch, plus per-instance fault words and max queue/snapshot use.
@@ -31,7 +32,8 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
                              size_t n_instances, int64_t max_clock, uint32_t threads, uint32_t* commit_counts,
                              uint64_t* active_rounds, uint64_t* last_states, lbft_oracle_commit* histories,
                              size_t history_cap, lbft_oracle_counters* counters, uint32_t* faults,
-                             uint32_t* maxq_out, uint32_t* maxsnap_out) {
+                             uint32_t* maxq_out, uint32_t* maxsnap_out, int64_t* round_switches /* [inst][rcap][n], INT64_MIN = none */,
+                             uint32_t* max_rounds /* [inst] */) {
   if (cfg->quirks != 0 || cfg->num_nodes > LBFT_MAX_NODES) return -10;
   Params p;
   memset(&p, 0, sizeof(p));
@@ -42,6 +44,7 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   p.max_clock = (i32)max_clock;
   p.ql = caps->ql;
   p.qheap = caps->qheap;
+  p.rcap = caps->rcap;
   p.delay_model = cfg->delay_model;
   p.mu = std::log(cfg->mean / std::sqrt(1.0 + cfg->variance / (cfg->mean * cfg->mean)));
   p.sigma = std::sqrt(std::log(1.0 + cfg->variance / (cfg->mean * cfg->mean)));
@@ -105,6 +108,16 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
     if (s.fault) rc = 1;
     if (maxq_out) maxq_out[i] = s.maxq;
     if (maxsnap_out) maxsnap_out[i] = s.maxsnap;
+    if (p.rcap && round_switches && max_rounds) {
+      u32 mr = 0;
+      for (u32 k = 0; k < p.n; k++) { u32 r = s.ld(p.off_trace + p.n * p.rcap + k); mr = r > mr ? r : mr; }
+      max_rounds[i] = mr;
+      for (u32 r = 0; r < p.rcap; r++)
+        for (u32 k = 0; k < p.n; k++) {
+          u32 t = s.ld(p.off_trace + k * p.rcap + r);
+          round_switches[((size_t)i * p.rcap + r) * p.n + k] = t == 0xffffffffu ? INT64_MIN : (int64_t)(i32)t;
+        }
+    }
     u64 min_round = UINT64_MAX, min_commits = UINT64_MAX;
     for (u32 n = 0; n < p.n; n++) {
       size_t o = i * p.n + n;

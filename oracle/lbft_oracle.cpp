@@ -1118,6 +1118,11 @@ struct lbft_oracle_sim {
   lbft_oracle_counters counters{};
   std::string error;
   std::vector<std::shared_ptr<Notification>> manual_notifications;  // node-level interface
+  // DataWriter (bft-lib/src/data_writer.rs:10-60): first pop time at which each node was seen in each round
+  bool data_writer = false;
+  std::vector<u64> dw_max_round;
+  std::vector<std::vector<std::pair<u64, i64>>> dw_switches;
+  u64 dw_messages = 0;
 
   lbft_oracle_sim(const lbft_oracle_config& c, u64 seed) : cfg(c), rng(seed) {  // Simulator::new :200-250
     rights.assign(c.num_nodes, 1);
@@ -1192,6 +1197,13 @@ struct lbft_oracle_sim {
       Event ev = pending_events.top();
       pending_events.pop();
       if (ev.scheduled_time > max_clock) break;
+      if (data_writer) {  // simulator.rs:393-396 -> data_writer.rs:34-60 (uses the event's own scheduled time)
+        for (size_t k = 0; k < nodes.size(); k++) {
+          u64 r = nodes[k].node.pacemaker.active_round;
+          if (r > dw_max_round[k]) { dw_max_round[k] = r; dw_switches[k].push_back({r, ev.scheduled_time}); }
+        }
+        if (ev.kind != 3) dw_messages++;
+      }
       i64 clk = std::max(ev.scheduled_time, clock);
       clock = clk;
       counters.events[ev.kind]++;
@@ -1339,6 +1351,26 @@ int lbft_oracle_node_view_get(const lbft_oracle_sim* sim, uint32_t node, lbft_or
   out->has_proposed_block = rs.current_proposed_block ? 1 : 0;
   out->has_timeout_certificate = rs.highest_timeout_certificate ? 1 : 0;
   return 0;
+}
+void lbft_oracle_enable_data_writer(lbft_oracle_sim* sim) {
+  sim->data_writer = true;
+  sim->dw_max_round.assign(sim->nodes.size(), 0);
+  sim->dw_switches.assign(sim->nodes.size(), {});
+}
+// round_switches.txt rows (data_writer.rs:62-86): out[round * num_nodes + node] = time or INT64_MIN (None), for
+// round in [0, max_round); returns max_round.  *messages = number_of_messages.txt.
+uint64_t lbft_oracle_round_switches(const lbft_oracle_sim* sim, int64_t* out, size_t cap_rounds, uint64_t* messages) {
+  u64 max_round = 0;
+  for (u64 r : sim->dw_max_round) max_round = std::max(max_round, r);
+  size_t n = sim->nodes.size();
+  for (u64 round = 0; round < max_round && round < cap_rounds; round++)
+    for (size_t k = 0; k < n; k++) {
+      i64 t = INT64_MIN;
+      for (auto& x : sim->dw_switches[k]) if (x.first == round) { t = x.second; break; }
+      out[round * n + k] = t;
+    }
+  if (messages) *messages = sim->dw_messages;
+  return max_round;
 }
 uint64_t lbft_oracle_active_round(const lbft_oracle_sim* sim, uint32_t node) {
   return sim->nodes[node].node.pacemaker.active_round;

@@ -109,6 +109,12 @@ int lbft_oracle_node_create_notification(lbft_oracle_sim* sim, uint32_t node);
 int lbft_oracle_node_handle_notification(lbft_oracle_sim* sim, uint32_t receiver, int handle, uint32_t* should_sync);
 int lbft_oracle_node_view_get(const lbft_oracle_sim* sim, uint32_t node, lbft_oracle_node_view* out);
 
+/* DataWriter of the reference (bft-lib/src/data_writer.rs; `--create_csv`): enable before lbft_oracle_run_until.
+ * lbft_oracle_round_switches fills out[round * num_nodes + node] with the rows of round_switches.txt (INT64_MIN =
+ * empty cell) for round < min(max_round, cap_rounds), returns max_round; *messages = number_of_messages.txt. */
+void lbft_oracle_enable_data_writer(lbft_oracle_sim* sim);
+uint64_t lbft_oracle_round_switches(const lbft_oracle_sim* sim, int64_t* out, size_t cap_rounds, uint64_t* messages);
+
 /* Known-answer helpers for the third-party arithmetic (tests/test_oracle_kat.py). */
 uint64_t lbft_oracle_siphash13(const uint8_t* bytes, size_t n);
 void lbft_oracle_xoshiro_first(uint64_t seed, uint64_t* out, size_t n);

@@ -127,6 +127,10 @@ def lib():
         L.lbft_oracle_node_handle_notification.restype = C.c_int
         L.lbft_oracle_node_view_get.argtypes = [vp, C.c_uint32, C.POINTER(OracleNodeView)]
         L.lbft_oracle_node_view_get.restype = C.c_int
+        L.lbft_oracle_enable_data_writer.argtypes = [vp]
+        L.lbft_oracle_enable_data_writer.restype = None
+        L.lbft_oracle_round_switches.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_uint64)]
+        L.lbft_oracle_round_switches.restype = C.c_uint64
         L.lbft_oracle_siphash13.argtypes = [C.c_char_p, C.c_size_t]
         L.lbft_oracle_siphash13.restype = C.c_uint64
         L.lbft_oracle_xoshiro_first.argtypes = [C.c_uint64, vp, C.c_size_t]
@@ -216,6 +220,19 @@ class OracleSim:
         lib().lbft_oracle_counters_get(self.h, C.byref(c))
         return c.as_dict()
 
+    # ---- DataWriter (bft-lib/src/data_writer.rs) ----
+    def enable_data_writer(self):
+        lib().lbft_oracle_enable_data_writer(self.h)
+        return self
+
+    def round_switches(self, cap_rounds=4096):
+        """(rows, messages): rows[round][node] = time or None, exactly the cells of round_switches.txt."""
+        out = np.full((cap_rounds, self.cfg.num_nodes), np.iinfo(np.int64).min, dtype=np.int64)
+        msgs = C.c_uint64()
+        mr = int(lib().lbft_oracle_round_switches(self.h, out.ctypes.data, cap_rounds, C.byref(msgs)))
+        rows = [[None if v == np.iinfo(np.int64).min else int(v) for v in out[r]] for r in range(min(mr, cap_rounds))]
+        return rows, int(msgs.value)
+
     # ---- node-level interface (the reference's traits on one node; no event loop) ----
     def node_update(self, node, clock):
         a = OracleActions()
@@ -284,7 +301,7 @@ def leader(num_nodes, rnd, weights=None):
 # Host build of the kernel logic (oracle/host_model.cpp) -- CPU-only differential testing.
 # ----------------------------------------------------------------------------------------------
 class HostModelCaps(C.Structure):
-    _fields_ = [("qcap", C.c_uint32), ("scap", C.c_uint32), ("bcap", C.c_uint32), ("lcap", C.c_uint32), ("ql", C.c_uint32), ("qheap", C.c_uint32), ("force_generic", C.c_uint32)]
+    _fields_ = [("qcap", C.c_uint32), ("scap", C.c_uint32), ("bcap", C.c_uint32), ("lcap", C.c_uint32), ("ql", C.c_uint32), ("qheap", C.c_uint32), ("force_generic", C.c_uint32), ("rcap", C.c_uint32)]
 
 
 _hm = None
@@ -301,16 +318,18 @@ def hostmodel_lib():
         vp = C.c_void_p
         L.lbft_hostmodel_run_batch.argtypes = [
             C.POINTER(OracleConfig), C.POINTER(HostModelCaps), vp, C.c_size_t, C.c_int64, C.c_uint32, vp, vp, vp,
-            vp, C.c_size_t, C.POINTER(OracleCounters), vp, vp, vp]
+            vp, C.c_size_t, C.POINTER(OracleCounters), vp, vp, vp, vp, vp]
         L.lbft_hostmodel_run_batch.restype = C.c_int
         _hm = L
     return _hm
 
 
-def hostmodel_run_batch(cfg, seeds, max_clock, threads=1, history_cap=0, qcap=256, scap=128, bcap=256, lcap=256, ql=0, qheap=0, force_generic=0):
+def hostmodel_run_batch(cfg, seeds, max_clock, threads=1, history_cap=0, qcap=256, scap=128, bcap=256, lcap=256, ql=0, qheap=0, force_generic=0, rcap=0):
     seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
     m, nn = len(seeds), cfg.num_nodes
-    caps = HostModelCaps(qcap, scap, bcap, lcap, ql, qheap, force_generic)
+    caps = HostModelCaps(qcap, scap, bcap, lcap, ql, qheap, force_generic, rcap)
+    rs = np.zeros((m, max(rcap, 1), nn), dtype=np.int64)
+    mr = np.zeros(m, dtype=np.uint32)
     commit_counts = np.zeros((m, nn), dtype=np.uint32)
     active_rounds = np.zeros((m, nn), dtype=np.uint64)
     last_states = np.zeros((m, nn), dtype=np.uint64)
@@ -322,8 +341,9 @@ def hostmodel_run_batch(cfg, seeds, max_clock, threads=1, history_cap=0, qcap=25
     rc = hostmodel_lib().lbft_hostmodel_run_batch(
         C.byref(cfg), C.byref(caps), seeds.ctypes.data, m, max_clock, threads, commit_counts.ctypes.data,
         active_rounds.ctypes.data, last_states.ctypes.data, hist.ctypes.data if hist is not None else None,
-        history_cap, C.byref(ctr), faults.ctypes.data, maxq.ctypes.data, maxsnap.ctypes.data)
+        history_cap, C.byref(ctr), faults.ctypes.data, maxq.ctypes.data, maxsnap.ctypes.data, rs.ctypes.data, mr.ctypes.data)
     if rc < 0:
         raise RuntimeError("host model failed: %d" % rc)
     return {"commit_counts": commit_counts, "active_rounds": active_rounds, "last_states": last_states,
-            "histories": hist, "counters": ctr.as_dict(), "faults": faults, "maxq": maxq, "maxsnap": maxsnap}
+            "histories": hist, "counters": ctr.as_dict(), "faults": faults, "maxq": maxq, "maxsnap": maxsnap,
+            "round_switches": rs, "max_rounds": mr}

@@ -223,3 +223,25 @@ def test_full_size_65536x4_properties(amd, oracle):
     assert (states[idx] == ref["last_states"]).all()
     assert (hist[idx] == ref["histories"]).all()
     assert (res.active_rounds[idx] == ref["active_rounds"]).all()
+
+
+def test_round_switch_csv_equals_reference_data_writer(amd, oracle, tmp_path):
+    """`--create_csv` (bft-lib/src/data_writer.rs): device trace == the oracle's DataWriter, and the files have the
+    reference's layout (header `node i`, empty cells, one message count)."""
+    for n, max_clock, kw in ((3, 1000, {}), (4, 2000, {}), (8, 600, {}), (5, 1500, dict(mean=10.0, variance=400.0))):
+        seeds = np.arange(50, 58, dtype=np.uint64)
+        sim = amd.BatchSimulator.new(seeds, n, amd.RandomDelay.new(kw.get("mean", 10.0), kw.get("variance", 4.0)))
+        res = sim.loop_until(max_clock, csv_path=str(tmp_path / ("csv%d" % n)))
+        cfg = oracle.make_config(num_nodes=n, math_mode=1, **kw)
+        for i, seed in enumerate(seeds):
+            o = oracle.OracleSim(cfg, int(seed)).enable_data_writer()
+            o.run_until(max_clock)
+            assert res.round_switches(i) == o.round_switches()
+        lines = (tmp_path / ("csv%d" % n) / "round_switches.txt").read_text().splitlines()
+        rows, messages = res.round_switches(0)
+        assert lines[0] == ",".join("node %d" % k for k in range(n)) and len(lines) == 1 + len(rows)
+        assert lines[1] == "," * (n - 1)  # round 0 is never entered
+        assert (tmp_path / ("csv%d" % n) / "number_of_messages.txt").read_text().strip() == str(messages)
+        # the trace does not change results
+        ref = oracle.run_batch(cfg, seeds, max_clock, threads=4)
+        assert (res.commit_counts == ref["commit_counts"]).all() and (res.last_committed_states == ref["last_states"]).all()

@@ -105,3 +105,26 @@ def test_strict_math_equals_libm_mode(oracle):
     a = oracle.run_batch(oracle.make_config(num_nodes=4, math_mode=0), seeds, 1000, threads=8, history_cap=64)
     b = oracle.run_batch(oracle.make_config(num_nodes=4, math_mode=1), seeds, 1000, threads=8, history_cap=64)
     assert (a["histories"] == b["histories"]).all() and (a["last_states"] == b["last_states"]).all()
+
+
+def round_switch_rows(rs, mr):
+    """rows of round_switches.txt from the [rcap][n] trace: rounds 0 .. max_round - 1, None = empty cell."""
+    lo = np.iinfo(np.int64).min
+    return [[None if v == lo else int(v) for v in rs[r]] for r in range(int(mr))]
+
+
+@pytest.mark.parametrize("n,max_clock", [(3, 1000), (4, 2000), (8, 600), (5, 1500)])
+def test_round_switch_trace_equals_data_writer(oracle, n, max_clock):
+    """DataWriter (bft-lib/src/data_writer.rs): the model examines only the previous event's node and re-checks after a
+    timer that had folded duplicates; the oracle scans every node at every popped event like the reference."""
+    kw = dict(num_nodes=n) if n != 5 else dict(num_nodes=5, mean=10.0, variance=400.0)  # long tail: timeouts, skipped rounds
+    cfg = oracle.make_config(math_mode=1, **kw)
+    seeds = np.arange(50, 58, dtype=np.uint64)
+    b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=4, qcap=4096, scap=64, bcap=512, lcap=512, ql=11, rcap=400)
+    assert not b["faults"].any()
+    for i, seed in enumerate(seeds):
+        sim = oracle.OracleSim(cfg, int(seed)).enable_data_writer()
+        sim.run_until(max_clock)
+        rows, messages = sim.round_switches()
+        assert round_switch_rows(b["round_switches"][i], b["max_rounds"][i]) == rows
+        assert len(rows) > 3
