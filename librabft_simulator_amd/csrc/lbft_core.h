@@ -92,6 +92,14 @@ struct Params {
   unsigned long long* prof;  // LBFT_PHASE_TIMERS builds only: cycles per phase of the event loop, summed over wavefronts
 };
 
+// A wavefront-uniform value that the compiler would otherwise re-read from the kernel-argument segment at every
+// use (s_load + s_waitcnt lgkmcnt(0), which also drains the LDS queue): pin it in a vector register instead.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LBFT_PIN_VGPR(x) asm volatile("" : "+v"(x))
+#else
+#define LBFT_PIN_VGPR(x) do { } while (0)
+#endif
+
 // Phase timers (diagnostic builds: -DLBFT_PHASE_TIMERS): s_memtime deltas accumulated per phase of the
 // event loop, so that one GPU run tells where a wavefront's time goes.  No-ops in product builds.
 #define LBFT_NPHASES 32  // [0..29] phases, [30] wavefront loop iterations, [31] last mark (device scratch) / total cycles (host view)
@@ -348,7 +356,11 @@ struct SimT {
   LBFT_HD SimT(const Params& p, u32* state, u32 i) : SimT(p, reinterpret_cast<char*>(state) + tile_offset_bytes(p, i), (i & 63u) * 4u, 0) {}
   LBFT_HD SimT(const Params& p, char* tile_base, u32 lane_byte_offset, int) : P(p), tile(tile_base), lane4(lane_byte_offset), qk(nullptr), qm(nullptr), qstr(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab),
         leader_lds(nullptr), dur_lds(nullptr), leader_lds_len(0), dur_lds_len(0) {}
-  LBFT_HD void attach_queue(u64* keys, u32* metas, u32 stride, u32 slots) { qk = keys; qm = metas; qstr = stride; ql = slots; }
+  LBFT_HD void attach_queue(u64* keys, u32* metas, u32 stride, u32 slots) {
+    qk = keys; qm = metas; qstr = stride; ql = slots;
+    LBFT_PIN_VGPR(qstr);
+    LBFT_PIN_VGPR(ql);
+  }
   LBFT_HD void attach_tables(const u64* zx, const u64* zf, const u64* et) { zig_x = zx; zig_f = zf; exp_tab = et; }
   LBFT_HD void attach_round_tables(const u8* leaders, u32 nl, const i64* durs, u32 nd) { leader_lds = leaders; leader_lds_len = nl; dur_lds = durs; dur_lds_len = nd; }
 
@@ -1022,8 +1034,10 @@ struct SimT {
     if (nf(node, NF_HC_ROUND) <= after) return;
     // committed_states_after (record_store.rs:557-574): from the grandparent of the commit-certificate
     // block back to the first block whose round is <= `after`
-    u32 start = blk_get(nf(node, NF_HCC_BLK)).pp(), k = 0;
-    for (u32 x = start; x;) {
+    u32 start = blk_get(nf(node, NF_HCC_BLK)).pp(), k = 1;
+    Blk r0 = blk_get(start);  // its round is highest_committed_round > after: at least this block commits
+    // the parent's round is denormalised in the record: the usual single-commit case needs no further lookups
+    for (u32 x = (r0.prev() && r0.prev_round() > after) ? r0.prev() : 0; x;) {
       Blk rx = blk_get(x);
       if (rx.round() <= after) break;
       k++;
@@ -1032,7 +1046,7 @@ struct SimT {
     for (u32 j = k; j-- > 0;) {  // oldest first
       u32 y = start;
       for (u32 s = 0; s < j; s++) y = blk_get(y).prev();
-      Blk ry = blk_get(y);
+      Blk ry = j == 0 ? r0 : blk_get(y);
       // SimulatedContext::commit (simulated_context.rs:160-185)
       if (!bm_test(y, ry, B_PEND, node)) { fault |= F_COMMIT_UNKNOWN_STATE; return; }
       u32 prev = ry.prev();
@@ -1172,10 +1186,18 @@ struct SimT {
       if (pb) insert_block(node, pb);
       LBFT_MARK(22);
       u32 tc_round = sn.w[S_TC_ROUND], to_round = sn.w[S_TO_ROUND];
-      insert_timeouts(node, slot, S_FIXED_WORDS, sn.w[S_TC_MASK], tc_round);
-      for (u32 k = 1; wide() && k < P.mw; k++) insert_timeouts(node, slot, S_FIXED_WORDS, ld(sxw(slot, 0, k)), tc_round, 32 * k);
-      insert_timeouts(node, slot, S_FIXED_WORDS + P.n, sn.w[S_TO_MASK], to_round);
-      for (u32 k = 1; wide() && k < P.mw; k++) insert_timeouts(node, slot, S_FIXED_WORDS + P.n, ld(sxw(slot, 1, k)), to_round, 32 * k);
+      // A timeout whose round is not the receiver's current round is rejected without side effects
+      // (record_store.rs:390-415), and the current round only moves forward while a set is inserted: a set whose
+      // round differs from the current round on entry is skipped as a whole -- which is the common case, because
+      // every notification keeps carrying the sender's last timeout certificate (data_sync.rs:93-96).
+      if (tc_round == nf(node, NF_CUR_ROUND)) {
+        insert_timeouts(node, slot, S_FIXED_WORDS, sn.w[S_TC_MASK], tc_round);
+        for (u32 k = 1; wide() && k < P.mw; k++) insert_timeouts(node, slot, S_FIXED_WORDS, ld(sxw(slot, 0, k)), tc_round, 32 * k);
+      }
+      if (to_round == nf(node, NF_CUR_ROUND)) {
+        insert_timeouts(node, slot, S_FIXED_WORDS + P.n, sn.w[S_TO_MASK], to_round);
+        for (u32 k = 1; wide() && k < P.mw; k++) insert_timeouts(node, slot, S_FIXED_WORDS + P.n, ld(sxw(slot, 1, k)), to_round, 32 * k);
+      }
       LBFT_MARK(23);
       if (vote) insert_vote(node, sender, vote, blk_get(vote));
       LBFT_MARK(24);
@@ -1333,8 +1355,10 @@ struct SimT {
   // ---- Simulator::loop_until (simulator.rs:380-475); returns true when the queue drained ----
   LBFT_HD bool run() {
     u32 steps = 0;
+    u32 max_steps = P.max_steps ? P.max_steps : 0xffffffffu;
+    LBFT_PIN_VGPR(max_steps);
     for (;;) {
-      if (P.max_steps && steps >= P.max_steps) return false;
+      if (steps >= max_steps) return false;
       i32 t; u32 kind, meta;
       if (!pop_event(t, kind, meta)) return true;
       LBFT_MARK(0);
