@@ -57,7 +57,12 @@ typedef struct lbft_config {
   double gamma;                   /* --gamma */
   double lambda;                  /* --lambda */
   uint32_t quirks;                /* must be 0: reference semantics incl. quirks Q1/Q2 */
-  uint32_t reserved;
+  uint32_t equivocate_every;      /* extension, 0 = all honest.  k > 0: every node with index % k == 0 is an equivocating
+                                     leader: (E1) whenever its pacemaker makes it propose (node.rs:191-201) it proposes TWO
+                                     blocks A, B on the same previous QC (two fetches, same NodeTime; B ends up as its current
+                                     proposed block, record_store.rs:466-476); (E2) receivers with an even author index get
+                                     its notifications with A instead of B as proposed_block; (E3) otherwise it follows the
+                                     protocol.  The reference has no Byzantine behaviour; oracle/lbft_oracle.cpp is the spec. */
   const uint64_t* voting_rights;  /* NULL: every node has weight 1 (simulated_context.rs:209-216); else num_nodes weights */
   /* Capacities of the per-instance device structures; 0 = choose from num_nodes / max_clock. */
   uint32_t queue_capacity;    /* pending events with time <= max_clock */

@@ -37,7 +37,7 @@ class LbftConfig(C.Structure):
         ("gamma", C.c_double),
         ("lambda_", C.c_double),
         ("quirks", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("equivocate_every", C.c_uint32),
         ("voting_rights", C.POINTER(C.c_uint64)),
         ("queue_capacity", C.c_uint32),
         ("snapshot_capacity", C.c_uint32),

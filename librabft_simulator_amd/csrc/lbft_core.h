@@ -70,6 +70,7 @@ struct Params {
   u32 mw;              // mask words = ceil(n / 32)
   u32 qheap;           // event queue is a binary heap in the HBM rows (large networks) instead of the LDS-fronted array
   u32 total_votes, quorum;
+  u32 equiv;         // extension: every node with index % equiv == 0 is an equivocating leader (0 = none; include/lbft.h)
   u32 unit_weights;  // every voting right is 1 (the reference's SimulatedContext, simulated_context.rs:209-216)
   u32 dur_len, leader_len;
   const i64* dur_tab;    // dur_tab[k] = (i64)(delta * pow(k, gamma)) computed by the host libm (pacemaker.rs:123)
@@ -314,7 +315,7 @@ struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at
 // ------------------------------------------------------------------------------------------------
 // CLS specialises the step for a network-size class so that the headline small-network path carries none of
 // the large-network machinery:
-//   0  n <= 16, array event queue behind the LDS front, receiver list packed in a register, one mask word
+//   0  n <= 16, all nodes honest, no round-switch trace, array event queue behind the LDS front, receiver list packed in a register, one mask word
 //   1  n <= 32, one mask word; heap / packed list decided at run time
 //   2  n <= 128, multi-word node/author sets (extension rows), heap event queue, receiver list in HBM rows
 //   3  everything decided at run time (init / read-back kernels)
@@ -323,6 +324,7 @@ template <int CLS>
 struct SimT {
   LBFT_HD bool wide() const { return CLS == 2 ? true : (CLS == 3 ? P.n > 32 : false); }
   LBFT_HD bool heap() const { return CLS == 0 ? false : (CLS == 2 ? true : P.qheap != 0); }
+  LBFT_HD bool tracing() const { return CLS != 0 && P.rcap != 0; }  // round-switch trace (DataWriter); class 0 never traces
   LBFT_HD bool packed() const { return CLS == 0 ? true : (CLS == 2 ? false : P.n <= 16); }
   const Params& P;
   char* tile;
@@ -402,7 +404,7 @@ struct SimT {
 #pragma unroll
 #endif
     for (u32 f = 0; f < NF_FIXED_WORDS; f++)
-      if ((cdirty >> f) & 1ULL) stf(nb, f, cw[f]);
+      if ((cdirty >> f) & 1ULL) stf(nb, f, cw[f]);  // (storing all 39 rows unconditionally measured 9 % slower)
   }
   LBFT_HD u32 bfw(u32 b, u32 f) const { return P.off_blk + (b - 1) * P.blk_words + f; }
   LBFT_HD u32 bf(u32 b, u32 f) const { return ld(bfw(b, f)); }   // cold fields (B_TIME, B_CMD) and read-back
@@ -725,6 +727,7 @@ struct SimT {
     if (r == 0) snap_free_slot(slot);
   }
 
+  LBFT_HD bool is_equivocator(u32 node) const { return CLS != 0 && P.equiv != 0 && node % P.equiv == 0; }  // class 0: all honest
   LBFT_HD u32 weight(u32 author) const { return P.unit_weights ? 1u : P.weights[author]; }  // vector load from a small table
 
   // ---- leader / duration ----
@@ -1090,7 +1093,12 @@ struct SimT {
       u32 lvr = nf(node, NF_LVR);
       if (pa.timeout_round > lvr) nfs(node, NF_LVR, pa.timeout_round);
     }
-    if (pa.propose) propose_block(node, pa.propose_prev, lclock);
+    if (pa.propose) {
+      propose_block(node, pa.propose_prev, lclock);
+      // extension (E1): an equivocator proposes a second block B on the same previous QC; B = A + 1 becomes its
+      // current proposed block, so the twin of an equivocator's own proposal is always "proposed block - 1"
+      if (is_equivocator(node)) propose_block(node, pa.propose_prev, lclock);
+    }
     LBFT_MARK(7);
     // vote
     u32 pb = proposed_block(node);
@@ -1120,12 +1128,14 @@ struct SimT {
   }
 
   // ---- DataSyncNode::create_notification (data_sync.rs:82-111) into snapshot slot ----
-  LBFT_HD void write_snapshot(u32 node, u32 slot) const {
+  // `twin`: (E2) the copy for even-indexed receivers of an equivocator's notification carries the twin proposal
+  LBFT_HD void write_snapshot(u32 node, u32 slot, bool twin = false) const {
     st(sfw(slot, S_EPOCH), nf(node, NF_EPOCH));
     // highest_commit_certificate: Q2 makes the previous-epoch lookup return None (base_types.rs:31-37)
     st(sfw(slot, S_CERTS), nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16));
     u32 pb = proposed_block(node);
     if (pb && blk_get(pb).author() != node) pb = 0;  // "Do not reshare other leaders' proposals."
+    if (twin && pb) pb -= 1;
     u32 vote = 0;  // current_vote(local author) (record_store.rs:762-764)
     if (am_test(node, NF_BAL0_AUTHORS, node)) vote = nf(node, NF_BAL0_BLK);
     else if (am_test(node, NF_BAL1_AUTHORS, node)) vote = nf(node, NF_BAL1_BLK);
@@ -1270,7 +1280,7 @@ struct SimT {
         // after its original, hence cancelled), so that event counts and the round-switch trace stay attributed
         // to the right time and queue position.
         u32 dups = nf(node, NF_TIMER_DUPS);
-        if (dups && P.rcap) {
+        if (dups && tracing()) {
           push_event((i64)(i32)nf(node, NF_LAST_TIMER_T), 3, node, 0, dups - 1, nf(node, NF_DUP_STAMP));
           nfs(node, NF_TIMER_DUPS, 0);
         }
@@ -1283,20 +1293,39 @@ struct SimT {
     if (act.broadcast) cnt = peers_all_but(node);
     else if (act.send_to >= 0 && (u32)act.send_to != node) { peers_one((u32)act.send_to); cnt = 1; }
     peers_shuffle(cnt);  // SliceRandom::shuffle
-    i32 slot = -1;
-    u32 refs = 0;
+    i32 slot = -1, slot_twin = -1;
+    u32 refs = 0, refs_twin = 0;
+    bool equivocal = false;
+    if (cnt && is_equivocator(node)) {  // (E2): does this notification carry one of the node's own (double) proposals?
+      u32 pb = proposed_block(node);
+      equivocal = pb != 0 && blk_get(pb).author() == node;
+    }
     for (u32 i = 0; i < cnt; i++) {
       i64 t = (i64)clock + sample_delay();
+      u32 r = peer(i);
+      if (equivocal && (r & 1u) == 0) {
+        if (t <= (i64)P.max_clock && slot_twin == -1) {
+          slot_twin = snap_alloc();
+          if (slot_twin < 0) slot_twin = -2; else write_snapshot(node, (u32)slot_twin, true);
+        }
+        if (slot_twin >= 0) { if (push_event(t, 0, r, node, (u32)slot_twin)) refs_twin++; }
+        else stamp++;
+        continue;
+      }
       if (t <= (i64)P.max_clock && slot == -1) {
         slot = snap_alloc();
         if (slot < 0) slot = -2; else write_snapshot(node, (u32)slot);
       }
-      if (slot >= 0) { if (push_event(t, 0, peer(i), node, (u32)slot)) refs++; }
+      if (slot >= 0) { if (push_event(t, 0, r, node, (u32)slot)) refs++; }
       else stamp++;  // dropped event still consumes a creation stamp
     }
     if (slot >= 0) {
       if (refs) st(P.off_snap_ref + (u32)slot, refs);
       else snap_free_slot((u32)slot);
+    }
+    if (slot_twin >= 0) {
+      if (refs_twin) st(P.off_snap_ref + (u32)slot_twin, refs_twin);
+      else snap_free_slot((u32)slot_twin);
     }
     LBFT_MARK(13);
     if (act.query_all) {
@@ -1364,7 +1393,7 @@ struct SimT {
       LBFT_MARK(0);
       LBFT_COUNT(30);
       steps++;
-      if (P.rcap) trace_round_switch(last_node, t);
+      if (tracing()) trace_round_switch(last_node, t);
       i32 t_event = t;
       if (t > clock) clock = t;
       u32 node = meta & 0xffu, sender = (meta >> 8) & 0xffu, slot = meta >> 16;
@@ -1427,14 +1456,14 @@ struct SimT {
         LBFT_MARK(17);
       }
       // folded duplicate timers of this scheduled time still pop after this timer in the reference
-      if (P.rcap && kind == 3 && (u32)t_event == vd_time && ev_stamp < vd_stamp) trace_round_switch(node, t_event);
+      if (tracing() && kind == 3 && (u32)t_event == vd_time && ev_stamp < vd_stamp) trace_round_switch(node, t_event);
     }
   }
 };
 
 typedef SimT<3> Sim;
 // The class lbft_k_run (and the host model) executes a batch with.
-inline int sim_class(const Params& p) { return p.n > 32 ? 2 : ((p.n <= 16 && !p.qheap) ? 0 : 1); }
+inline int sim_class(const Params& p) { return p.n > 32 ? 2 : ((p.n <= 16 && !p.qheap && !p.equiv && !p.rcap) ? 0 : 1); }
 
 // Row layout for a batch; fills the offset fields of `p` and returns words per instance.
 inline u32 compute_layout(Params& p) {

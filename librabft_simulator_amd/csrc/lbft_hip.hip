@@ -335,6 +335,7 @@ static int fill_params(const lbft_config* cfg, size_t m, Params& p, std::vector<
   p.cpe = cfg->commands_per_epoch;
   p.tci = cfg->target_commit_interval;
   p.lambda = cfg->lambda;
+  p.equiv = cfg->equivocate_every;
   p.total_votes = 0;
   weights.assign(p.n, 1);
   p.unit_weights = 1;

@@ -53,6 +53,7 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   p.cpe = cfg->commands_per_epoch;
   p.tci = cfg->target_commit_interval;
   p.lambda = cfg->lambda;
+  p.equiv = cfg->equivocate_every;
   p.total_votes = 0;
   std::vector<u32> weights(p.n);
   for (u32 i = 0; i < p.n; i++) { weights[i] = cfg->voting_rights ? (u32)cfg->voting_rights[i] : 1; p.total_votes += weights[i]; }

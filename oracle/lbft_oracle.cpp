@@ -916,6 +916,8 @@ struct NodeState {  // node.rs:28-45
   CommitTracker tracker;
   std::map<u64, std::unique_ptr<RecordStore>> past_record_stores;
   u32 quirks = 0;
+  bool equivocator = false;                 // extension, see lbft_oracle.h "Equivocators"
+  std::map<u64, Block> equivocation_twin;   // hash of proposed block B -> its twin A
   u64 response_inserts = 0;
 
   static NodeState make_initial_state(const Context& ctx, const lbft_oracle_config& c, i64 node_time) {  // :87-114
@@ -952,7 +954,17 @@ struct NodeState {  // node.rs:28-45
       record_store->create_timeout(ctx.author, *pa.should_create_timeout, ctx);
       latest_voted_round = std::max(latest_voted_round, *pa.should_create_timeout);
     }
-    if (pa.should_propose_block) record_store->propose_block(ctx, *pa.should_propose_block, clock);
+    if (pa.should_propose_block) {
+      if (equivocator) {  // (E1): A first, then B on the same previous QC
+        record_store->propose_block(ctx, *pa.should_propose_block, clock);
+        std::optional<u64> a = record_store->current_proposed_block;
+        record_store->propose_block(ctx, *pa.should_propose_block, clock);
+        std::optional<u64> b = record_store->current_proposed_block;
+        if (a && b && *a != *b) equivocation_twin[*b] = *record_store->block(*a);
+      } else {
+        record_store->propose_block(ctx, *pa.should_propose_block, clock);
+      }
+    }
     return actions;
   }
   void process_commits(Context& ctx) {  // :313-350
@@ -1026,6 +1038,15 @@ struct NodeState {  // node.rs:28-45
       if (pb->author == ctx.author) n.proposed_block = *record_store->block(pb->hash);
     }
     return n;
+  }
+  // (E2): the copy of `n` that even-indexed receivers get, if `n` carries an equivocal proposal
+  std::optional<Notification> equivocal_copy(const Notification& n) const {
+    if (!equivocator || !n.proposed_block) return std::nullopt;
+    auto it = equivocation_twin.find(n.proposed_block->hash());
+    if (it == equivocation_twin.end()) return std::nullopt;
+    Notification alt = n;
+    alt.proposed_block = it->second;
+    return alt;
   }
   std::optional<Request> handle_notification(Context& ctx, const Notification& n) {  // :113-177
     bool should_sync = false;
@@ -1134,6 +1155,7 @@ struct lbft_oracle_sim {
       // context_factory (main.rs:23-34): SimulatedContext::new + NodeState::make_initial_state(.., NodeTime(0))
       Context context((Author)index, c.num_nodes, c.commands_per_epoch, rights);
       NodeState node = NodeState::make_initial_state(context, c, 0);
+      node.equivocator = c.equivocate_every && index % c.equivocate_every == 0;
       i64 startup_time = clock + network_delay.sample(rng) + 1;
       i64 scheduled_time = 0 + startup_time;  // from_node_time(NodeTime(0), startup)
       Event ev{scheduled_time, event_count++, 3};
@@ -1176,9 +1198,11 @@ struct lbft_oracle_sim {
     }
     rng.shuffle(receivers);
     auto notification = std::make_shared<Notification>(node.node.create_notification(node.context));
+    std::shared_ptr<Notification> alt;
+    if (auto a = node.node.equivocal_copy(*notification)) alt = std::make_shared<Notification>(std::move(*a));
     for (Author r : receivers) {
       Event ev{0, 0, 0};
-      ev.sender = author; ev.receiver = r; ev.notification = notification;
+      ev.sender = author; ev.receiver = r; ev.notification = (alt && r % 2 == 0) ? alt : notification;
       schedule_network_event(ev);
     }
     std::vector<Author> senders;

@@ -35,10 +35,20 @@ typedef struct lbft_oracle_config {
   double gamma;                   /* --gamma */
   double lambda;                  /* --lambda */
   uint32_t quirks;                /* 0 = reference semantics; bit0: route requests to the peer (fixes Q1); bit1: EpochId::previous() = id-1 (fixes Q2) */
+  uint32_t equivocate_every;      /* extension (no reference counterpart): k > 0 makes every node with index % k == 0 an equivocating
+                                     leader, see "Equivocators" below; 0 = all honest */
   uint32_t math_mode;             /* 0 = host libm (what the Rust reference calls); 1 = lbft_math.h (bit-identical to the HIP path) */
   const uint64_t* voting_rights;  /* NULL = all 1 (simulated_context.rs:209-216); else num_nodes weights (extension) */
 } lbft_oracle_config;
 
+/* Equivocators (extension; the reference has no Byzantine behaviour, simulator.rs:25 / data_sync.rs:120-122 only
+ * mention it).  THIS FILE'S IMPLEMENTATION IS THE SPECIFICATION the HIP path is tested against:
+ *  (E1) whenever an equivocator's pacemaker makes it propose (node.rs:191-201) it proposes TWO blocks for the round
+ *       on the same previous QC, A then B (two CommandFetcher::fetch calls, same NodeTime); both enter its own
+ *       record store, where B ends up as current_proposed_block (record_store.rs:466-476);
+ *  (E2) whenever it creates a notification while its proposed block is such a B, receivers with an EVEN author index
+ *       get a copy whose proposed_block is the twin A; nothing else differs;
+ *  (E3) in every other respect (votes, timeouts, QCs) it follows the protocol. */
 typedef struct lbft_oracle_commit {
   uint64_t proposer; /* Command.proposer (simulated_context.rs:31-35) */
   uint64_t index;    /* Command.index */

@@ -27,6 +27,7 @@ class OracleConfig(C.Structure):
         ("gamma", C.c_double),
         ("lambda_", C.c_double),
         ("quirks", C.c_uint32),
+        ("equivocate_every", C.c_uint32),
         ("math_mode", C.c_uint32),
         ("voting_rights", C.POINTER(C.c_uint64)),
     ]
@@ -155,7 +156,7 @@ def lib():
 
 def make_config(num_nodes=3, mean=10.0, variance=4.0, delay_model=0, uniform_lo=5, uniform_hi=15,
                 commands_per_epoch=30000, target_commit_interval=100000, delta=20, gamma=2.0,
-                lambda_=0.5, quirks=0, math_mode=0, voting_rights=None):
+                lambda_=0.5, quirks=0, math_mode=0, voting_rights=None, equivocate_every=0):
     """Defaults = the reference CLI defaults (librabft-v2/src/main.rs:73-140)."""
     cfg = OracleConfig()
     cfg.num_nodes = num_nodes
@@ -171,6 +172,7 @@ def make_config(num_nodes=3, mean=10.0, variance=4.0, delay_model=0, uniform_lo=
     cfg.lambda_ = lambda_
     cfg.quirks = quirks
     cfg.math_mode = math_mode
+    cfg.equivocate_every = equivocate_every
     if voting_rights is not None:
         arr = (C.c_uint64 * num_nodes)(*voting_rights)
         cfg._keepalive = arr

@@ -28,7 +28,7 @@ def run_gpu(amd, kw, seeds, max_clock, **sim_kw):
     nc = amd.NodeConfig(kw.get("target_commit_interval", 100000), kw.get("delta", 20), kw.get("gamma", 2.0),
                         kw.get("lambda_", 0.5))
     sim = amd.BatchSimulator.new(seeds, n, delay, nc, commands_per_epoch=kw.get("commands_per_epoch", 30000),
-                                 voting_rights=kw.get("voting_rights"), **sim_kw)
+                                 voting_rights=kw.get("voting_rights"), equivocate_every=kw.get("equivocate_every", 0), **sim_kw)
     return sim, sim.loop_until(max_clock)
 
 
@@ -76,6 +76,11 @@ CASES = {
     "n100_weighted": (dict(num_nodes=100, voting_rights=[1 + (i % 4) for i in range(100)]), 2, 200),
     "n36_timeouts": (dict(num_nodes=36, mean=10.0, variance=900.0, delta=5), 4, 400),
     "n8_timeouts": (dict(num_nodes=8, mean=10.0, variance=400.0), 64, 1500),
+    # equivocating leaders (extension; oracle/lbft_oracle.h "Equivocators" is the specification) -- config 4's shape
+    "equiv_n4": (dict(num_nodes=4, equivocate_every=4), 256, 1000),
+    "equiv_n7_every_third": (dict(num_nodes=7, equivocate_every=3), 64, 1000),
+    "equiv_n64_long_tail_every_fifth": (dict(num_nodes=64, mean=10.0, variance=400.0, equivocate_every=5), 4, 300),
+    "equiv_n5_weighted_epochs": (dict(num_nodes=5, equivocate_every=2, voting_rights=[1, 3, 1, 2, 2], commands_per_epoch=7), 64, 1500),
     "epoch_change_cpe50": (dict(num_nodes=4, commands_per_epoch=50), 128, 3000),
     "weighted": (dict(num_nodes=5, voting_rights=[5, 1, 1, 2, 3]), 128, 1000),
     "long_tail": (dict(num_nodes=4, mean=10.0, variance=400.0), 256, 2000),

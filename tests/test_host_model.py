@@ -128,3 +128,41 @@ def test_round_switch_trace_equals_data_writer(oracle, n, max_clock):
         rows, messages = sim.round_switches()
         assert round_switch_rows(b["round_switches"][i], b["max_rounds"][i]) == rows
         assert len(rows) > 3
+
+
+# Equivocating leaders (extension; oracle/lbft_oracle.h "Equivocators" is the specification)
+EQUIV = {
+    "n4_one_equivocator": (dict(num_nodes=4, equivocate_every=4), 64, 1000),
+    "n4_all_equivocate": (dict(num_nodes=4, equivocate_every=1), 16, 600),
+    "n7_every_third": (dict(num_nodes=7, equivocate_every=3), 32, 1000),
+    "n16_every_fifth_long_tail": (dict(num_nodes=16, equivocate_every=5, mean=10.0, variance=400.0), 8, 600),
+    "n40_every_fifth": (dict(num_nodes=40, equivocate_every=5), 2, 300),
+    "n5_weighted_epochs": (dict(num_nodes=5, equivocate_every=2, voting_rights=[1, 3, 1, 2, 2], commands_per_epoch=7), 32, 1500),
+}
+
+
+@pytest.mark.parametrize("name", sorted(EQUIV))
+def test_host_model_equivocators(oracle, name):
+    kw, m, max_clock = EQUIV[name]
+    n = kw["num_nodes"]
+    cfg = oracle.make_config(math_mode=1, **kw)
+    seeds = np.arange(300, 300 + m, dtype=np.uint64)
+    a = oracle.run_batch(cfg, seeds, max_clock, threads=8, history_cap=128)
+    b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=8, history_cap=128, qcap=max(4096, 8 * n * n), scap=max(64, 16 * n),
+                                   bcap=1024, lcap=512, ql=13, qheap=1 if n > 4 else 0)
+    assert not b["faults"].any()
+    for key in ("commit_counts", "active_rounds", "last_states", "histories"):
+        assert (a[key] == b[key]).all(), key
+    for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
+        assert a["counters"][key] == b["counters"][key], key
+    # fuzzing property: with fewer than a third of the voting power equivocating, the logs of any two nodes of a
+    # network are prefix-consistent (safety), whatever happens to liveness
+    k = kw["equivocate_every"]
+    rights = kw.get("voting_rights", [1] * n)
+    if 3 * sum(rights[i] for i in range(0, n, k)) < sum(rights):
+        h, cc = a["histories"], a["commit_counts"]
+        for i in range(m):
+            longest = h[i, int(cc[i].argmax())]
+            for node in range(n):
+                c = int(cc[i, node])
+                assert (h[i, node, :min(c, 128)] == longest[:min(c, 128)]).all()
