@@ -1128,6 +1128,25 @@ struct SimT {
   }
 
   // ---- DataSyncNode::create_notification (data_sync.rs:82-111) into snapshot slot ----
+  // hcbr words of the authors in `mask` (author = author0 + bit): node buffer -> snapshot, four loads in flight at a
+  // time (a load-store-load-store chain would be one memory round trip per author)
+  LBFT_HD void copy_hcbr(u32 node, u32 slot, u32 mask, u32 author0, u32 node_word0, u32 snap_word0) const {
+    while (mask) {
+      u32 a[4], h[4], k = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 j = 0; j < 4; j++) {
+        a[j] = 0; h[j] = 0;
+        if (mask) { a[j] = author0 + ctz32(mask); mask &= mask - 1; h[j] = nfm(node, node_word0 + a[j]); k = j + 1; }
+      }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 j = 0; j < 4; j++)
+        if (j < k) st(sfw(slot, snap_word0 + a[j]), h[j]);
+    }
+  }
   // `twin`: (E2) the copy for even-indexed receivers of an equivocator's notification carries the twin proposal
   LBFT_HD void write_snapshot(u32 node, u32 slot, bool twin = false) const {
     st(sfw(slot, S_EPOCH), nf(node, NF_EPOCH));
@@ -1148,14 +1167,14 @@ struct SimT {
     st(sfw(slot, S_TC_MASK), tcm);
     st(sfw(slot, S_TO_MASK), tom);
     u32 tc_sel = nf(node, NF_TC_SEL);
-    for (u32 m = tcm; m;) { u32 a = ctz32(m); m &= m - 1; st(sfw(slot, S_FIXED_WORDS + a), nfm(node, NF_FIXED_WORDS + tc_sel * P.n + a)); }
-    for (u32 m = tom; m;) { u32 a = ctz32(m); m &= m - 1; st(sfw(slot, S_FIXED_WORDS + P.n + a), nfm(node, NF_FIXED_WORDS + (1u - tc_sel) * P.n + a)); }
+    copy_hcbr(node, slot, tcm, 0, NF_FIXED_WORDS + tc_sel * P.n, S_FIXED_WORDS);
+    copy_hcbr(node, slot, tom, 0, NF_FIXED_WORDS + (1u - tc_sel) * P.n, S_FIXED_WORDS + P.n);
     for (u32 k = 1; wide() && k < P.mw; k++) {  // authors >= 32 (n > 32 only): extension words of the two sets + their hcbr entries
       u32 tk = htc ? am_word(node, NF_TC_MASK, k) : 0, ok = am_word(node, NF_TO_MASK, k);
       st(sxw(slot, 0, k), tk);
       st(sxw(slot, 1, k), ok);
-      for (u32 m = tk; m;) { u32 a = 32 * k + ctz32(m); m &= m - 1; st(sfw(slot, S_FIXED_WORDS + a), nfm(node, NF_FIXED_WORDS + tc_sel * P.n + a)); }
-      for (u32 m = ok; m;) { u32 a = 32 * k + ctz32(m); m &= m - 1; st(sfw(slot, S_FIXED_WORDS + P.n + a), nfm(node, NF_FIXED_WORDS + (1u - tc_sel) * P.n + a)); }
+      copy_hcbr(node, slot, tk, 32 * k, NF_FIXED_WORDS + tc_sel * P.n, S_FIXED_WORDS);
+      copy_hcbr(node, slot, ok, 32 * k, NF_FIXED_WORDS + (1u - tc_sel) * P.n, S_FIXED_WORDS + P.n);
     }
   }
 
