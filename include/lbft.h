@@ -148,6 +148,20 @@ int lbft_batch_phase_cycles(const lbft_batch* b, uint64_t* out);
 /* Tuning: how many of a wavefront's 64 lanes carry an instance (0 = auto from the batch size). Results do not depend on it. */
 int lbft_batch_set_lanes_per_wavefront(lbft_batch* b, uint32_t lanes);
 
+/* Stepwise execution and checkpoint / resume.  The reference persists every node after every event (save_node:
+ * bincode of the whole NodeState, node.rs:211-238, simulator.rs:307-309) and reads it back once (load_node,
+ * simulator.rs:221); inside a run that is a semantic no-op, so this library checkpoints at batch granularity instead:
+ * the complete device state (nodes, queues, RNGs, blocks, logs) of all instances.
+ *   lbft_batch_run_steps: first call = Simulator::new for every instance; every call processes at most `steps`
+ *     events per instance (0 = until drained) and reports how many instances still have pending events; when that
+ *     reaches 0 the batch is finished and every read-back call works as after lbft_batch_run_until (same results).
+ *   lbft_batch_checkpoint_save / _load: between two lbft_batch_run_steps calls; load into a batch created with the
+ *     same configuration and seeds count (typically in another process), then keep calling lbft_batch_run_steps. */
+int lbft_batch_run_steps(lbft_batch* b, int64_t max_clock, uint32_t steps, uint64_t* unfinished);
+size_t lbft_batch_checkpoint_bytes(const lbft_batch* b);
+int lbft_batch_checkpoint_save(const lbft_batch* b, void* buf, size_t cap);
+int lbft_batch_checkpoint_load(lbft_batch* b, const void* buf, size_t len);
+
 /* DataWriter of the reference (`--create_csv`; bft-lib/src/data_writer.rs, called per popped event from
  * simulator.rs:393-396): records, per node, the GlobalTime of the first popped event at which the node was seen in
  * each round, and counts the non-timer events.  Enable before lbft_batch_run_until (max_rounds = rows kept per

@@ -307,6 +307,9 @@ struct lbft_batch {
   Params p;
   bool ran = false;
   bool manual = false;  // node-level interface active (lbft_batch_manual_begin)
+  bool started = false; // lbft_batch_run_steps / checkpoint_load: state initialised, event loop not drained yet
+  int64_t started_max_clock = 0;
+  u64 step_launches = 0;
   u32 max_steps = 0;
   u32 lpw = 0;  // 0 = auto
   int ql = -1;  // LDS queue slots per instance; -1 = auto
@@ -320,6 +323,7 @@ struct lbft_batch {
 
 static int prepare_run(lbft_batch* b, int64_t max_clock);
 static int finalize_run(lbft_batch* b, u32 grid_full, u64 launches);
+static int launch_run(lbft_batch* b);
 
 static int fill_params(const lbft_config* cfg, size_t m, Params& p, std::vector<u32>& weights) {
   memset(&p, 0, sizeof(p));
@@ -616,6 +620,8 @@ int lbft_batch_reset(lbft_batch* b) {
   if (!b) return LBFT_ERR_INVALID;
   b->ran = false;
   b->manual = false;
+  b->started = false;
+  b->step_launches = 0;
   return LBFT_OK;
 }
 
@@ -674,30 +680,22 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
 
 int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
   if (!b) return LBFT_ERR_INVALID;
-  if (b->ran) { g_err = "batch already ran; call lbft_batch_reset first"; return LBFT_ERR_STATE; }
+  if (b->ran || b->started) { g_err = "batch already ran (or is being stepped); call lbft_batch_reset first"; return LBFT_ERR_STATE; }
   int prc = prepare_run(b, max_clock);
   if (prc != LBFT_OK) return prc;
   Params& p = b->p;
   u32 lpw = p.lpw;
-  int cls = sim_class(p);
-  const void* run_fn = cls == 0 ? reinterpret_cast<const void*>(lbft_k_run<0>)
-                     : cls == 1 ? reinterpret_cast<const void*>(lbft_k_run<1>) : reinterpret_cast<const void*>(lbft_k_run<2>);
-  HIP_TRY(hipFuncSetAttribute(run_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
   HIP_TRY(hipMemsetAsync(b->d_prof, 0, LBFT_NPHASES * sizeof(unsigned long long), b->stream));
   u32 grid_full = (u32)((b->m + LBFT_BLOCK - 1) / LBFT_BLOCK);
   u32 grid_init = (u32)((b->m + lpw - 1) / lpw);
-  u32 grid_run = (u32)((b->m + (size_t)LBFT_RUN_WAVES * lpw - 1) / ((size_t)LBFT_RUN_WAVES * lpw));
   HIP_TRY(hipEventRecord(b->ev0, b->stream));
   lbft_k_init<<<grid_init, LBFT_BLOCK, 0, b->stream>>>(p, b->d_state, b->d_seeds);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev1, b->stream));
   u64 launches = 0;
   for (;;) {
-    HIP_TRY(hipMemsetAsync(b->d_unfinished, 0, sizeof(u32), b->stream));
-    if (cls == 0) lbft_k_run<0><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
-    else if (cls == 1) lbft_k_run<1><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
-    else lbft_k_run<2><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
-    HIP_TRY(hipGetLastError());
+    int rc = launch_run(b);
+    if (rc != LBFT_OK) return rc;
     launches++;
     if (p.max_steps == 0) break;  // whole simulation in one launch
     u32 unfinished = 0;
@@ -707,6 +705,116 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
   }
   HIP_TRY(hipEventRecord(b->ev2, b->stream));
   return finalize_run(b, grid_full, launches);
+}
+
+static int launch_run(lbft_batch* b) {
+  Params& p = b->p;
+  int cls = sim_class(p);
+  const void* run_fn = cls == 0 ? reinterpret_cast<const void*>(lbft_k_run<0>)
+                     : cls == 1 ? reinterpret_cast<const void*>(lbft_k_run<1>) : reinterpret_cast<const void*>(lbft_k_run<2>);
+  HIP_TRY(hipFuncSetAttribute(run_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
+  u32 grid_run = (u32)((b->m + (size_t)LBFT_RUN_WAVES * p.lpw - 1) / ((size_t)LBFT_RUN_WAVES * p.lpw));
+  HIP_TRY(hipMemsetAsync(b->d_unfinished, 0, sizeof(u32), b->stream));
+  if (cls == 0) lbft_k_run<0><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  else if (cls == 1) lbft_k_run<1><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  else lbft_k_run<2><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  HIP_TRY(hipGetLastError());
+  return LBFT_OK;
+}
+
+// ---- stepwise execution and checkpoint / resume (the reference's save_node / load_node, node.rs:211-238, at batch
+// granularity: the whole SoA state instead of one bincode blob per node per event) ----
+int lbft_batch_run_steps(lbft_batch* b, int64_t max_clock, uint32_t steps, uint64_t* unfinished) {
+  if (!b || !unfinished) return LBFT_ERR_INVALID;
+  if (b->ran || b->manual) { g_err = "batch already ran; call lbft_batch_reset first"; return LBFT_ERR_STATE; }
+  if (!b->started) {
+    int rc = prepare_run(b, max_clock);
+    if (rc != LBFT_OK) return rc;
+    u32 grid_init = (u32)((b->m + b->p.lpw - 1) / b->p.lpw);
+    HIP_TRY(hipEventRecord(b->ev0, b->stream));
+    lbft_k_init<<<grid_init, LBFT_BLOCK, 0, b->stream>>>(b->p, b->d_state, b->d_seeds);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(b->ev1, b->stream));
+    b->started = true;
+    b->started_max_clock = max_clock;
+  } else if (max_clock != b->started_max_clock) {
+    g_err = "max_clock differs from the one this run was started with (events past it were already dropped)";
+    return LBFT_ERR_INVALID;
+  }
+  b->p.max_steps = steps;
+  int rc = launch_run(b);
+  if (rc != LBFT_OK) return rc;
+  b->step_launches++;
+  u32 left = 0;
+  HIP_TRY(hipMemcpyAsync(&left, b->d_unfinished, sizeof(u32), hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  *unfinished = left;
+  if (left == 0) {
+    HIP_TRY(hipEventRecord(b->ev2, b->stream));
+    b->started = false;
+    return finalize_run(b, (u32)((b->m + LBFT_BLOCK - 1) / LBFT_BLOCK), b->step_launches);
+  }
+  return LBFT_OK;
+}
+
+struct CheckpointHeader {
+  char magic[8];  // "LBFTCKP1"
+  u32 n, qcap, scap, bcap, lcap, rcap, total_words, equiv;
+  u64 m, cpe;
+  i64 max_clock, tci, delta, uni_lo, uni_hi;
+  double mean, variance, gamma, lambda;
+  u32 delay_model, weights_hash;
+};
+static u32 weights_hash(const std::vector<u32>& w) {
+  u32 h = 2166136261u;
+  for (u32 v : w) { h ^= v; h *= 16777619u; }
+  return h;
+}
+static void fill_header(const lbft_batch* b, CheckpointHeader& h) {
+  memset(&h, 0, sizeof(h));
+  memcpy(h.magic, "LBFTCKP1", 8);
+  const Params& p = b->p; const lbft_config& c = b->cfg;
+  h.n = p.n; h.qcap = p.qcap; h.scap = p.scap; h.bcap = p.bcap; h.lcap = p.lcap; h.rcap = p.rcap; h.total_words = p.total_words;
+  h.equiv = p.equiv; h.m = b->m; h.cpe = c.commands_per_epoch; h.max_clock = b->started_max_clock; h.tci = c.target_commit_interval;
+  h.delta = c.delta; h.uni_lo = c.uniform_lo; h.uni_hi = c.uniform_hi; h.mean = c.mean; h.variance = c.variance; h.gamma = c.gamma;
+  h.lambda = c.lambda; h.delay_model = c.delay_model; h.weights_hash = weights_hash(b->weights);
+}
+size_t lbft_batch_checkpoint_bytes(const lbft_batch* b) {
+  if (!b || !b->started) return 0;
+  return sizeof(CheckpointHeader) + b->state_bytes;
+}
+int lbft_batch_checkpoint_save(const lbft_batch* b, void* buf, size_t cap) {
+  if (!b || !buf) return LBFT_ERR_INVALID;
+  if (!b->started) { g_err = "nothing to checkpoint: start the run with lbft_batch_run_steps"; return LBFT_ERR_STATE; }
+  if (cap < sizeof(CheckpointHeader) + b->state_bytes) { g_err = "checkpoint buffer too small"; return LBFT_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(b->device));
+  CheckpointHeader h;
+  fill_header(b, h);
+  memcpy(buf, &h, sizeof(h));
+  HIP_TRY(hipMemcpy((char*)buf + sizeof(h), b->d_state, b->state_bytes, hipMemcpyDeviceToHost));
+  return LBFT_OK;
+}
+int lbft_batch_checkpoint_load(lbft_batch* b, const void* buf, size_t len) {
+  if (!b || !buf || len < sizeof(CheckpointHeader)) return LBFT_ERR_INVALID;
+  if (b->ran || b->manual || b->started) { g_err = "load a checkpoint into a fresh (or reset) batch"; return LBFT_ERR_STATE; }
+  CheckpointHeader h;
+  memcpy(&h, buf, sizeof(h));
+  if (memcmp(h.magic, "LBFTCKP1", 8) != 0) { g_err = "not a checkpoint"; return LBFT_ERR_INVALID; }
+  // the batch must have been created with the same configuration; capacities come from the checkpoint
+  b->cfg.queue_capacity = h.qcap; b->cfg.snapshot_capacity = h.scap; b->cfg.block_capacity = h.bcap; b->cfg.log_capacity = h.lcap;
+  b->rcap = h.rcap;
+  int rc = prepare_run(b, h.max_clock);
+  if (rc != LBFT_OK) return rc;
+  b->started_max_clock = h.max_clock;
+  CheckpointHeader mine;
+  fill_header(b, mine);
+  if (memcmp(&mine, &h, sizeof(h)) != 0) { g_err = "checkpoint was taken from a batch with a different configuration"; return LBFT_ERR_INVALID; }
+  if (len != sizeof(h) + b->state_bytes) { g_err = "checkpoint size mismatch"; return LBFT_ERR_INVALID; }
+  HIP_TRY(hipMemcpy(b->d_state, (const char*)buf + sizeof(h), b->state_bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipEventRecord(b->ev0, b->stream));
+  HIP_TRY(hipEventRecord(b->ev1, b->stream));
+  b->started = true;
+  return LBFT_OK;
 }
 
 static int finalize_run(lbft_batch* b, u32 grid_full, u64 launches) {

@@ -258,6 +258,26 @@ class BatchSimulator:
             write_data_files(csv_path, *res.round_switches(0), self.num_nodes)
         return res
 
+    def run_steps(self, max_clock, steps, allow_faults=False):
+        """At most ``steps`` events per instance (first call = Simulator::new).  Returns (unfinished instances, BatchResult
+        or None); the result is available once nothing is left to process."""
+        left = C.c_uint64()
+        check(_lib.lib().lbft_batch_run_steps(self._h, int(max_clock), int(steps), C.byref(left)), allow_fault=allow_faults)
+        return int(left.value), (BatchResult(self) if left.value == 0 else None)
+
+    def save_checkpoint(self, path):
+        """Whole-batch checkpoint (the reference's save_node, node.rs:233-238, at batch granularity)."""
+        nbytes = _lib.lib().lbft_batch_checkpoint_bytes(self._h)
+        buf = np.zeros(nbytes, dtype=np.uint8)
+        check(_lib.lib().lbft_batch_checkpoint_save(self._h, buf.ctypes.data, nbytes))
+        buf.tofile(path)
+        return nbytes
+
+    def load_checkpoint(self, path):
+        """load_node (node.rs:211-231) at batch granularity: into a batch created with the same configuration."""
+        buf = np.fromfile(path, dtype=np.uint8)
+        check(_lib.lib().lbft_batch_checkpoint_load(self._h, buf.ctypes.data, buf.size))
+
     def manual(self, max_clock=1000):
         """Node-level mode: initial node states only (NodeState::make_initial_state), no event loop.  Returns
         ``nodes[instance][author]`` -> NodeHandle."""

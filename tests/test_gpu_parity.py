@@ -250,3 +250,30 @@ def test_round_switch_csv_equals_reference_data_writer(amd, oracle, tmp_path):
         # the trace does not change results
         ref = oracle.run_batch(cfg, seeds, max_clock, threads=4)
         assert (res.commit_counts == ref["commit_counts"]).all() and (res.last_committed_states == ref["last_states"]).all()
+
+
+def test_checkpoint_resume_equals_uninterrupted_run(amd, oracle, tmp_path):
+    """save_node / load_node at batch granularity: step, checkpoint, restore into a NEW batch, continue == one run."""
+    kw, seeds, max_clock = dict(num_nodes=4), np.arange(1, 193, dtype=np.uint64), 1000
+    sim = amd.BatchSimulator.new(seeds, 4, amd.RandomDelay.new(10.0, 4.0))
+    left, res = sim.run_steps(max_clock, 250)
+    assert left == len(seeds) and res is None
+    left, res = sim.run_steps(max_clock, 400)
+    assert left > 0
+    path = str(tmp_path / "batch.ckpt")
+    assert sim.save_checkpoint(path) > 192 * 16000
+    sim.close()
+    sim2 = amd.BatchSimulator.new(np.zeros(len(seeds), dtype=np.uint64), 4, amd.RandomDelay.new(10.0, 4.0))  # seeds live in the state
+    sim2.load_checkpoint(path)
+    launches = 0
+    while True:
+        left, res = sim2.run_steps(max_clock, 300)
+        launches += 1
+        if left == 0:
+            break
+    assert launches >= 2
+    assert_equal_to_oracle(oracle, res, kw, seeds, max_clock)
+    # a checkpoint does not load into a differently configured batch
+    sim3 = amd.BatchSimulator.new(seeds, 5, amd.RandomDelay.new(10.0, 4.0))
+    with pytest.raises(amd.LbftError):
+        sim3.load_checkpoint(path)
