@@ -69,6 +69,14 @@ typedef struct lbft_config {
   uint32_t snapshot_capacity; /* notifications in flight */
   uint32_t block_capacity;    /* blocks proposed per instance (<= 65534) */
   uint32_t log_capacity;      /* commits per node */
+  /* Lossy network (extension; the reference lists network changes / disconnects as TODO, simulator.rs:25; the oracle is
+   * the specification).  Every message Simulator::schedule_network_event would schedule draws its delay as usual, then
+   * (L1) if drop_per_million > 0 one more next_u64() draw d decides: lost iff mulhi64(d, 1000000) < drop_per_million;
+   * (L2) if partition_size > 0 and partition_start <= clock < partition_end, messages between a node < partition_size
+   * and a node >= partition_size are lost.  A lost message consumes its creation stamp and is never queued. */
+  uint32_t drop_per_million;
+  uint32_t partition_size;
+  int64_t partition_start, partition_end;
 } lbft_config;
 
 /* One entry of SimulatedContext::committed_history() (simulated_context.rs:31-35,98-100). */

@@ -43,6 +43,10 @@ class LbftConfig(C.Structure):
         ("snapshot_capacity", C.c_uint32),
         ("block_capacity", C.c_uint32),
         ("log_capacity", C.c_uint32),
+        ("drop_per_million", C.c_uint32),
+        ("partition_size", C.c_uint32),
+        ("partition_start", C.c_int64),
+        ("partition_end", C.c_int64),
     ]
 
 

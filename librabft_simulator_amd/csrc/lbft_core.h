@@ -71,6 +71,8 @@ struct Params {
   u32 qheap;           // event queue is a binary heap in the HBM rows (large networks) instead of the LDS-fronted array
   u32 total_votes, quorum;
   u32 equiv;         // extension: every node with index % equiv == 0 is an equivocating leader (0 = none; include/lbft.h)
+  u32 drop_ppm, part_size;     // extension "lossy network" (include/lbft.h): random loss per million, partition cut
+  i32 part_start, part_end;    // partition active while part_start <= clock < part_end
   u32 unit_weights;  // every voting right is 1 (the reference's SimulatedContext, simulated_context.rs:209-216)
   u32 dur_len, leader_len;
   const i64* dur_tab;    // dur_tab[k] = (i64)(delta * pow(k, gamma)) computed by the host libm (pacemaker.rs:123)
@@ -315,7 +317,7 @@ struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at
 // ------------------------------------------------------------------------------------------------
 // CLS specialises the step for a network-size class so that the headline small-network path carries none of
 // the large-network machinery:
-//   0  n <= 16, all nodes honest, no round-switch trace, array event queue behind the LDS front, receiver list packed in a register, one mask word
+//   0  n <= 16, all nodes honest, lossless network, no round-switch trace, array event queue behind the LDS front, receiver list packed in a register, one mask word
 //   1  n <= 32, one mask word; heap / packed list decided at run time
 //   2  n <= 128, multi-word node/author sets (extension rows), heap event queue, receiver list in HBM rows
 //   3  everything decided at run time (init / read-back kernels)
@@ -727,6 +729,15 @@ struct SimT {
     if (r == 0) snap_free_slot(slot);
   }
 
+  // extension "lossy network": called right after a message's delay draw; true = the message is lost
+  LBFT_HD bool lossy() const { return CLS != 0 && (P.drop_ppm | P.part_size) != 0; }
+  LBFT_HD bool net_lost(u32 a, u32 b) {
+    if (!lossy()) return false;
+    bool lost = false;
+    if (P.drop_ppm) { u64 d = rng.next_u64(); lost = mulhi64(d, 1000000ULL) < (u64)P.drop_ppm; }
+    if (P.part_size && clock >= P.part_start && clock < P.part_end && ((a < P.part_size) != (b < P.part_size))) lost = true;
+    return lost;
+  }
   LBFT_HD bool is_equivocator(u32 node) const { return CLS != 0 && P.equiv != 0 && node % P.equiv == 0; }  // class 0: all honest
   LBFT_HD u32 weight(u32 author) const { return P.unit_weights ? 1u : P.weights[author]; }  // vector load from a small table
 
@@ -1322,6 +1333,7 @@ struct SimT {
     for (u32 i = 0; i < cnt; i++) {
       i64 t = (i64)clock + sample_delay();
       u32 r = peer(i);
+      if (net_lost(node, r)) { stamp++; continue; }  // a lost message still consumes its creation stamp
       if (equivocal && (r & 1u) == 0) {
         if (t <= (i64)P.max_clock && slot_twin == -1) {
           slot_twin = snap_alloc();
@@ -1352,6 +1364,7 @@ struct SimT {
       peers_shuffle(cnt);
       for (u32 i = 0; i < cnt; i++) {
         i64 t = (i64)clock + sample_delay();
+        if (net_lost(node, peer(i))) { stamp++; continue; }
         push_event(t, 1, node, peer(i), 0);
       }
     }
@@ -1455,7 +1468,8 @@ struct SimT {
       } else if (kind == 1) {  // DataSyncRequestEvent (simulator.rs:441-453)
         ev1++;
         // Q1: answered by the requester itself; the response carries nothing insertable
-        push_event((i64)clock + sample_delay(), 2, node, sender, 0);
+        i64 t_resp = (i64)clock + sample_delay();
+        if (net_lost(node, sender)) stamp++; else push_event(t_resp, 2, node, sender, 0);
         do_update = false;
         LBFT_MARK(4);
       } else {  // DataSyncResponseEvent (simulator.rs:454-466): handle_response inserts nothing (Q1)
@@ -1464,7 +1478,10 @@ struct SimT {
       }
       if (do_update) {
         Actions a = node_update(node);
-        if (sync) push_event((i64)clock + sample_delay(), 1, node, sender, 0);
+        if (sync) {
+          i64 t_req = (i64)clock + sample_delay();
+          if (net_lost(node, sender)) stamp++; else push_event(t_req, 1, node, sender, 0);
+        }
         LBFT_MARK(11);
         process_node_actions(node, a);
         LBFT_DRAIN_VMEM();
@@ -1482,7 +1499,7 @@ struct SimT {
 
 typedef SimT<3> Sim;
 // The class lbft_k_run (and the host model) executes a batch with.
-inline int sim_class(const Params& p) { return p.n > 32 ? 2 : ((p.n <= 16 && !p.qheap && !p.equiv && !p.rcap) ? 0 : 1); }
+inline int sim_class(const Params& p) { return p.n > 32 ? 2 : ((p.n <= 16 && !p.qheap && !p.equiv && !p.rcap && !p.drop_ppm && !p.part_size) ? 0 : 1); }
 
 // Row layout for a batch; fills the offset fields of `p` and returns words per instance.
 inline u32 compute_layout(Params& p) {

@@ -340,6 +340,10 @@ static int fill_params(const lbft_config* cfg, size_t m, Params& p, std::vector<
   p.tci = cfg->target_commit_interval;
   p.lambda = cfg->lambda;
   p.equiv = cfg->equivocate_every;
+  p.drop_ppm = cfg->drop_per_million;
+  p.part_size = cfg->partition_size;
+  p.part_start = (i32)(cfg->partition_start < 0 ? 0 : (cfg->partition_start > 0x7fffffff ? 0x7fffffff : cfg->partition_start));
+  p.part_end = (i32)(cfg->partition_end < 0 ? 0 : (cfg->partition_end > 0x7fffffff ? 0x7fffffff : cfg->partition_end));
   p.total_votes = 0;
   weights.assign(p.n, 1);
   p.unit_weights = 1;

@@ -54,6 +54,10 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   p.tci = cfg->target_commit_interval;
   p.lambda = cfg->lambda;
   p.equiv = cfg->equivocate_every;
+  p.drop_ppm = cfg->drop_per_million;
+  p.part_size = cfg->partition_size;
+  p.part_start = (i32)(cfg->partition_start < 0 ? 0 : (cfg->partition_start > 0x7fffffff ? 0x7fffffff : cfg->partition_start));
+  p.part_end = (i32)(cfg->partition_end < 0 ? 0 : (cfg->partition_end > 0x7fffffff ? 0x7fffffff : cfg->partition_end));
   p.total_votes = 0;
   std::vector<u32> weights(p.n);
   for (u32 i = 0; i < p.n; i++) { weights[i] = cfg->voting_rights ? (u32)cfg->voting_rights[i] : 1; p.total_votes += weights[i]; }

@@ -1175,6 +1175,16 @@ struct lbft_oracle_sim {
   }
   void schedule_network_event(Event e) {  // :266-269
     i64 t = clock + network_delay.sample(rng);
+    // extension "Lossy network" (lbft_oracle.h): (L1) random loss, (L2) partition
+    bool lost = false;
+    if (cfg.drop_per_million) {
+      u64 d = rng.next_u64();
+      lost = (u64)(((unsigned __int128)d * 1000000u) >> 64) < cfg.drop_per_million;
+    }
+    if (cfg.partition_size && clock >= cfg.partition_start && clock < cfg.partition_end &&
+        ((e.sender < cfg.partition_size) != (e.receiver < cfg.partition_size)))
+      lost = true;
+    if (lost) { event_count++; return; }
     schedule_event(t, std::move(e));
   }
   NodeUpdateActions node_update(SimNode& n, i64 global_clock) {  // :176-179

@@ -37,6 +37,9 @@ typedef struct lbft_oracle_config {
   uint32_t quirks;                /* 0 = reference semantics; bit0: route requests to the peer (fixes Q1); bit1: EpochId::previous() = id-1 (fixes Q2) */
   uint32_t equivocate_every;      /* extension (no reference counterpart): k > 0 makes every node with index % k == 0 an equivocating
                                      leader, see "Equivocators" below; 0 = all honest */
+  uint32_t drop_per_million;      /* extension, see "Lossy network" below */
+  uint32_t partition_size;        /* extension: nodes [0, partition_size) vs the rest */
+  int64_t partition_start, partition_end; /* extension: GlobalTime interval [start, end) of the partition */
   uint32_t math_mode;             /* 0 = host libm (what the Rust reference calls); 1 = lbft_math.h (bit-identical to the HIP path) */
   const uint64_t* voting_rights;  /* NULL = all 1 (simulated_context.rs:209-216); else num_nodes weights (extension) */
 } lbft_oracle_config;
@@ -49,6 +52,14 @@ typedef struct lbft_oracle_config {
  *  (E2) whenever it creates a notification while its proposed block is such a B, receivers with an EVEN author index
  *       get a copy whose proposed_block is the twin A; nothing else differs;
  *  (E3) in every other respect (votes, timeouts, QCs) it follows the protocol. */
+/* Lossy network (extension; the reference lists "network changes/disconnects" as TODO, simulator.rs:25).
+ * SPECIFICATION: every message that Simulator::schedule_network_event (simulator.rs:266-269) would schedule --
+ * notification, request, response -- first draws its delay as usual, then
+ *  (L1) if drop_per_million > 0: one more next_u64() draw d; the message is lost iff mulhi64(d, 1000000) < drop_per_million;
+ *  (L2) if partition_size > 0 and partition_start <= clock < partition_end (clock = the sending event's time) and the
+ *       two endpoints (Event sender / receiver fields) lie on different sides of the cut {0..partition_size-1} | rest:
+ *       the message is lost;
+ * a lost message still consumes its creation stamp (simulator.rs:252-264) but is never queued. */
 typedef struct lbft_oracle_commit {
   uint64_t proposer; /* Command.proposer (simulated_context.rs:31-35) */
   uint64_t index;    /* Command.index */

@@ -28,6 +28,10 @@ class OracleConfig(C.Structure):
         ("lambda_", C.c_double),
         ("quirks", C.c_uint32),
         ("equivocate_every", C.c_uint32),
+        ("drop_per_million", C.c_uint32),
+        ("partition_size", C.c_uint32),
+        ("partition_start", C.c_int64),
+        ("partition_end", C.c_int64),
         ("math_mode", C.c_uint32),
         ("voting_rights", C.POINTER(C.c_uint64)),
     ]
@@ -156,7 +160,8 @@ def lib():
 
 def make_config(num_nodes=3, mean=10.0, variance=4.0, delay_model=0, uniform_lo=5, uniform_hi=15,
                 commands_per_epoch=30000, target_commit_interval=100000, delta=20, gamma=2.0,
-                lambda_=0.5, quirks=0, math_mode=0, voting_rights=None, equivocate_every=0):
+                lambda_=0.5, quirks=0, math_mode=0, voting_rights=None, equivocate_every=0, drop_per_million=0, partition_size=0,
+                partition_start=0, partition_end=0):
     """Defaults = the reference CLI defaults (librabft-v2/src/main.rs:73-140)."""
     cfg = OracleConfig()
     cfg.num_nodes = num_nodes
@@ -173,6 +178,10 @@ def make_config(num_nodes=3, mean=10.0, variance=4.0, delay_model=0, uniform_lo=
     cfg.quirks = quirks
     cfg.math_mode = math_mode
     cfg.equivocate_every = equivocate_every
+    cfg.drop_per_million = drop_per_million
+    cfg.partition_size = partition_size
+    cfg.partition_start = partition_start
+    cfg.partition_end = partition_end
     if voting_rights is not None:
         arr = (C.c_uint64 * num_nodes)(*voting_rights)
         cfg._keepalive = arr

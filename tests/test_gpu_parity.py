@@ -28,7 +28,10 @@ def run_gpu(amd, kw, seeds, max_clock, **sim_kw):
     nc = amd.NodeConfig(kw.get("target_commit_interval", 100000), kw.get("delta", 20), kw.get("gamma", 2.0),
                         kw.get("lambda_", 0.5))
     sim = amd.BatchSimulator.new(seeds, n, delay, nc, commands_per_epoch=kw.get("commands_per_epoch", 30000),
-                                 voting_rights=kw.get("voting_rights"), equivocate_every=kw.get("equivocate_every", 0), **sim_kw)
+                                 voting_rights=kw.get("voting_rights"), equivocate_every=kw.get("equivocate_every", 0),
+                                 drop_per_million=kw.get("drop_per_million", 0),
+                                 partition=(kw["partition_size"], kw["partition_start"], kw["partition_end"]) if "partition_size" in kw else None,
+                                 **sim_kw)
     return sim, sim.loop_until(max_clock)
 
 
@@ -80,6 +83,11 @@ CASES = {
     "equiv_n4": (dict(num_nodes=4, equivocate_every=4), 256, 1000),
     "equiv_n7_every_third": (dict(num_nodes=7, equivocate_every=3), 64, 1000),
     "equiv_n64_long_tail_every_fifth": (dict(num_nodes=64, mean=10.0, variance=400.0, equivocate_every=5), 4, 300),
+    # lossy network (extension; oracle/lbft_oracle.h "Lossy network"): random loss, partition
+    "lossy_drop_5_percent": (dict(num_nodes=4, drop_per_million=50000), 256, 1500),
+    "lossy_partition_2_2": (dict(num_nodes=4, partition_size=2, partition_start=200, partition_end=700), 128, 1500),
+    "lossy_drop_partition_n40": (dict(num_nodes=40, drop_per_million=20000, partition_size=13, partition_start=50, partition_end=150), 4, 300),
+    "lossy_drop_equivocators_long_tail": (dict(num_nodes=7, drop_per_million=100000, equivocate_every=4, mean=10.0, variance=400.0), 64, 1500),
     "equiv_n5_weighted_epochs": (dict(num_nodes=5, equivocate_every=2, voting_rights=[1, 3, 1, 2, 2], commands_per_epoch=7), 64, 1500),
     "epoch_change_cpe50": (dict(num_nodes=4, commands_per_epoch=50), 128, 3000),
     "weighted": (dict(num_nodes=5, voting_rights=[5, 1, 1, 2, 3]), 128, 1000),

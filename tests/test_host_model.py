@@ -166,3 +166,40 @@ def test_host_model_equivocators(oracle, name):
             for node in range(n):
                 c = int(cc[i, node])
                 assert (h[i, node, :min(c, 128)] == longest[:min(c, 128)]).all()
+
+
+# Lossy network (extension; oracle/lbft_oracle.h "Lossy network" is the specification): random loss and a partition
+LOSSY = {
+    "drop_5_percent": (dict(num_nodes=4, drop_per_million=50000), 64, 1500),
+    "drop_30_percent_n7": (dict(num_nodes=7, drop_per_million=300000), 32, 1500),
+    "partition_2_2": (dict(num_nodes=4, partition_size=2, partition_start=200, partition_end=700), 64, 1500),
+    "partition_minority_n7": (dict(num_nodes=7, partition_size=2, partition_start=100, partition_end=600), 32, 1200),
+    "drop_and_partition_n40": (dict(num_nodes=40, drop_per_million=20000, partition_size=13, partition_start=50, partition_end=150), 2, 300),
+    "drop_equivocators_long_tail": (dict(num_nodes=7, drop_per_million=100000, equivocate_every=4, mean=10.0, variance=400.0), 32, 1500),
+}
+
+
+@pytest.mark.parametrize("name", sorted(LOSSY))
+def test_host_model_lossy_network(oracle, name):
+    kw, m, max_clock = LOSSY[name]
+    n = kw["num_nodes"]
+    cfg = oracle.make_config(math_mode=1, **kw)
+    seeds = np.arange(900, 900 + m, dtype=np.uint64)
+    a = oracle.run_batch(cfg, seeds, max_clock, threads=8, history_cap=128)
+    b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=8, history_cap=128, qcap=max(4096, 8 * n * n), scap=max(64, 16 * n),
+                                   bcap=1024, lcap=512, ql=13, qheap=1 if n > 4 else 0)
+    assert not b["faults"].any()
+    for key in ("commit_counts", "active_rounds", "last_states", "histories"):
+        assert (a[key] == b[key]).all(), key
+    for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
+        assert a["counters"][key] == b["counters"][key], key
+    # safety under message loss: logs stay prefix-consistent
+    h, cc = a["histories"], a["commit_counts"]
+    for i in range(m):
+        longest = h[i, int(cc[i].argmax())]
+        for node in range(n):
+            c = min(int(cc[i, node]), 128)
+            assert (h[i, node, :c] == longest[:c]).all()
+    if name == "partition_2_2":  # no quorum on either side while the cut lasts: commits stall at what was reached before it
+        healthy = oracle.run_batch(oracle.make_config(math_mode=1, num_nodes=4), seeds, max_clock, threads=8)
+        assert a["commit_counts"].max() <= 12 and healthy["commit_counts"].min() >= 40
