@@ -285,3 +285,54 @@ def test_checkpoint_resume_equals_uninterrupted_run(amd, oracle, tmp_path):
     sim3 = amd.BatchSimulator.new(seeds, 5, amd.RandomDelay.new(10.0, 4.0))
     with pytest.raises(amd.LbftError):
         sim3.load_checkpoint(path)
+
+
+def _prefix_consistent(cc, hist):
+    """Safety: within an instance every node's committed log is a prefix of the longest one."""
+    m = cc.shape[0]
+    longest = hist[np.arange(m), cc.argmax(axis=1)]
+    k = np.arange(hist.shape[2])[None, None, :]
+    valid = k < cc[:, :, None]
+    return bool(((hist == longest[:, None, :]) | ~valid).all())
+
+
+def test_full_size_config4_16384x64_equivocators_properties(amd, oracle):
+    """BASELINE.json configs[3]: 16 384 x 64 nodes (f = 21), long-tail delays, every fifth node equivocating.
+    Size-independent properties at full size + bit-exact oracle spot check on a strided subset."""
+    m, n, max_clock = 16384, 64, 300
+    kw = dict(num_nodes=n, mean=10.0, variance=400.0, equivocate_every=5)
+    seeds = np.arange(1, m + 1, dtype=np.uint64)
+    _, res = run_gpu(amd, kw, seeds, max_clock)
+    assert not res.faults.any()
+    cc = res.commit_counts
+    hist = res.committed_histories(max(int(cc.max()), 1))
+    assert _prefix_consistent(cc, hist)                      # 13 < 64/3 equivocators cannot break safety
+    ar = res.active_rounds
+    assert (ar >= 1).all() and (ar.max(axis=1) - ar.min(axis=1) <= ar.max()).all()
+    c = res.counters
+    assert c["events"][1] == c["events"][2] or c["events"][1] >= c["events"][2]  # every processed response had a request
+    idx = np.arange(0, m, 4096)
+    ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds[idx], max_clock, threads=4, history_cap=hist.shape[2])
+    assert (cc[idx] == ref["commit_counts"]).all() and (ar[idx] == ref["active_rounds"]).all()
+    assert (res.last_committed_states[idx] == ref["last_states"]).all() and (hist[idx] == ref["histories"]).all()
+
+
+def test_full_size_config5_8192x100_weighted_epochs_properties(amd, oracle):
+    """BASELINE.json configs[4]: 8 192 x 100 nodes, voting rights 1 + (i mod 4), an epoch every 50 commands
+    (reference semantics incl. quirks Q1/Q2).  Properties at full size + oracle spot check."""
+    m, n, max_clock = 8192, 100, 300
+    rights = [1 + (i % 4) for i in range(n)]
+    kw = dict(num_nodes=n, voting_rights=rights, commands_per_epoch=50)
+    seeds = np.arange(1, m + 1, dtype=np.uint64)
+    _, res = run_gpu(amd, kw, seeds, max_clock)
+    assert not res.faults.any()
+    cc = res.commit_counts
+    hist = res.committed_histories(max(int(cc.max()), 1))
+    assert _prefix_consistent(cc, hist)
+    assert (hist["proposer"][np.arange(hist.shape[2])[None, None, :] < cc[:, :, None]] < n).all()
+    assert (cc.min(axis=1) >= 1).mean() > 0.9               # the healthy weighted network commits
+    assert (res.epochs == 0).all()                           # 50 commands are not reached by clock 300
+    idx = np.arange(0, m, 4096)
+    ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds[idx], max_clock, threads=2, history_cap=hist.shape[2])
+    assert (cc[idx] == ref["commit_counts"]).all() and (res.active_rounds[idx] == ref["active_rounds"]).all()
+    assert (res.last_committed_states[idx] == ref["last_states"]).all() and (hist[idx] == ref["histories"]).all()
