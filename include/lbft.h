@@ -143,13 +143,16 @@ int lbft_batch_last_run_ms(const lbft_batch* b, float* init_ms, float* run_ms);
 size_t lbft_batch_device_bytes(const lbft_batch* b);
 /* Sizes behind the roofline arithmetic (bench.py): out[8] = bytes of one node's rows, of one queued event, of one
  * notification snapshot, of one block record, HBM bytes per instance, LDS-resident queue slots, lanes per wavefront,
- * kernel size class | heap-queue flag << 8. */
+ * kernel size class | heap-queue flag << 8 | calendar-queue flag << 9. */
 int lbft_batch_layout(const lbft_batch* b, uint32_t* out);
 /* Events processed per run-kernel launch (0 = whole simulation in one launch). */
 int lbft_batch_set_max_steps(lbft_batch* b, uint32_t max_steps);
 /* Tuning: event-queue slots per instance kept in LDS by the run kernel (-1 = as many as the CU's 160 KiB
  * afford, 0 = queue in HBM only); slots beyond it spill to HBM.  Results do not depend on it. */
 int lbft_batch_set_lds_queue_slots(lbft_batch* b, int32_t slots);
+/* Tuning / tests: 0 forces the binary-heap event queue where the calendar queue would be used (networks outside kernel
+ * class 0 with max_clock <= 2047).  Results do not depend on it. */
+int lbft_batch_set_calendar_queue(lbft_batch* b, int enabled);
 /* Diagnostic builds (-DLBFT_PHASE_TIMERS) only: out[32] = shader cycles per phase of the event loop summed
  * over wavefronts ([30] = wavefront loop iterations, [31] = total cycles) (see Sim::run); LBFT_ERR_UNSUPPORTED in product builds. */
 int lbft_batch_phase_cycles(const lbft_batch* b, uint64_t* out);

@@ -102,7 +102,7 @@ ABI_SYMBOLS = [
     "lbft_batch_last_committed_states", "lbft_batch_startup_times", "lbft_batch_epochs", "lbft_batch_counters",
     "lbft_batch_faults", "lbft_batch_destroy", "lbft_batch_stream", "lbft_batch_last_run_ms",
     "lbft_batch_device_bytes", "lbft_batch_set_max_steps", "lbft_batch_set_lanes_per_wavefront",
-    "lbft_batch_set_lds_queue_slots", "lbft_batch_phase_cycles", "lbft_batch_layout",
+    "lbft_batch_set_lds_queue_slots", "lbft_batch_set_calendar_queue", "lbft_batch_phase_cycles", "lbft_batch_layout",
     "lbft_batch_run_steps", "lbft_batch_checkpoint_bytes", "lbft_batch_checkpoint_save", "lbft_batch_checkpoint_load",
     "lbft_batch_enable_round_trace", "lbft_batch_round_switches", "lbft_batch_manual_begin", "lbft_batch_manual_finalize", "lbft_node_update", "lbft_node_create_notification",
     "lbft_node_handle_notification", "lbft_node_release_notification", "lbft_node_view_get", "lbft_device_leaders", "lbft_device_sample_delays",
@@ -185,6 +185,8 @@ def lib():
     L.lbft_node_release_notification.restype = C.c_int
     L.lbft_node_view_get.argtypes = [vp, C.c_size_t, C.c_uint32, C.POINTER(LbftNodeView)]
     L.lbft_node_view_get.restype = C.c_int
+    L.lbft_batch_set_calendar_queue.argtypes = [vp, C.c_int]
+    L.lbft_batch_set_calendar_queue.restype = C.c_int
     L.lbft_batch_layout.argtypes = [vp, vp]
     L.lbft_batch_layout.restype = C.c_int
     L.lbft_batch_phase_cycles.argtypes = [vp, vp]

@@ -69,6 +69,8 @@ struct Params {
   const u32* weights;  // voting rights (device table; unit_weights short-cuts it)
   u32 mw;              // mask words = ceil(n / 32)
   u32 qheap;           // event queue is a binary heap in the HBM rows (large networks) instead of the LDS-fronted array
+  u32 qcal;            // event queue is a calendar (one FIFO per (time, kind) bucket) -- needs max_clock <= LBFT_CAL_MAX_CLOCK
+  u32 off_cal_head, off_cal_tail, off_cal_bm, cal_buckets;
   u32 total_votes, quorum;
   u32 equiv;         // extension: every node with index % equiv == 0 is an equivocating leader (0 = none; include/lbft.h)
   u32 drop_ppm, part_size;     // extension "lossy network" (include/lbft.h): random loss per million, partition cut
@@ -131,7 +133,7 @@ struct Params {
 enum InstField : u32 {
   I_CLOCK = 0, I_STAMP, I_RNG0, I_RNG1, I_RNG2, I_RNG3, I_RNG4, I_RNG5, I_RNG6, I_RNG7,
   I_QLEN, I_SNAP_FREE, I_NBLOCKS, I_FAULT, I_EV0, I_EV1, I_EV2, I_EV3, I_DRAWS, I_DONE,
-  I_MAXQ, I_MAXSNAP, I_SNAP_MASK_LO, I_SNAP_MASK_HI, I_LAST_NODE, I_VD_TIME, I_VD_STAMP, I_WORDS
+  I_MAXQ, I_MAXSNAP, I_SNAP_MASK_LO, I_SNAP_MASK_HI, I_LAST_NODE, I_VD_TIME, I_VD_STAMP, I_CAL_CURSOR, I_CAL_FREE, I_CAL_BUMP, I_WORDS
 };
 
 // Node-level rows (RecordStoreState record_store.rs:93-119, PacemakerState pacemaker.rs:60-77,
@@ -169,6 +171,7 @@ enum BlockField : u32 {
 // Snapshot (notification, data_sync.rs:16-39) rows; followed by tc_hcbr[n], to_hcbr[n].
 enum SnapField : u32 { S_EPOCH = 0, S_CERTS /* hcc | hqc << 16 */, S_PROP_VOTE /* proposed | vote << 16 */, S_TC_ROUND, S_TO_ROUND, S_TC_MASK, S_TO_MASK, S_FIXED_WORDS };
 
+#define LBFT_CAL_MAX_CLOCK 2047  // calendar queue: (max_clock + 1) * 4 buckets per instance
 #define LBFT_NO_LEADER 0xffu
 #define LBFT_NEVER INT64_MAX
 
@@ -327,6 +330,7 @@ struct SimT {
   LBFT_HD bool wide() const { return CLS == 2 ? true : (CLS == 3 ? P.n > 32 : false); }
   LBFT_HD bool heap() const { return CLS == 0 ? false : (CLS == 2 ? true : P.qheap != 0); }
   LBFT_HD bool tracing() const { return CLS != 0 && P.rcap != 0; }  // round-switch trace (DataWriter); class 0 never traces
+  LBFT_HD bool cal() const { return CLS != 0 && P.qcal != 0; }
   LBFT_HD bool packed() const { return CLS == 0 ? true : (CLS == 2 ? false : P.n <= 16); }
   const Params& P;
   char* tile;
@@ -335,6 +339,7 @@ struct SimT {
   i32 clock;
   u32 stamp, qlen, snap_free, nblocks, fault, maxq, maxsnap;
   u32 ev_stamp;   // creation stamp of the event being processed
+  u32 cal_cursor, cal_free, cal_bump;  // calendar queue: first possibly non-empty bucket, free-list head (slot + 1), bump allocator
   u32 last_node;  // node of the previous event (round-switch trace)
   // round-switch trace: folded duplicate timers of time vd_time still "pop" in the reference until stamp vd_stamp
   u32 vd_time, vd_stamp;
@@ -534,6 +539,7 @@ struct SimT {
     maxq = ld(I_MAXQ); maxsnap = ld(I_MAXSNAP);
     snap_mask = ld(I_SNAP_MASK_LO) | ((u64)ld(I_SNAP_MASK_HI) << 32);
     last_node = ld(I_LAST_NODE); vd_time = ld(I_VD_TIME); vd_stamp = ld(I_VD_STAMP);
+    cal_cursor = ld(I_CAL_CURSOR); cal_free = ld(I_CAL_FREE); cal_bump = ld(I_CAL_BUMP);
     blk_cache_reset();
   }
   LBFT_HD void store_scalars(bool done) {
@@ -546,6 +552,7 @@ struct SimT {
     st(I_MAXQ, maxq); st(I_MAXSNAP, maxsnap);
     st(I_SNAP_MASK_LO, (u32)snap_mask); st(I_SNAP_MASK_HI, (u32)(snap_mask >> 32));
     st(I_LAST_NODE, last_node); st(I_VD_TIME, vd_time); st(I_VD_STAMP, vd_stamp);
+    st(I_CAL_CURSOR, cal_cursor); st(I_CAL_FREE, cal_free); st(I_CAL_BUMP, cal_bump);
     st(I_DONE, done ? 1u : 0u);
   }
 
@@ -617,7 +624,25 @@ struct SimT {
     if (qlen >= P.qcap) { fault |= F_QUEUE_OVERFLOW; return false; }
     u64 key = ((u64)(u32)time << 32) | ((3u - kind) << 30) | my_stamp;
     u32 meta = node | (sender << 8) | (slot << 16);
-    if (heap()) {  // large networks: binary min-heap in the HBM rows, sift up
+    if (cal()) {
+      // Calendar queue: bucket = (time, kind) in pop order; creation stamps grow with every push, so appending
+      // keeps each bucket sorted by stamp and the key never has to be stored or compared.  O(1), ~1 round trip.
+      u32 idx = (u32)time * 4u + (3u - kind);
+      u32 s1 = cal_free;                      // slot + 1
+      u32 tl = ld(P.off_cal_tail + idx);
+      if (s1) cal_free = ld(P.off_qhi + s1 - 1);
+      else s1 = ++cal_bump;                   // bounded by the qlen < qcap check above
+      st(P.off_qmeta + s1 - 1, meta);
+      st(P.off_qhi + s1 - 1, 0);              // next
+      if (tl) st(P.off_qhi + tl - 1, s1);
+      else {
+        st(P.off_cal_head + idx, s1);
+        u32 bw = P.off_cal_bm + (idx >> 5);
+        st(bw, ld(bw) | (1u << (idx & 31u)));
+      }
+      st(P.off_cal_tail + idx, s1);
+      if (idx < cal_cursor) cal_cursor = idx;
+    } else if (heap()) {  // large networks: binary min-heap in the HBM rows, sift up
       u32 i = qlen;
       while (i > 0) {
         u32 par = (i - 1) >> 1;
@@ -638,6 +663,26 @@ struct SimT {
   // Removes the minimum; returns false when the queue is empty.
   LBFT_HD bool pop_event(i32& time, u32& kind, u32& meta) {
     if (qlen == 0) return false;
+    if (cal()) {  // first non-empty bucket at or after the cursor, head of its FIFO
+      u32 w = cal_cursor >> 5;
+      u32 raw = ld(P.off_cal_bm + w);
+      u32 bits = raw & (~0u << (cal_cursor & 31u));
+      while (!bits) { w++; raw = ld(P.off_cal_bm + w); bits = raw; }
+      u32 idx = w * 32u + ctz32(bits);
+      cal_cursor = idx;
+      u32 s1 = ld(P.off_cal_head + idx);
+      meta = ld(P.off_qmeta + s1 - 1);
+      u32 nx = ld(P.off_qhi + s1 - 1);
+      st(P.off_cal_head + idx, nx);
+      if (!nx) { st(P.off_cal_tail + idx, 0); st(P.off_cal_bm + w, raw & ~(1u << (idx & 31u))); }
+      st(P.off_qhi + s1 - 1, cal_free);       // free-list link
+      cal_free = s1;
+      time = (i32)(idx >> 2);
+      kind = 3u - (idx & 3u);
+      ev_stamp = 0;                           // (only the round trace needs stamps; it runs on the heap queue)
+      qlen--;
+      return true;
+    }
     if (heap()) {  // binary min-heap: take the root, sift the last entry down from the top
       u64 rk; u32 rm;
       q_get(0, rk, rm);
@@ -1380,6 +1425,7 @@ struct SimT {
     snap_free = P.scap;
     snap_mask = P.scap >= 64 ? ~0ULL : ((1ULL << P.scap) - 1);
     last_node = 0; vd_time = 0xffffffffu; vd_stamp = 0;
+    cal_cursor = 0; cal_free = 0; cal_bump = 0;  // (the calendar's head / tail / bitmap rows are zeroed by the host)
     if (P.rcap) {
       for (u32 k = 0; k < P.n * P.rcap; k++) st(P.off_trace + k, 0xffffffffu);
       for (u32 k = 0; k < P.n; k++) st(P.off_trace + P.n * P.rcap + k, 0);
@@ -1507,8 +1553,12 @@ inline u32 compute_layout(Params& p) {
   p.mw = (p.n + 31) / 32;
   p.off_node = w; p.node_words = NF_FIXED_WORDS + 2 * p.n + 4 * (p.mw - 1); w += p.n * p.node_words;
   p.off_qhi = w; w += p.qcap;
-  p.off_qlo = w; w += p.qcap;
+  p.off_qlo = w; w += p.qcal ? 0 : p.qcap;  // the calendar stores no keys
   p.off_qmeta = w; w += p.qcap;
+  p.cal_buckets = p.qcal ? ((u32)p.max_clock + 1u) * 4u : 0;
+  p.off_cal_head = w; w += p.cal_buckets;
+  p.off_cal_tail = w; w += p.cal_buckets;
+  p.off_cal_bm = w; w += (p.cal_buckets + 31) / 32 + (p.qcal ? 1 : 0);
   p.snap_words = S_FIXED_WORDS + 2 * p.n + 2 * (p.mw - 1);
   p.off_snap = w; w += p.scap * p.snap_words;
   p.off_snap_ref = w; w += p.scap;

@@ -307,6 +307,7 @@ struct lbft_batch {
   Params p;
   bool ran = false;
   bool manual = false;  // node-level interface active (lbft_batch_manual_begin)
+  bool allow_calendar = true;  // tuning / test knob: 0 forces the heap queue where the calendar would be used
   bool started = false; // lbft_batch_run_steps / checkpoint_load: state initialised, event loop not drained yet
   int64_t started_max_clock = 0;
   u64 step_launches = 0;
@@ -324,6 +325,7 @@ struct lbft_batch {
 static int prepare_run(lbft_batch* b, int64_t max_clock);
 static int finalize_run(lbft_batch* b, u32 grid_full, u64 launches);
 static int launch_run(lbft_batch* b);
+static int zero_calendar(lbft_batch* b);
 
 static int fill_params(const lbft_config* cfg, size_t m, Params& p, std::vector<u32>& weights) {
   memset(&p, 0, sizeof(p));
@@ -478,6 +480,7 @@ int lbft_batch_manual_begin(lbft_batch* b, int64_t max_clock) {
   int rc = prepare_run(b, max_clock);
   if (rc != LBFT_OK) return rc;
   u32 grid_init = (u32)((b->m + b->p.lpw - 1) / b->p.lpw);
+  { int zrc = zero_calendar(b); if (zrc != LBFT_OK) return zrc; }
   lbft_k_init<<<grid_init, LBFT_BLOCK, 0, b->stream>>>(b->p, b->d_state, b->d_seeds);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(b->stream));
@@ -586,6 +589,12 @@ int lbft_batch_round_switches(const lbft_batch* b, size_t inst, int64_t* out, si
   return LBFT_OK;
 }
 
+int lbft_batch_set_calendar_queue(lbft_batch* b, int enabled) {
+  if (!b) return LBFT_ERR_INVALID;
+  b->allow_calendar = enabled != 0;
+  return LBFT_OK;
+}
+
 int lbft_batch_set_lds_queue_slots(lbft_batch* b, int32_t slots) {
   if (!b || slots < -1) return LBFT_ERR_INVALID;
   b->ql = slots;
@@ -616,7 +625,7 @@ int lbft_batch_layout(const lbft_batch* b, uint32_t* out) {
   out[4] = p.total_words * 4; // HBM bytes per instance
   out[5] = p.ql;              // event-queue slots per instance resident in LDS
   out[6] = p.lpw;             // lanes per wavefront carrying an instance
-  out[7] = (uint32_t)sim_class(p) | (p.qheap << 8);
+  out[7] = (uint32_t)sim_class(p) | (p.qheap << 8) | (p.qcal << 9);
   return LBFT_OK;
 }
 
@@ -626,6 +635,18 @@ int lbft_batch_reset(lbft_batch* b) {
   b->manual = false;
   b->started = false;
   b->step_launches = 0;
+  return LBFT_OK;
+}
+
+// The calendar queue's head / tail / bitmap rows must be zero when Simulator::new runs: they are one contiguous
+// range of rows in every 64-instance tile.
+static int zero_calendar(lbft_batch* b) {
+  const Params& p = b->p;
+  if (!p.qcal) return LBFT_OK;
+  size_t rows = (size_t)p.off_snap - p.off_cal_head;  // head, tail, bitmap
+  size_t tiles = p.stride / 64;
+  HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(b->d_state) + (size_t)p.off_cal_head * LBFT_ROW_BYTES, (size_t)p.total_words * LBFT_ROW_BYTES, 0,
+                           rows * LBFT_ROW_BYTES, tiles, b->stream));
   return LBFT_OK;
 }
 
@@ -646,8 +667,16 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   u32 bcap = c.block_capacity ? c.block_capacity : (u32)(bauto > 65534 ? 65534 : bauto);
   if (bcap > 65534 || scap > 65535 || n > 255) { g_err = "capacity out of range"; return LBFT_ERR_INVALID; }
   u32 lcap = c.log_capacity ? c.log_capacity : bcap;
-  bool relayout = !(p.qcap == qcap && p.scap == scap && p.bcap == bcap && p.lcap == lcap && p.rcap == b->rcap && b->d_state);
-  p.qcap = qcap; p.scap = scap; p.bcap = bcap; p.lcap = lcap; p.rcap = b->rcap;
+  // Queue discipline: 4-node honest lossless networks scan an LDS-resident array (kernel class 0); everything else keeps
+  // hundreds to tens of thousands of pending events and uses a calendar of (time, kind) FIFOs when max_clock allows it
+  // (O(1) push and pop), otherwise a binary heap whose top levels are the LDS-resident slots.
+  bool big = qcap > 256 || n > 32;
+  u32 qheap = big ? 1u : 0u;
+  bool class0 = n <= 16 && !qheap && !p.equiv && !b->rcap && !p.drop_ppm && !p.part_size;
+  u32 qcal = (!class0 && !b->rcap && b->allow_calendar && max_clock <= LBFT_CAL_MAX_CLOCK) ? 1u : 0u;
+  bool relayout = !(p.qcap == qcap && p.scap == scap && p.bcap == bcap && p.lcap == lcap && p.rcap == b->rcap && p.qcal == qcal &&
+                    p.max_clock == (i32)max_clock && b->d_state);
+  p.qcap = qcap; p.scap = scap; p.bcap = bcap; p.lcap = lcap; p.rcap = b->rcap; p.qcal = qcal; p.qheap = qheap;
   p.max_clock = (i32)max_clock;
   p.max_steps = b->max_steps;
   compute_layout(p);
@@ -672,11 +701,9 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   u32 ql_auto = (u32)((budget - run_lds_bytes(0, lpw) - 1024) / (12u * LBFT_RUN_WAVES * lpw));  // 1 KiB slack: allocation granularity
   u32 ql = b->ql < 0 ? ql_auto : (u32)b->ql;
   if (ql > qcap) ql = qcap;
+  if (p.qcal) ql = 0;  // the calendar lives in HBM rows
   if (run_lds_bytes(ql, lpw) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
   p.ql = ql;
-  // networks above 4 nodes keep hundreds to tens of thousands of pending events: binary heap (its top levels
-  // are the LDS-resident slots) instead of the linear scan
-  p.qheap = (qcap > 256 || n > 32) ? 1u : 0u;
   b->lds_bytes = run_lds_bytes(ql, lpw);
   p.prof = b->d_prof;
   return LBFT_OK;
@@ -693,6 +720,7 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
   u32 grid_full = (u32)((b->m + LBFT_BLOCK - 1) / LBFT_BLOCK);
   u32 grid_init = (u32)((b->m + lpw - 1) / lpw);
   HIP_TRY(hipEventRecord(b->ev0, b->stream));
+  { int zrc = zero_calendar(b); if (zrc != LBFT_OK) return zrc; }
   lbft_k_init<<<grid_init, LBFT_BLOCK, 0, b->stream>>>(p, b->d_state, b->d_seeds);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev1, b->stream));
@@ -736,6 +764,7 @@ int lbft_batch_run_steps(lbft_batch* b, int64_t max_clock, uint32_t steps, uint6
     if (rc != LBFT_OK) return rc;
     u32 grid_init = (u32)((b->m + b->p.lpw - 1) / b->p.lpw);
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
+    { int zrc = zero_calendar(b); if (zrc != LBFT_OK) return zrc; }
     lbft_k_init<<<grid_init, LBFT_BLOCK, 0, b->stream>>>(b->p, b->d_state, b->d_seeds);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev1, b->stream));

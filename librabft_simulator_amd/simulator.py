@@ -225,7 +225,8 @@ class BatchSimulator:
 
     def __init__(self, rng_seeds, num_nodes, network_delay, node_config=None, commands_per_epoch=30000,
                  voting_rights=None, device=0, queue_capacity=0, snapshot_capacity=0, block_capacity=0,
-                 log_capacity=0, max_steps_per_launch=0, lanes_per_wavefront=0, lds_queue_slots=-1, equivocate_every=0, drop_per_million=0, partition=None):
+                 log_capacity=0, max_steps_per_launch=0, lanes_per_wavefront=0, lds_queue_slots=-1, equivocate_every=0, drop_per_million=0, partition=None,
+                 calendar_queue=True):
         seeds = np.ascontiguousarray(rng_seeds, dtype=np.uint64)
         self.seeds = seeds
         self.num_instances = int(seeds.shape[0])
@@ -240,6 +241,8 @@ class BatchSimulator:
             check(_lib.lib().lbft_batch_set_max_steps(self._h, max_steps_per_launch))
         if lanes_per_wavefront:
             check(_lib.lib().lbft_batch_set_lanes_per_wavefront(self._h, lanes_per_wavefront))
+        if not calendar_queue:
+            check(_lib.lib().lbft_batch_set_calendar_queue(self._h, 0))
         if lds_queue_slots != -1:
             check(_lib.lib().lbft_batch_set_lds_queue_slots(self._h, lds_queue_slots))
 

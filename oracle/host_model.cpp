@@ -25,6 +25,7 @@ typedef struct lbft_hostmodel_caps {
   uint32_t qheap;  // 1 = binary-heap event queue (the device's large-network mode)
   uint32_t force_generic;  // 1 = run the step as the run-time-generic class SimT<3> instead of the specialised one
   uint32_t rcap;           // > 0: round-switch trace (DataWriter) with this many rounds per node
+  uint32_t qcal;           // 1 = calendar event queue (needs max_clock <= LBFT_CAL_MAX_CLOCK and a class >= 1 kernel)
 } lbft_hostmodel_caps;
 
 // Same outputs as lbft_oracle_run_batch, plus per-instance fault words and max queue/snapshot use.
@@ -45,6 +46,8 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   p.ql = caps->ql;
   p.qheap = caps->qheap;
   p.rcap = caps->rcap;
+  p.qcal = caps->qcal;
+  if (p.qcal) { if (max_clock > LBFT_CAL_MAX_CLOCK || p.rcap) return -11; p.qheap = 1; p.ql = 0; }
   p.delay_model = cfg->delay_model;
   p.mu = std::log(cfg->mean / std::sqrt(1.0 + cfg->variance / (cfg->mean * cfg->mean)));
   p.sigma = std::sqrt(std::log(1.0 + cfg->variance / (cfg->mean * cfg->mean)));

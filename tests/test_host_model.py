@@ -60,15 +60,17 @@ LARGE = {
 }
 
 
+# qcal = 1: calendar event queue (one FIFO per (time, kind) bucket) instead of the binary heap
+@pytest.mark.parametrize("qcal", [0, 1])
 @pytest.mark.parametrize("name", sorted(LARGE))
-def test_host_model_large_networks(oracle, name):
+def test_host_model_large_networks(oracle, name, qcal):
     kw, m, max_clock, qheap = LARGE[name]
     cfg = oracle.make_config(math_mode=1, **kw)
     n = kw["num_nodes"]
     seeds = np.arange(7, 7 + m, dtype=np.uint64) * 31337
     a = oracle.run_batch(cfg, seeds, max_clock, threads=8, history_cap=128)
     b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=8, history_cap=128, qcap=max(4096, 8 * n * n), scap=16 * n,
-                                   bcap=512, lcap=512, ql=7 if n in (8, 40) else 0, qheap=qheap)
+                                   bcap=512, lcap=512, ql=7 if n in (8, 40) else 0, qheap=qheap, qcal=qcal)
     assert not b["faults"].any()
     for key in ("commit_counts", "active_rounds", "last_states", "histories"):
         assert (a[key] == b[key]).all(), key
@@ -141,15 +143,16 @@ EQUIV = {
 }
 
 
+@pytest.mark.parametrize("qcal", [0, 1])
 @pytest.mark.parametrize("name", sorted(EQUIV))
-def test_host_model_equivocators(oracle, name):
+def test_host_model_equivocators(oracle, name, qcal):
     kw, m, max_clock = EQUIV[name]
     n = kw["num_nodes"]
     cfg = oracle.make_config(math_mode=1, **kw)
     seeds = np.arange(300, 300 + m, dtype=np.uint64)
     a = oracle.run_batch(cfg, seeds, max_clock, threads=8, history_cap=128)
     b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=8, history_cap=128, qcap=max(4096, 8 * n * n), scap=max(64, 16 * n),
-                                   bcap=1024, lcap=512, ql=13, qheap=1 if n > 4 else 0)
+                                   bcap=1024, lcap=512, ql=13, qheap=1 if n > 4 else 0, qcal=qcal)
     assert not b["faults"].any()
     for key in ("commit_counts", "active_rounds", "last_states", "histories"):
         assert (a[key] == b[key]).all(), key
@@ -179,15 +182,16 @@ LOSSY = {
 }
 
 
+@pytest.mark.parametrize("qcal", [0, 1])
 @pytest.mark.parametrize("name", sorted(LOSSY))
-def test_host_model_lossy_network(oracle, name):
+def test_host_model_lossy_network(oracle, name, qcal):
     kw, m, max_clock = LOSSY[name]
     n = kw["num_nodes"]
     cfg = oracle.make_config(math_mode=1, **kw)
     seeds = np.arange(900, 900 + m, dtype=np.uint64)
     a = oracle.run_batch(cfg, seeds, max_clock, threads=8, history_cap=128)
     b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=8, history_cap=128, qcap=max(4096, 8 * n * n), scap=max(64, 16 * n),
-                                   bcap=1024, lcap=512, ql=13, qheap=1 if n > 4 else 0)
+                                   bcap=1024, lcap=512, ql=13, qheap=1 if n > 4 else 0, qcal=qcal)
     assert not b["faults"].any()
     for key in ("commit_counts", "active_rounds", "last_states", "histories"):
         assert (a[key] == b[key]).all(), key
