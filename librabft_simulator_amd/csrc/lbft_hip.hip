@@ -691,7 +691,7 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   u32 lpw = b->lpw;
   if (lpw == 0) {
     u64 want = (b->m + 1023) / 1024;  // 256 CUs x 4 SIMDs
-    lpw = want <= 16 ? 16 : (want <= 32 ? 32 : 64);
+    lpw = want <= 8 ? 8 : (want <= 16 ? 16 : (want <= 32 ? 32 : 64));  // measured: 8192 x 100 nodes 9.0 s at 16 lanes, 5.9 s at 8, 7.8 s at 4
   }
   p.lpw = lpw;
   // LDS queue slots per instance: what one CU's LDS affords when it hosts 64/lpw workgroups

@@ -21,7 +21,7 @@ CONFIGS = {
 }
 
 
-def run(name, scale=1.0, reps=1):
+def run(name, scale=1.0, reps=1, lpw=0):
     import numpy as np
     from librabft_simulator_amd import BatchSimulator, NodeConfig, RandomDelay
     c = CONFIGS[name]
@@ -29,7 +29,7 @@ def run(name, scale=1.0, reps=1):
     seeds = np.arange(1, m + 1, dtype=np.uint64)
     delay = RandomDelay.uniform(*c["uniform"]) if "uniform" in c else RandomDelay.new(10.0, c.get("variance", 4.0))
     sim = BatchSimulator.new(seeds, c["nodes"], delay, NodeConfig(), commands_per_epoch=c.get("commands_per_epoch", 30000),
-                             voting_rights=c.get("weights"), equivocate_every=c.get("equivocate_every", 0))
+                             voting_rights=c.get("weights"), equivocate_every=c.get("equivocate_every", 0), lanes_per_wavefront=lpw)
     best = None
     for _ in range(reps):
         sim.reset()
@@ -50,6 +50,7 @@ if __name__ == "__main__":
     ap.add_argument("names", nargs="*", default=list(CONFIGS))
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the configuration's instance count")
     ap.add_argument("--reps", type=int, default=1)
+    ap.add_argument("--lpw", type=int, default=0, help="lanes per wavefront carrying an instance (0 = auto)")
     a = ap.parse_args()
     for n in a.names:
-        run(n, a.scale, a.reps)
+        run(n, a.scale, a.reps, a.lpw)
