@@ -22,7 +22,7 @@ extern "C" {
 #define LBFT_OK 0
 #define LBFT_ERR_INVALID (-1)     /* bad argument (NULL pointer, num_nodes out of range, max_clock >= 2^31-1, ...) */
 #define LBFT_ERR_HIP (-2)         /* HIP runtime error / no device; see lbft_last_error() */
-#define LBFT_ERR_UNSUPPORTED (-3) /* quirks != 0 or num_nodes > LBFT_MAX_NODES_SUPPORTED on this kernel family */
+#define LBFT_ERR_UNSUPPORTED (-3) /* quirks bit 0 or num_nodes > LBFT_MAX_NODES_SUPPORTED on this kernel family */
 #define LBFT_ERR_STATE (-4)       /* call order violated (e.g. results requested before lbft_batch_run_until) */
 #define LBFT_ERR_FAULT (-5)       /* the run finished but >= 1 instance raised a sticky fault (capacity overflow or an
                                      invariant on which the reference itself would have panicked); see lbft_batch_faults */
@@ -56,7 +56,10 @@ typedef struct lbft_config {
   int64_t delta;                  /* --delta */
   double gamma;                   /* --gamma */
   double lambda;                  /* --lambda */
-  uint32_t quirks;                /* must be 0: reference semantics incl. quirks Q1/Q2 */
+  uint32_t quirks;                /* 0: reference semantics incl. quirks Q1/Q2.  Bit 1 (value 2): EpochId::previous()
+                                     returns id - 1 as intended (fixes Q2, base_types.rs:31-37): notifications forward the previous epoch's
+                                     commit certificate (data_sync.rs:84-92), which keeps a network live across epoch changes.  Bit 0
+                                     (requests answered by the peer, fixes Q1) is not implemented: LBFT_ERR_UNSUPPORTED. */
   uint32_t equivocate_every;      /* extension, 0 = all honest.  k > 0: every node with index % k == 0 is an equivocating
                                      leader: (E1) whenever its pacemaker makes it propose (node.rs:191-201) it proposes TWO
                                      blocks A, B on the same previous QC (two fetches, same NodeTime; B ends up as its current

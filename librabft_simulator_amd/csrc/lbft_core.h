@@ -73,6 +73,7 @@ struct Params {
   u32 off_cal_head, off_cal_tail, off_cal_bm, cal_buckets;
   u32 total_votes, quorum;
   u32 equiv;         // extension: every node with index % equiv == 0 is an equivocating leader (0 = none; include/lbft.h)
+  u32 quirks;                  // bit 1: EpochId::previous() = id - 1 (fixes reference quirk Q2, base_types.rs:31-37); bit 0 unsupported
   u32 drop_ppm, part_size;     // extension "lossy network" (include/lbft.h): random loss per million, partition cut
   i32 part_start, part_end;    // partition active while part_start <= clock < part_end
   u32 unit_weights;  // every voting right is 1 (the reference's SimulatedContext, simulated_context.rs:209-216)
@@ -149,6 +150,7 @@ enum NodeField : u32 {
   NF_NEXT_CMD, NF_LAST_COMMITTED_BLK, NF_NCOMMITS,
   NF_LAST_TIMER_T, NF_TIMER_DUPS,  // duplicate-timer folding (see process_node_actions)
   NF_DUP_STAMP,  // creation stamp of the most recently folded duplicate timer (round-switch trace)
+  NF_PREV_EPOCH_HCC,  // commit-certificate block of the previous epoch's record store (quirks bit 1: Q2 fixed)
   NF_TC_SEL,  // which of the two hcbr[n] buffers holds the timeout certificate (the other: current timeouts)
   NF_FIXED_WORDS  // followed by hcbr[2][n]: highest_certified_block_round per timeout author
 };
@@ -1123,6 +1125,7 @@ struct SimT {
         u64 new_epoch = (u64)ry.depth() / P.cpe;
         // fresh RecordStoreState for the new epoch (node.rs:331-348, record_store.rs:169-198)
         nfs(node, NF_EPOCH, (u32)new_epoch);
+        nfs(node, NF_PREV_EPOCH_HCC, nf(node, NF_HCC_BLK));  // the store being retired keeps its commit certificate (node.rs:331-348)
         nfs(node, NF_INIT_STATE_BLK, y);
         nfs(node, NF_PROPOSED_BLK, 0);
         nfs(node, NF_HQC_ROUND, 0); nfs(node, NF_HQC_BLK, 0); nfs(node, NF_HTC_ROUND, 0);
@@ -1206,8 +1209,12 @@ struct SimT {
   // `twin`: (E2) the copy for even-indexed receivers of an equivocator's notification carries the twin proposal
   LBFT_HD void write_snapshot(u32 node, u32 slot, bool twin = false) const {
     st(sfw(slot, S_EPOCH), nf(node, NF_EPOCH));
-    // highest_commit_certificate: Q2 makes the previous-epoch lookup return None (base_types.rs:31-37)
-    st(sfw(slot, S_CERTS), nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16));
+    // highest_commit_certificate (data_sync.rs:84-92): the current store's, else the previous epoch's store's.
+    // Reference quirk Q2: EpochId::previous() returns the SAME epoch (base_types.rs:31-37), so that lookup finds
+    // the current store again and yields None; quirks bit 1 makes it id - 1 as intended.
+    u32 hcc = nf(node, NF_HCC_BLK);
+    if (!hcc && (P.quirks & 2u) && nf(node, NF_EPOCH) != 0) hcc = nf(node, NF_PREV_EPOCH_HCC);
+    st(sfw(slot, S_CERTS), hcc | (nf(node, NF_HQC_BLK) << 16));
     u32 pb = proposed_block(node);
     if (pb && blk_get(pb).author() != node) pb = 0;  // "Do not reshare other leaders' proposals."
     if (twin && pb) pb -= 1;

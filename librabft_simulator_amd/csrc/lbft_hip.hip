@@ -342,6 +342,7 @@ static int fill_params(const lbft_config* cfg, size_t m, Params& p, std::vector<
   p.tci = cfg->target_commit_interval;
   p.lambda = cfg->lambda;
   p.equiv = cfg->equivocate_every;
+  p.quirks = cfg->quirks;
   p.drop_ppm = cfg->drop_per_million;
   p.part_size = cfg->partition_size;
   p.part_start = (i32)(cfg->partition_start < 0 ? 0 : (cfg->partition_start > 0x7fffffff ? 0x7fffffff : cfg->partition_start));
@@ -366,7 +367,7 @@ static int validate(const lbft_config* cfg) {
   if (!cfg) return LBFT_ERR_INVALID;
   if (cfg->num_nodes == 0) return LBFT_ERR_INVALID;
   if (cfg->num_nodes > LBFT_MAX_NODES_SUPPORTED) return LBFT_ERR_UNSUPPORTED;
-  if (cfg->quirks != 0) return LBFT_ERR_UNSUPPORTED;
+  if ((cfg->quirks & ~2u) != 0) return LBFT_ERR_UNSUPPORTED;  // bit 1 (Q2 fixed) is implemented; bit 0 (Q1 fixed: real request/response payloads) is not
   if (cfg->delay_model > 1) return LBFT_ERR_INVALID;
   if (cfg->delay_model == 0 && !(cfg->mean > 0.0 && cfg->variance >= 0.0)) return LBFT_ERR_INVALID;
   if (cfg->delay_model == 1 && !(cfg->uniform_lo >= 0 && cfg->uniform_hi >= cfg->uniform_lo)) return LBFT_ERR_INVALID;

@@ -35,7 +35,7 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
                              size_t history_cap, lbft_oracle_counters* counters, uint32_t* faults,
                              uint32_t* maxq_out, uint32_t* maxsnap_out, int64_t* round_switches /* [inst][rcap][n], INT64_MIN = none */,
                              uint32_t* max_rounds /* [inst] */) {
-  if (cfg->quirks != 0 || cfg->num_nodes > LBFT_MAX_NODES) return -10;
+  if ((cfg->quirks & ~2u) != 0 || cfg->num_nodes > LBFT_MAX_NODES) return -10;  // bit 1 (Q2 fixed) is implemented, bit 0 (Q1) is not
   Params p;
   memset(&p, 0, sizeof(p));
   p.n = cfg->num_nodes;
@@ -57,6 +57,7 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   p.tci = cfg->target_commit_interval;
   p.lambda = cfg->lambda;
   p.equiv = cfg->equivocate_every;
+  p.quirks = cfg->quirks;
   p.drop_ppm = cfg->drop_per_million;
   p.part_size = cfg->partition_size;
   p.part_start = (i32)(cfg->partition_start < 0 ? 0 : (cfg->partition_start > 0x7fffffff ? 0x7fffffff : cfg->partition_start));

@@ -29,7 +29,7 @@ def run_gpu(amd, kw, seeds, max_clock, **sim_kw):
                         kw.get("lambda_", 0.5))
     sim = amd.BatchSimulator.new(seeds, n, delay, nc, commands_per_epoch=kw.get("commands_per_epoch", 30000),
                                  voting_rights=kw.get("voting_rights"), equivocate_every=kw.get("equivocate_every", 0),
-                                 drop_per_million=kw.get("drop_per_million", 0),
+                                 drop_per_million=kw.get("drop_per_million", 0), quirks=kw.get("quirks", 0),
                                  partition=(kw["partition_size"], kw["partition_start"], kw["partition_end"]) if "partition_size" in kw else None,
                                  **sim_kw)
     return sim, sim.loop_until(max_clock)
@@ -88,6 +88,10 @@ CASES = {
     "lossy_partition_2_2": (dict(num_nodes=4, partition_size=2, partition_start=200, partition_end=700), 128, 1500),
     "lossy_drop_partition_n40": (dict(num_nodes=40, drop_per_million=20000, partition_size=13, partition_start=50, partition_end=150), 4, 300),
     "lossy_drop_equivocators_long_tail": (dict(num_nodes=7, drop_per_million=100000, equivocate_every=4, mean=10.0, variance=400.0), 64, 1500),
+    # quirks bit 1: EpochId::previous() = id - 1 (reference quirk Q2 fixed): epoch changes do not stall the network
+    "q2fixed_n4_cpe50": (dict(num_nodes=4, commands_per_epoch=50, quirks=2), 128, 3000),
+    "q2fixed_n7_weighted_cpe9": (dict(num_nodes=7, commands_per_epoch=9, quirks=2, voting_rights=[2, 1, 1, 3, 1, 2, 1]), 64, 2000),
+    "q2fixed_n36_cpe3": (dict(num_nodes=36, commands_per_epoch=3, quirks=2), 4, 300),
     "equiv_n5_weighted_epochs": (dict(num_nodes=5, equivocate_every=2, voting_rights=[1, 3, 1, 2, 2], commands_per_epoch=7), 64, 1500),
     "epoch_change_cpe50": (dict(num_nodes=4, commands_per_epoch=50), 128, 3000),
     "weighted": (dict(num_nodes=5, voting_rights=[5, 1, 1, 2, 3]), 128, 1000),

@@ -207,3 +207,33 @@ def test_host_model_lossy_network(oracle, name, qcal):
     if name == "partition_2_2":  # no quorum on either side while the cut lasts: commits stall at what was reached before it
         healthy = oracle.run_batch(oracle.make_config(math_mode=1, num_nodes=4), seeds, max_clock, threads=8)
         assert a["commit_counts"].max() <= 12 and healthy["commit_counts"].min() >= 40
+
+
+# quirks bit 1: EpochId::previous() = id - 1 (reference quirk Q2 fixed): epoch changes no longer stall the network
+Q2 = {
+    "n4_cpe50": (dict(num_nodes=4, commands_per_epoch=50, quirks=2), 64, 3000),
+    "n3_cpe5": (dict(num_nodes=3, commands_per_epoch=5, quirks=2), 64, 1500),
+    "n7_weighted_cpe9": (dict(num_nodes=7, commands_per_epoch=9, quirks=2, voting_rights=[2, 1, 1, 3, 1, 2, 1]), 32, 2000),
+    "n36_cpe3": (dict(num_nodes=36, commands_per_epoch=3, quirks=2), 2, 300),
+}
+
+
+@pytest.mark.parametrize("name", sorted(Q2))
+def test_host_model_q2_fixed(oracle, name):
+    kw, m, max_clock = Q2[name]
+    n = kw["num_nodes"]
+    cfg = oracle.make_config(math_mode=1, **kw)
+    seeds = np.arange(3, 3 + m, dtype=np.uint64)
+    a = oracle.run_batch(cfg, seeds, max_clock, threads=8, history_cap=256)
+    b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=8, history_cap=256, qcap=max(4096, 8 * n * n), scap=max(64, 16 * n),
+                                   bcap=1024, lcap=1024, ql=13, qheap=1 if n > 4 else 0, qcal=1 if n > 4 and max_clock <= 2047 else 0)
+    assert not b["faults"].any()
+    for key in ("commit_counts", "active_rounds", "last_states", "histories"):
+        assert (a[key] == b[key]).all(), key
+    for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
+        assert a["counters"][key] == b["counters"][key], key
+    if name == "n4_cpe50":
+        # under reference semantics this network stalls at [50, 50, 49, 49]; with previous() fixed it stays live
+        stalled = oracle.run_batch(oracle.make_config(math_mode=1, num_nodes=4, commands_per_epoch=50), seeds, max_clock, threads=8)
+        assert stalled["commit_counts"].max() <= 50
+        assert (a["commit_counts"].min(axis=1) >= 90).all()

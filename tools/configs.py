@@ -18,6 +18,9 @@ CONFIGS = {
     "c4_16384x64_longtail_equivocators": dict(instances=16384, nodes=64, max_clock=300, variance=400.0, equivocate_every=5),
     "c5_8192x100_weighted_epochs": dict(instances=8192, nodes=100, max_clock=300, weights=[1 + (i % 4) for i in range(100)],
                                         commands_per_epoch=50),
+    # same with quirk Q2 fixed and a horizon long enough to cross epochs (the reference semantics stall at the first change)
+    "c5b_1024x100_weighted_epochs_q2fixed": dict(instances=1024, nodes=100, max_clock=2000, weights=[1 + (i % 4) for i in range(100)],
+                                                 commands_per_epoch=50, quirks=2),
 }
 
 
@@ -29,7 +32,7 @@ def run(name, scale=1.0, reps=1, lpw=0):
     seeds = np.arange(1, m + 1, dtype=np.uint64)
     delay = RandomDelay.uniform(*c["uniform"]) if "uniform" in c else RandomDelay.new(10.0, c.get("variance", 4.0))
     sim = BatchSimulator.new(seeds, c["nodes"], delay, NodeConfig(), commands_per_epoch=c.get("commands_per_epoch", 30000),
-                             voting_rights=c.get("weights"), equivocate_every=c.get("equivocate_every", 0), lanes_per_wavefront=lpw)
+                             voting_rights=c.get("weights"), equivocate_every=c.get("equivocate_every", 0), lanes_per_wavefront=lpw, quirks=c.get("quirks", 0))
     best = None
     for _ in range(reps):
         sim.reset()
