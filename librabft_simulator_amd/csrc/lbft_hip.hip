@@ -692,14 +692,17 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   u32 lpw = b->lpw;
   if (lpw == 0) {
     u64 want = (b->m + 1023) / 1024;  // 256 CUs x 4 SIMDs
-    lpw = want <= 8 ? 8 : (want <= 16 ? 16 : (want <= 32 ? 32 : 64));  // measured: 8192 x 100 nodes 9.0 s at 16 lanes, 5.9 s at 8, 7.8 s at 4
+    // measured: 8192 x 100 nodes 9.0 s at 16 lanes, 5.9 s at 8, 7.8 s at 4; 65536 x 4 nodes 40.0 ms at 64 lanes (one wavefront
+    // per SIMD), 36.5 ms at 32 (two per SIMD, which the 227-VGPR kernel still allows), 57 ms at 16 (would need four)
+    lpw = want <= 8 ? 8 : (want <= 16 ? 16 : 32);
   }
   p.lpw = lpw;
   // LDS queue slots per instance: what one CU's LDS affords when it hosts 64/lpw workgroups
   u32 wg_per_cu = 64 / lpw ? 64 / lpw : 1;
   if (wg_per_cu > 4) wg_per_cu = 4;
   size_t budget = (160u * 1024u) / wg_per_cu;
-  u32 ql_auto = (u32)((budget - run_lds_bytes(0, lpw) - 1024) / (12u * LBFT_RUN_WAVES * lpw));  // 1 KiB slack: allocation granularity
+  // 2 KiB slack per workgroup: with less, two workgroups of 32-lane wavefronts do not become co-resident on a CU
+  u32 ql_auto = (u32)((budget - run_lds_bytes(0, lpw) - 2048) / (12u * LBFT_RUN_WAVES * lpw));
   u32 ql = b->ql < 0 ? ql_auto : (u32)b->ql;
   if (ql > qcap) ql = qcap;
   if (p.qcal) ql = 0;  // the calendar lives in HBM rows
