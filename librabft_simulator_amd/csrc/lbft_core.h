@@ -167,7 +167,7 @@ enum BlockField : u32 {
   B_TIME = BC_WORDS, B_CMD, B_WORDS
 };
 #ifndef LBFT_BLK_CACHE
-#define LBFT_BLK_CACHE 6  // register-resident block records per instance (FIFO)
+#define LBFT_BLK_CACHE 4  // register-resident block records per instance (second-chance FIFO); measured at two wavefronts/SIMD: 3 -> 35.7 ms, 4 -> 35.0, 5 -> 35.6, 6 -> 36.6
 #endif
 
 // Snapshot (notification, data_sync.rs:16-39) rows; followed by tc_hcbr[n], to_hcbr[n].
