@@ -1,0 +1,92 @@
+"""Randomised differential test (seeded, CPU-only): the kernel logic compiled for the host (every size class, queue
+discipline and extension) against the full-fidelity oracle on configurations drawn at random -- node counts, voting
+rights, delay models, pacemaker parameters, epoch lengths, equivocators, message loss, partitions, Q2 on/off."""
+import numpy as np
+import pytest
+
+
+def draw_config(rng):
+    n = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 6, 7, 8, 9, 12, 16, 17, 24, 33, 40]))
+    kw = dict(num_nodes=n)
+    if rng.random() < 0.3:
+        kw.update(delay_model=1, uniform_lo=int(rng.integers(0, 8)), uniform_hi=int(rng.integers(8, 30)))
+    else:
+        mean = float(rng.choice([3.0, 10.0, 10.0, 25.0]))
+        kw.update(mean=mean, variance=float(rng.choice([0.0, 4.0, 4.0, 100.0, 400.0])))
+    if rng.random() < 0.4:
+        kw["voting_rights"] = [int(v) for v in rng.integers(1, 6, n)]
+    if rng.random() < 0.4:
+        kw["commands_per_epoch"] = int(rng.choice([3, 7, 20, 50]))
+    if rng.random() < 0.5:
+        # (lambda * delta >= 2: a query period of 0 makes every update query all peers and the event population explode)
+        kw.update(delta=int(rng.choice([5, 10, 20, 40])), gamma=float(rng.choice([1.0, 1.5, 2.0])), lambda_=float(rng.choice([0.5, 1.0])))
+    if rng.random() < 0.3:
+        kw["target_commit_interval"] = int(rng.choice([50, 200, 100000]))
+    if rng.random() < 0.3 and n >= 2:
+        kw["equivocate_every"] = int(rng.integers(1, n + 1))
+    if rng.random() < 0.3:
+        kw["drop_per_million"] = int(rng.choice([1000, 50000, 300000]))
+    if rng.random() < 0.25 and n >= 2:
+        start = int(rng.integers(0, 300))
+        kw.update(partition_size=int(rng.integers(1, n)), partition_start=start, partition_end=start + int(rng.integers(50, 400)))
+    if rng.random() < 0.3:
+        kw["quirks"] = 2
+    return kw
+
+
+@pytest.mark.parametrize("chunk", range(12))
+def test_random_configurations_match_the_oracle(oracle, chunk):
+    rng = np.random.default_rng(20240 + chunk)
+    for _ in range(16):
+        kw = draw_config(rng)
+        n = kw["num_nodes"]
+        max_clock = int(rng.choice([300, 600, 1000])) if n <= 16 else 250
+        m = 6 if n <= 16 else 2
+        seeds = rng.integers(1, 2 ** 62, m, dtype=np.uint64)
+        cfg = oracle.make_config(math_mode=1, **kw)
+        a = oracle.run_batch(cfg, seeds, max_clock, threads=4, history_cap=96)
+        special = any(k in kw for k in ("equivocate_every", "drop_per_million", "partition_size"))
+        big = n > 4
+        qheap = 1 if (big or rng.random() < 0.3) else 0
+        qcal = 1 if (rng.random() < 0.5 and (qheap or special or n > 16)) else 0
+        b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=4, history_cap=96, qcap=max(4096, 24 * n * n), scap=max(64, 32 * n),
+                                       bcap=1024, lcap=1024, ql=int(rng.choice([0, 3, 11, 48])), qheap=qheap, qcal=qcal,
+                                       force_generic=int(rng.random() < 0.2))
+        assert not b["faults"].any(), kw
+        for key in ("commit_counts", "active_rounds", "last_states", "histories"):
+            assert (a[key] == b[key]).all(), (key, kw)
+        for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
+            assert a["counters"][key] == b["counters"][key], (key, kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", range(4))
+def test_random_configurations_on_the_device_match_the_oracle(oracle, chunk):
+    import librabft_simulator_amd as amd
+    rng = np.random.default_rng(777 + chunk)
+    for _ in range(10):
+        kw = draw_config(rng)
+        n = kw["num_nodes"]
+        max_clock = int(rng.choice([300, 600, 1000, 2500])) if n <= 16 else 250
+        m = int(rng.choice([3, 40, 70])) if n <= 16 else 3
+        seeds = rng.integers(1, 2 ** 62, m, dtype=np.uint64)
+        ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds, max_clock, threads=8, history_cap=96)
+        delay = amd.RandomDelay.uniform(kw["uniform_lo"], kw["uniform_hi"]) if kw.get("delay_model") == 1 else \
+            amd.RandomDelay.new(kw.get("mean", 10.0), kw.get("variance", 4.0))
+        nc = amd.NodeConfig(kw.get("target_commit_interval", 100000), kw.get("delta", 20), kw.get("gamma", 2.0), kw.get("lambda_", 0.5))
+        part = (kw["partition_size"], kw["partition_start"], kw["partition_end"]) if "partition_size" in kw else None
+        sim = amd.BatchSimulator.new(seeds, n, delay, nc, commands_per_epoch=kw.get("commands_per_epoch", 30000),
+                                     voting_rights=kw.get("voting_rights"), equivocate_every=kw.get("equivocate_every", 0),
+                                     drop_per_million=kw.get("drop_per_million", 0), partition=part, quirks=kw.get("quirks", 0),
+                                     calendar_queue=bool(rng.random() < 0.7), max_steps_per_launch=int(rng.choice([0, 0, 173])),
+                                     lanes_per_wavefront=int(rng.choice([0, 8, 64])), block_capacity=max_clock + 64,
+                                     queue_capacity=max(4096, 64 * n * n), snapshot_capacity=max(64, 32 * n))
+        res = sim.loop_until(max_clock, allow_faults=True)
+        assert not res.faults.any(), (kw, sorted(set(int(f) for f in res.faults)), res.counters, sim.layout())
+        assert (res.commit_counts == ref["commit_counts"]).all(), kw
+        assert (res.active_rounds == ref["active_rounds"]).all(), kw
+        assert (res.last_committed_states == ref["last_states"]).all(), kw
+        assert (res.committed_histories(96) == ref["histories"]).all(), kw
+        c, rc = res.counters, ref["counters"]
+        for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
+            assert c[key] == rc[key], (key, kw)
