@@ -22,7 +22,7 @@ extern "C" {
 #define LBFT_OK 0
 #define LBFT_ERR_INVALID (-1)     /* bad argument (NULL pointer, num_nodes out of range, max_clock >= 2^31-1, ...) */
 #define LBFT_ERR_HIP (-2)         /* HIP runtime error / no device; see lbft_last_error() */
-#define LBFT_ERR_UNSUPPORTED (-3) /* quirks bit 0 or num_nodes > LBFT_MAX_NODES_SUPPORTED on this kernel family */
+#define LBFT_ERR_UNSUPPORTED (-3) /* unknown quirks bits or num_nodes > LBFT_MAX_NODES_SUPPORTED on this kernel family */
 #define LBFT_ERR_STATE (-4)       /* call order violated (e.g. results requested before lbft_batch_run_until) */
 #define LBFT_ERR_FAULT (-5)       /* the run finished but >= 1 instance raised a sticky fault (capacity overflow or an
                                      invariant on which the reference itself would have panicked); see lbft_batch_faults */
@@ -41,6 +41,7 @@ extern "C" {
 #define LBFT_FAULT_STAMP_OVERFLOW (1u << 8)
 #define LBFT_FAULT_INTERNAL (1u << 9)
 #define LBFT_FAULT_TRACE_OVERFLOW (1u << 11)
+#define LBFT_FAULT_EPOCH_OVERFLOW (1u << 12) /* quirks bit 0: record-store archive / response scratch exhausted */
 
 /* Simulation parameters: the arguments of Simulator::new (bft-lib/src/simulator.rs:200-208),
  * RandomDelay::new (:99-106), SimulatedContext::new (bft-lib/src/simulated_context.rs:86-96) and
@@ -59,7 +60,10 @@ typedef struct lbft_config {
   uint32_t quirks;                /* 0: reference semantics incl. quirks Q1/Q2.  Bit 1 (value 2): EpochId::previous()
                                      returns id - 1 as intended (fixes Q2, base_types.rs:31-37): notifications forward the previous epoch's
                                      commit certificate (data_sync.rs:84-92), which keeps a network live across epoch changes.  Bit 0
-                                     (requests answered by the peer, fixes Q1) is not implemented: LBFT_ERR_UNSUPPORTED. */
+                                     (value 1): a DataSyncRequest is answered by the peer it was sent to, as bft-driver does
+                                     (bft-driver/src/core.rs:174-178), instead of by the requester itself (fixes Q1, simulator.rs:446):
+                                     responses carry the records the requester lacks (record_store.rs:766-831) and lagging nodes catch
+                                     up.  3 = both.  The oracle implements the same modes. */
   uint32_t equivocate_every;      /* extension, 0 = all honest.  k > 0: every node with index % k == 0 is an equivocating
                                      leader: (E1) whenever its pacemaker makes it propose (node.rs:191-201) it proposes TWO
                                      blocks A, B on the same previous QC (two fetches, same NodeTime; B ends up as its current

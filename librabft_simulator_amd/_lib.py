@@ -19,7 +19,7 @@ LBFT_ERR_FAULT = -5
 FAULT_NAMES = {
     1 << 0: "queue_overflow", 1 << 1: "snapshot_overflow", 1 << 2: "block_overflow", 1 << 3: "log_overflow",
     1 << 4: "ballot_overflow", 1 << 5: "duration_table", 1 << 6: "commit_unknown_state",
-    1 << 7: "commit_not_successor", 1 << 8: "stamp_overflow", 1 << 9: "internal", 1 << 11: "trace_overflow",
+    1 << 7: "commit_not_successor", 1 << 8: "stamp_overflow", 1 << 9: "internal", 1 << 11: "trace_overflow", 1 << 12: "epoch_overflow",
 }
 
 

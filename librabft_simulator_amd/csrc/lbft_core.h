@@ -49,7 +49,8 @@ enum Fault : u32 {
   F_STAMP_OVERFLOW = 1u << 8,
   F_INTERNAL = 1u << 9,
   F_STEP_LIMIT = 1u << 10,
-  F_TRACE_OVERFLOW = 1u << 11,  // a node went past round_trace_capacity (round-switch trace only)
+  F_TRACE_OVERFLOW = 1u << 11,
+  F_EPOCH_OVERFLOW = 1u << 12,  // quirks bit 0 only: more epochs than epoch_archive capacity / sync list overflow  // a node went past round_trace_capacity (round-switch trace only)
 };
 
 // Batch-uniform parameters (kernel argument).
@@ -90,6 +91,8 @@ struct Params {
   u32 off_blk, blk_words;
   u32 off_log;
   u32 off_list;  // n > 16 only: receiver list scratch of process_node_actions
+  u32 off_arch, ecap;   // quirks bit 0 (Q1 fixed): frozen record stores of past epochs, snapshot format, [n][ecap]
+  u32 off_sync;         // quirks bit 0: scratch list of block ids (bcap words) for building a response's record order
   u32 off_trace, rcap;  // round-switch trace (DataWriter, data_writer.rs): first_time[n][rcap] then max_round[n]; rcap == 0: off
   u32 total_words;
   u32 max_steps;  // events per instance per launch (0 = unlimited)
@@ -322,7 +325,7 @@ struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at
 // ------------------------------------------------------------------------------------------------
 // CLS specialises the step for a network-size class so that the headline small-network path carries none of
 // the large-network machinery:
-//   0  n <= 16, all nodes honest, lossless network, no round-switch trace, array event queue behind the LDS front, receiver list packed in a register, one mask word
+//   0  n <= 16, all nodes honest, lossless network, no round-switch trace, reference request routing (Q1), array event queue behind the LDS front, receiver list packed in a register, one mask word
 //   1  n <= 32, one mask word; heap / packed list decided at run time
 //   2  n <= 128, multi-word node/author sets (extension rows), heap event queue, receiver list in HBM rows
 //   3  everything decided at run time (init / read-back kernels)
@@ -332,6 +335,7 @@ struct SimT {
   LBFT_HD bool wide() const { return CLS == 2 ? true : (CLS == 3 ? P.n > 32 : false); }
   LBFT_HD bool heap() const { return CLS == 0 ? false : (CLS == 2 ? true : P.qheap != 0); }
   LBFT_HD bool tracing() const { return CLS != 0 && P.rcap != 0; }  // round-switch trace (DataWriter); class 0 never traces
+  LBFT_HD bool q1() const { return CLS != 0 && (P.quirks & 1u) != 0; }  // requests are answered by the peer with real payloads
   LBFT_HD bool cal() const { return CLS != 0 && P.qcal != 0; }
   LBFT_HD bool packed() const { return CLS == 0 ? true : (CLS == 2 ? false : P.n <= 16); }
   const Params& P;
@@ -1124,8 +1128,12 @@ struct SimT {
       if ((u64)ry.depth() >= ((u64)nf(node, NF_EPOCH) + 1) * P.cpe) {
         u64 new_epoch = (u64)ry.depth() / P.cpe;
         // fresh RecordStoreState for the new epoch (node.rs:331-348, record_store.rs:169-198)
+        if (q1()) {  // the store being retired stays readable for peers that ask later (past_record_stores, node.rs:43,339)
+          u32 old_epoch = nf(node, NF_EPOCH);
+          if (old_epoch < P.ecap) write_store_snapshot(node, arch_base(node, old_epoch)); else fault |= F_EPOCH_OVERFLOW;
+        }
+        nfs(node, NF_PREV_EPOCH_HCC, nf(node, NF_HCC_BLK));  // ... and its commit certificate is what notifications forward (Q2 fixed)
         nfs(node, NF_EPOCH, (u32)new_epoch);
-        nfs(node, NF_PREV_EPOCH_HCC, nf(node, NF_HCC_BLK));  // the store being retired keeps its commit certificate (node.rs:331-348)
         nfs(node, NF_INIT_STATE_BLK, y);
         nfs(node, NF_PROPOSED_BLK, 0);
         nfs(node, NF_HQC_ROUND, 0); nfs(node, NF_HQC_BLK, 0); nfs(node, NF_HTC_ROUND, 0);
@@ -1206,6 +1214,103 @@ struct SimT {
         if (j < k) st(sfw(slot, snap_word0 + a[j]), h[j]);
     }
   }
+  // ---- quirks bit 0 (reference quirk Q1 fixed): requests are answered by the PEER (bft-driver/src/core.rs:174-178
+  // instead of simulator.rs:446) with the records the requester lacks (data_sync.rs:183-207, record_store.rs:766-831).
+  // All records are immutable and live in the instance's block pool, so a response is described by the certificates
+  // heading the peer's chains plus its timeouts and proposed block -- the same words as a notification snapshot. ----
+  LBFT_HD u32 sqw(u32 base, u32 k) const { return base + S_FIXED_WORDS + 2 * P.n + 2 * (P.mw - 1) + k; }
+  // RecordStoreState as seen by unknown_records: written into `base` (a snapshot slot or an epoch-archive entry)
+  LBFT_HD void write_store_snapshot(u32 node, u32 base) const {
+    st(base + S_EPOCH, nf(node, NF_EPOCH));
+    st(base + S_CERTS, nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16));
+    st(base + S_PROP_VOTE, nf(node, NF_PROPOSED_BLK));  // current_proposed_block, whoever proposed it
+    u32 htc = nf(node, NF_HTC_ROUND);
+    st(base + S_TC_ROUND, htc);
+    st(base + S_TO_ROUND, nf(node, NF_CUR_ROUND));
+    u32 tc_sel = nf(node, NF_TC_SEL);
+    for (u32 k = 0; k < P.mw; k++) {
+      u32 tk = htc ? am_word(node, NF_TC_MASK, k) : 0, ok = am_word(node, NF_TO_MASK, k);
+      st(k == 0 ? base + S_TC_MASK : base + S_FIXED_WORDS + 2 * P.n + (k - 1), tk);
+      st(k == 0 ? base + S_TO_MASK : base + S_FIXED_WORDS + 2 * P.n + (P.mw - 1) + (k - 1), ok);
+      for (u32 m = tk; m;) { u32 a = 32 * k + ctz32(m); m &= m - 1; st(base + S_FIXED_WORDS + a, nfm(node, NF_FIXED_WORDS + tc_sel * P.n + a)); }
+      for (u32 m = ok; m;) { u32 a = 32 * k + ctz32(m); m &= m - 1; st(base + S_FIXED_WORDS + P.n + a, nfm(node, NF_FIXED_WORDS + (1u - tc_sel) * P.n + a)); }
+    }
+  }
+  LBFT_HD u32 arch_base(u32 node, u32 epoch) const { return P.off_arch + (node * P.ecap + epoch) * P.snap_words; }
+  // is `round` in known_quorum_certificate_rounds (record_store.rs:766-799) of a store whose chains start at hqc / hcc?
+  LBFT_HD bool known_round(u32 hqc, u32 hcc, u32 round) const {
+    for (u32 c = 0; c < 2; c++) {
+      u32 i = 0;
+      for (u32 x = c ? hcc : hqc; x; i++) {
+        Blk rx = blk_get(x);
+        if (rx.round() < round) break;
+        if (((i & (i + 1)) == 0) && rx.round() == round) return true;
+        x = rx.prev();
+      }
+    }
+    return false;
+  }
+  // unknown_records (record_store.rs:801-831) of the store described at `base`, inserted into node's current store in
+  // the order the reference sends them: (block, QC) pairs by ascending round, the timeouts, the proposed block.
+  LBFT_HD void insert_unknown_records(u32 node, u32 base, bool filter, u32 k_hqc, u32 k_hcc) {
+    u32 certs = ld(base + S_CERTS);
+    u32 x1 = certs >> 16, x2 = certs & 0xffffu, cnt = 0;
+    for (;;) {  // util.rs merge_sort of the two chains by descending round, identical certificates once
+      Blk r1, r2;
+      if (x1) { r1 = blk_get(x1); if (filter && known_round(k_hqc, k_hcc, r1.round())) x1 = 0; }
+      if (x2) { r2 = blk_get(x2); if (filter && known_round(k_hqc, k_hcc, r2.round())) x2 = 0; }
+      if (!x1 && !x2) break;
+      u32 e1 = 0, e2 = 0;
+      if (x1 && x2) {
+        if (r2.round() < r1.round()) e1 = x1;
+        else if (r2.round() == r1.round()) { e1 = x1; if (x2 != x1) e2 = x2; }
+        else e2 = x2;
+        if (r2.round() <= r1.round()) x1 = r1.prev();
+        if (r2.round() >= r1.round()) x2 = r2.prev();
+      } else if (x1) { e1 = x1; x1 = r1.prev(); }
+      else { e2 = x2; x2 = r2.prev(); }
+      if (e1) { if (cnt < P.bcap) st(P.off_sync + cnt, e1); else fault |= F_EPOCH_OVERFLOW; cnt++; }
+      if (e2) { if (cnt < P.bcap) st(P.off_sync + cnt, e2); else fault |= F_EPOCH_OVERFLOW; cnt++; }
+    }
+    if (cnt > P.bcap) cnt = P.bcap;
+    u32 epoch = nf(node, NF_EPOCH);
+    for (u32 j = cnt; j-- > 0;) {
+      u32 b = ld(P.off_sync + j);
+      Blk rb = blk_get(b);
+      if (rb.epoch() != epoch) continue;  // (cannot happen: a store only holds records of its own epoch)
+      insert_block(node, b, rb);
+      insert_qc(node, b, rb);
+    }
+    u32 tc_round = ld(base + S_TC_ROUND), to_round = ld(base + S_TO_ROUND);
+    for (u32 k = 0; k < P.mw; k++) {
+      u32 tk = ld(k == 0 ? base + S_TC_MASK : base + S_FIXED_WORDS + 2 * P.n + (k - 1));
+      for (u32 m = tk; m;) { u32 a = 32 * k + ctz32(m); m &= m - 1; insert_timeout(node, a, tc_round, ld(base + S_FIXED_WORDS + a)); }
+    }
+    for (u32 k = 0; k < P.mw; k++) {
+      u32 ok = ld(k == 0 ? base + S_TO_MASK : base + S_FIXED_WORDS + 2 * P.n + (P.mw - 1) + (k - 1));
+      for (u32 m = ok; m;) { u32 a = 32 * k + ctz32(m); m &= m - 1; insert_timeout(node, a, to_round, ld(base + S_FIXED_WORDS + P.n + a)); }
+    }
+    u32 pb = ld(base + S_PROP_VOTE) & 0xffffu;
+    if (pb) insert_block(node, pb);
+  }
+  // DataSyncNode::handle_response (data_sync.rs:209-240): `slot` = the peer's store at request time + the request
+  LBFT_HD void handle_response(u32 node, u32 peer, u32 slot, i64 lclock) {
+    u32 rbase = sfw(slot, 0);
+    u32 req_epoch = ld(sqw(rbase, 0)), req_certs = ld(sqw(rbase, 1));
+    u32 peer_epoch = ld(rbase + S_EPOCH);
+    for (u32 e = req_epoch; e <= peer_epoch; e++) {  // (no entries when the requester was ahead of the peer)
+      u32 mine = nf(node, NF_EPOCH);
+      if (e < mine) continue;
+      if (e > mine) break;
+      u32 base = e == peer_epoch ? rbase : arch_base(peer, e);
+      insert_unknown_records(node, base, e == req_epoch, req_certs >> 16, req_certs & 0xffffu);
+      if (e == peer_epoch) break;
+      process_commits(node);
+      bool tq; i64 tnext;
+      update_tracker(node, (i64)(i32)nf(node, NF_LQAT), lclock, tq, tnext);
+    }
+  }
+
   // `twin`: (E2) the copy for even-indexed receivers of an equivocator's notification carries the twin proposal
   LBFT_HD void write_snapshot(u32 node, u32 slot, bool twin = false) const {
     st(sfw(slot, S_EPOCH), nf(node, NF_EPOCH));
@@ -1299,6 +1404,14 @@ struct SimT {
 
   // ---- SimulatedNode::update (simulator.rs:176-179) ----
   LBFT_HD Actions node_update(u32 node) { return update_node(node, (i64)clock - (i64)(i32)nf(node, NF_STARTUP)); }
+
+  // quirks bit 0: a request carries the requester's epoch and the certificates heading its chains, from which the peer
+  // derives known_quorum_certificate_rounds (data_sync.rs:66-71).  Returns a snapshot slot (refcount still 0) or -1.
+  LBFT_HD i32 make_request_slot(u32 epoch, u32 certs) {
+    i32 rs = snap_alloc();
+    if (rs >= 0) { st(sfw((u32)rs, S_EPOCH), epoch); st(sfw((u32)rs, S_CERTS), certs); }
+    return rs;
+  }
 
   // ---- receiver / sender lists of process_node_actions (simulator.rs:326-343,356-370) ----
   // n <= 16: sixteen 4-bit entries in one 64-bit register (a dynamically indexed array would be a
@@ -1413,12 +1526,15 @@ struct SimT {
     LBFT_MARK(13);
     if (act.query_all) {
       cnt = peers_all_but(node);
+      i32 rs = q1() ? make_request_slot(nf(node, NF_EPOCH), nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16)) : 0;  // create_request (simulator.rs:365-368)
+      u32 rrefs = 0;
       peers_shuffle(cnt);
       for (u32 i = 0; i < cnt; i++) {
         i64 t = (i64)clock + sample_delay();
-        if (net_lost(node, peer(i))) { stamp++; continue; }
-        push_event(t, 1, node, peer(i), 0);
+        if (net_lost(node, peer(i)) || rs < 0) { stamp++; continue; }
+        if (push_event(t, 1, node, peer(i), (u32)rs)) rrefs++;
       }
+      if (q1() && rs >= 0) { if (rrefs) st(P.off_snap_ref + (u32)rs, rrefs); else snap_free_slot((u32)rs); }
     }
     LBFT_MARK(14);
   }
@@ -1487,7 +1603,8 @@ struct SimT {
       // burst), one for update_node + process_node_actions: lanes of a wavefront that handle different
       // event kinds issue their loads together instead of one serialized round trip per kind.
       bool do_update = true, sync = false;
-      begin_node(node);
+      u32 sync_epoch = 0, sync_certs = 0;
+      begin_node((q1() && kind == 1) ? sender : node);  // Q1 fixed: a request is processed on the peer it was sent to
       Snap sn;
 #if defined(__HIPCC__)
 #pragma unroll
@@ -1517,23 +1634,49 @@ struct SimT {
         ev0++;
         sync = handle_notification(node, sender, slot, sn);
         snap_release(slot);
+        if (q1()) { sync_epoch = nf(node, NF_EPOCH); sync_certs = nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16); }  // the request is created now (data_sync.rs:170-176)
         LBFT_MARK(3);
       } else if (kind == 1) {  // DataSyncRequestEvent (simulator.rs:441-453)
         ev1++;
-        // Q1: answered by the requester itself; the response carries nothing insertable
-        i64 t_resp = (i64)clock + sample_delay();
-        if (net_lost(node, sender)) stamp++; else push_event(t_resp, 2, node, sender, 0);
+        if (q1()) {
+          // handle_request on the peer `sender` (data_sync.rs:183-207): its store now, plus what the request said
+          u32 qb = sfw(slot, 0);
+          u32 req_epoch = ld(qb + S_EPOCH), req_certs = ld(qb + S_CERTS);
+          snap_release(slot);
+          i32 rs = snap_alloc();
+          if (rs >= 0) {
+            u32 rb = sfw((u32)rs, 0);
+            write_store_snapshot(sender, rb);
+            st(sqw(rb, 0), req_epoch); st(sqw(rb, 1), req_certs);
+          }
+          i64 t_resp = (i64)clock + sample_delay();
+          bool lost = net_lost(node, sender);
+          if (lost || rs < 0) { stamp++; if (rs >= 0) snap_free_slot((u32)rs); }
+          else if (push_event(t_resp, 2, node, sender, (u32)rs)) st(P.off_snap_ref + (u32)rs, 1);
+          else snap_free_slot((u32)rs);
+        } else {
+          // Q1: answered by the requester itself; the response carries nothing insertable
+          i64 t_resp = (i64)clock + sample_delay();
+          if (net_lost(node, sender)) stamp++; else push_event(t_resp, 2, node, sender, 0);
+        }
         do_update = false;
         LBFT_MARK(4);
-      } else {  // DataSyncResponseEvent (simulator.rs:454-466): handle_response inserts nothing (Q1)
+      } else {  // DataSyncResponseEvent (simulator.rs:454-466): under Q1 handle_response inserts nothing
         ev2++;
+        if (q1()) {
+          handle_response(node, sender, slot, (i64)clock - (i64)(i32)nf(node, NF_STARTUP));
+          snap_release(slot);
+        }
         LBFT_MARK(5);
       }
       if (do_update) {
         Actions a = node_update(node);
         if (sync) {
+          i32 rs = q1() ? make_request_slot(sync_epoch, sync_certs) : 0;
           i64 t_req = (i64)clock + sample_delay();
-          if (net_lost(node, sender)) stamp++; else push_event(t_req, 1, node, sender, 0);
+          if (net_lost(node, sender) || rs < 0) { stamp++; if (q1() && rs >= 0) snap_free_slot((u32)rs); }
+          else if (push_event(t_req, 1, node, sender, (u32)rs)) { if (q1()) st(P.off_snap_ref + (u32)rs, 1); }
+          else if (q1()) snap_free_slot((u32)rs);
         }
         LBFT_MARK(11);
         process_node_actions(node, a);
@@ -1552,7 +1695,7 @@ struct SimT {
 
 typedef SimT<3> Sim;
 // The class lbft_k_run (and the host model) executes a batch with.
-inline int sim_class(const Params& p) { return p.n > 32 ? 2 : ((p.n <= 16 && !p.qheap && !p.equiv && !p.rcap && !p.drop_ppm && !p.part_size) ? 0 : 1); }
+inline int sim_class(const Params& p) { return p.n > 32 ? 2 : ((p.n <= 16 && !p.qheap && !p.equiv && !p.rcap && !p.drop_ppm && !p.part_size && !(p.quirks & 1u)) ? 0 : 1); }
 
 // Row layout for a batch; fills the offset fields of `p` and returns words per instance.
 inline u32 compute_layout(Params& p) {
@@ -1566,7 +1709,7 @@ inline u32 compute_layout(Params& p) {
   p.off_cal_head = w; w += p.cal_buckets;
   p.off_cal_tail = w; w += p.cal_buckets;
   p.off_cal_bm = w; w += (p.cal_buckets + 31) / 32 + (p.qcal ? 1 : 0);
-  p.snap_words = S_FIXED_WORDS + 2 * p.n + 2 * (p.mw - 1);
+  p.snap_words = S_FIXED_WORDS + 2 * p.n + 2 * (p.mw - 1) + ((p.quirks & 1u) ? 2 : 0);  // + the request's (epoch, certificates)
   p.off_snap = w; w += p.scap * p.snap_words;
   p.off_snap_ref = w; w += p.scap;
   p.off_snap_free = w; w += p.scap;
@@ -1575,6 +1718,8 @@ inline u32 compute_layout(Params& p) {
   p.off_log = w; w += p.n * p.lcap;
   p.off_list = w; w += p.n > 16 ? p.n : 0;
   p.off_trace = w; w += p.rcap ? p.n * p.rcap + p.n : 0;
+  p.off_arch = w; w += (p.quirks & 1u) ? p.n * p.ecap * p.snap_words : 0;
+  p.off_sync = w; w += (p.quirks & 1u) ? p.bcap : 0;
   p.total_words = w;
   return w;
 }

@@ -367,7 +367,7 @@ static int validate(const lbft_config* cfg) {
   if (!cfg) return LBFT_ERR_INVALID;
   if (cfg->num_nodes == 0) return LBFT_ERR_INVALID;
   if (cfg->num_nodes > LBFT_MAX_NODES_SUPPORTED) return LBFT_ERR_UNSUPPORTED;
-  if ((cfg->quirks & ~2u) != 0) return LBFT_ERR_UNSUPPORTED;  // bit 1 (Q2 fixed) is implemented; bit 0 (Q1 fixed: real request/response payloads) is not
+  if ((cfg->quirks & ~3u) != 0) return LBFT_ERR_UNSUPPORTED;
   if (cfg->delay_model > 1) return LBFT_ERR_INVALID;
   if (cfg->delay_model == 0 && !(cfg->mean > 0.0 && cfg->variance >= 0.0)) return LBFT_ERR_INVALID;
   if (cfg->delay_model == 1 && !(cfg->uniform_lo >= 0 && cfg->uniform_hi >= cfg->uniform_lo)) return LBFT_ERR_INVALID;
@@ -662,7 +662,9 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   // (large networks: ~n^2 messages in flight per round; the heap keeps push/pop logarithmic)
   u32 qauto = n <= 16 ? 16 * n * n : 8 * n * n;
   u32 qcap = c.queue_capacity ? c.queue_capacity : (qauto < 128 ? 128 : qauto);
-  u32 scap = c.snapshot_capacity ? c.snapshot_capacity : (8 * n < 32 ? 32 : 8 * n);
+  // (quirks bit 0: every request and response in flight holds a slot as well)
+  u32 sauto = (c.quirks & 1u) ? 64 * n : 8 * n;
+  u32 scap = c.snapshot_capacity ? c.snapshot_capacity : (sauto < 32 ? 32 : (sauto > 65535 ? 65535 : sauto));
   // one block per round; a 1- or 2-node network can finish a round per time unit
   u64 bauto = n <= 2 ? (u64)max_clock + 64 : (u64)max_clock / 10 + 64;
   u32 bcap = c.block_capacity ? c.block_capacity : (u32)(bauto > 65534 ? 65534 : bauto);
@@ -673,11 +675,14 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   // (O(1) push and pop), otherwise a binary heap whose top levels are the LDS-resident slots.
   bool big = qcap > 256 || n > 32;
   u32 qheap = big ? 1u : 0u;
-  bool class0 = n <= 16 && !qheap && !p.equiv && !b->rcap && !p.drop_ppm && !p.part_size;
+  bool class0 = n <= 16 && !qheap && !p.equiv && !b->rcap && !p.drop_ppm && !p.part_size && !(p.quirks & 1u);
+  // epochs a node can go through are bounded by its commits: the archive of retired record stores (quirks bit 0) is exact
+  u64 eauto = (u64)bcap / (c.commands_per_epoch ? c.commands_per_epoch : 1) + 2;
+  u32 ecap = (p.quirks & 1u) ? (u32)(eauto > 4096 ? 4096 : eauto) : 0;
   u32 qcal = (!class0 && !b->rcap && b->allow_calendar && max_clock <= LBFT_CAL_MAX_CLOCK) ? 1u : 0u;
-  bool relayout = !(p.qcap == qcap && p.scap == scap && p.bcap == bcap && p.lcap == lcap && p.rcap == b->rcap && p.qcal == qcal &&
+  bool relayout = !(p.qcap == qcap && p.scap == scap && p.bcap == bcap && p.lcap == lcap && p.rcap == b->rcap && p.qcal == qcal && p.ecap == ecap &&
                     p.max_clock == (i32)max_clock && b->d_state);
-  p.qcap = qcap; p.scap = scap; p.bcap = bcap; p.lcap = lcap; p.rcap = b->rcap; p.qcal = qcal; p.qheap = qheap;
+  p.qcap = qcap; p.scap = scap; p.bcap = bcap; p.lcap = lcap; p.rcap = b->rcap; p.qcal = qcal; p.qheap = qheap; p.ecap = ecap;
   p.max_clock = (i32)max_clock;
   p.max_steps = b->max_steps;
   compute_layout(p);

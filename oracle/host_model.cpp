@@ -35,7 +35,7 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
                              size_t history_cap, lbft_oracle_counters* counters, uint32_t* faults,
                              uint32_t* maxq_out, uint32_t* maxsnap_out, int64_t* round_switches /* [inst][rcap][n], INT64_MIN = none */,
                              uint32_t* max_rounds /* [inst] */) {
-  if ((cfg->quirks & ~2u) != 0 || cfg->num_nodes > LBFT_MAX_NODES) return -10;  // bit 1 (Q2 fixed) is implemented, bit 0 (Q1) is not
+  if ((cfg->quirks & ~3u) != 0 || cfg->num_nodes > LBFT_MAX_NODES) return -10;
   Params p;
   memset(&p, 0, sizeof(p));
   p.n = cfg->num_nodes;
@@ -46,6 +46,7 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   p.ql = caps->ql;
   p.qheap = caps->qheap;
   p.rcap = caps->rcap;
+  p.ecap = 64;
   p.qcal = caps->qcal;
   if (p.qcal) { if (max_clock > LBFT_CAL_MAX_CLOCK || p.rcap) return -11; p.qheap = 1; p.ql = 0; }
   p.delay_model = cfg->delay_model;

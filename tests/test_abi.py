@@ -54,7 +54,7 @@ def test_argument_validation_needs_no_gpu(hiplib):
     assert L.lbft_batch_create(ctypes.byref(cfg), seeds.ctypes.data, 4, 0, ctypes.byref(h)) == hiplib.LBFT_ERR_INVALID
     cfg.num_nodes = 4
     cfg.mean, cfg.variance, cfg.commands_per_epoch = 10.0, 4.0, 30000
-    cfg.quirks = 1
+    cfg.quirks = 4  # bits 0 (Q1 fixed) and 1 (Q2 fixed) exist; anything else does not
     assert L.lbft_batch_create(ctypes.byref(cfg), seeds.ctypes.data, 4, 0, ctypes.byref(h)) == hiplib.LBFT_ERR_UNSUPPORTED
     cfg.quirks = 0
     cfg.num_nodes = 129  # LBFT_MAX_NODES_SUPPORTED is 128

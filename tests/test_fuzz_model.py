@@ -29,8 +29,8 @@ def draw_config(rng):
     if rng.random() < 0.25 and n >= 2:
         start = int(rng.integers(0, 300))
         kw.update(partition_size=int(rng.integers(1, n)), partition_start=start, partition_end=start + int(rng.integers(50, 400)))
-    if rng.random() < 0.3:
-        kw["quirks"] = 2
+    if rng.random() < 0.45:
+        kw["quirks"] = int(rng.choice([1, 2, 3]))
     return kw
 
 
@@ -45,11 +45,11 @@ def test_random_configurations_match_the_oracle(oracle, chunk):
         seeds = rng.integers(1, 2 ** 62, m, dtype=np.uint64)
         cfg = oracle.make_config(math_mode=1, **kw)
         a = oracle.run_batch(cfg, seeds, max_clock, threads=4, history_cap=96)
-        special = any(k in kw for k in ("equivocate_every", "drop_per_million", "partition_size"))
+        special = any(k in kw for k in ("equivocate_every", "drop_per_million", "partition_size")) or (kw.get("quirks", 0) & 1)
         big = n > 4
         qheap = 1 if (big or rng.random() < 0.3) else 0
         qcal = 1 if (rng.random() < 0.5 and (qheap or special or n > 16)) else 0
-        b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=4, history_cap=96, qcap=max(4096, 24 * n * n), scap=max(64, 32 * n),
+        b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=4, history_cap=96, qcap=max(4096, 24 * n * n), scap=max(128, 128 * n),
                                        bcap=1024, lcap=1024, ql=int(rng.choice([0, 3, 11, 48])), qheap=qheap, qcal=qcal,
                                        force_generic=int(rng.random() < 0.2))
         assert not b["faults"].any(), kw
@@ -80,7 +80,7 @@ def test_random_configurations_on_the_device_match_the_oracle(oracle, chunk):
                                      drop_per_million=kw.get("drop_per_million", 0), partition=part, quirks=kw.get("quirks", 0),
                                      calendar_queue=bool(rng.random() < 0.7), max_steps_per_launch=int(rng.choice([0, 0, 173])),
                                      lanes_per_wavefront=int(rng.choice([0, 8, 64])), block_capacity=max_clock + 64,
-                                     queue_capacity=max(4096, 64 * n * n), snapshot_capacity=max(64, 32 * n))
+                                     queue_capacity=max(4096, 64 * n * n), snapshot_capacity=max(128, 128 * n))
         res = sim.loop_until(max_clock, allow_faults=True)
         assert not res.faults.any(), (kw, sorted(set(int(f) for f in res.faults)), res.counters, sim.layout())
         assert (res.commit_counts == ref["commit_counts"]).all(), kw

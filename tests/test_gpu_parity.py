@@ -92,6 +92,13 @@ CASES = {
     "q2fixed_n4_cpe50": (dict(num_nodes=4, commands_per_epoch=50, quirks=2), 128, 3000),
     "q2fixed_n7_weighted_cpe9": (dict(num_nodes=7, commands_per_epoch=9, quirks=2, voting_rights=[2, 1, 1, 3, 1, 2, 1]), 64, 2000),
     "q2fixed_n36_cpe3": (dict(num_nodes=36, commands_per_epoch=3, quirks=2), 4, 300),
+    # quirks bit 0: requests answered by the peer with real payloads (reference quirk Q1 fixed); 3 = Q1 and Q2 fixed
+    "q1fixed_n4_long_tail": (dict(num_nodes=4, quirks=1, mean=10.0, variance=400.0), 128, 2500),
+    "q3fixed_n4_cpe50": (dict(num_nodes=4, quirks=3, commands_per_epoch=50), 128, 3000),
+    "q3fixed_n7_weighted_cpe9": (dict(num_nodes=7, quirks=3, commands_per_epoch=9, voting_rights=[2, 1, 1, 3, 1, 2, 1]), 64, 2000),
+    "q3fixed_n5_partition_heals": (dict(num_nodes=5, quirks=3, partition_size=2, partition_start=100, partition_end=400, commands_per_epoch=20), 64, 2500),
+    "q3fixed_n36_cpe3": (dict(num_nodes=36, quirks=3, commands_per_epoch=3), 4, 300),
+    "q1fixed_n7_equivocators_lossy": (dict(num_nodes=7, quirks=1, equivocate_every=3, drop_per_million=100000), 64, 1500),
     "equiv_n5_weighted_epochs": (dict(num_nodes=5, equivocate_every=2, voting_rights=[1, 3, 1, 2, 2], commands_per_epoch=7), 64, 1500),
     "epoch_change_cpe50": (dict(num_nodes=4, commands_per_epoch=50), 128, 3000),
     "weighted": (dict(num_nodes=5, voting_rights=[5, 1, 1, 2, 3]), 128, 1000),

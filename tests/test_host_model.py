@@ -237,3 +237,37 @@ def test_host_model_q2_fixed(oracle, name):
         stalled = oracle.run_batch(oracle.make_config(math_mode=1, num_nodes=4, commands_per_epoch=50), seeds, max_clock, threads=8)
         assert stalled["commit_counts"].max() <= 50
         assert (a["commit_counts"].min(axis=1) >= 90).all()
+
+
+# quirks bit 0: requests are answered by the peer with real payloads (reference quirk Q1 fixed); with bit 1 too = "fixed" mode
+Q1 = {
+    "q1_n4": (dict(num_nodes=4, quirks=1), 64, 1500),
+    "q1_n4_long_tail": (dict(num_nodes=4, quirks=1, mean=10.0, variance=400.0), 64, 2500),
+    "q3_n4_cpe50": (dict(num_nodes=4, quirks=3, commands_per_epoch=50), 64, 3000),
+    "q1_n4_cpe50": (dict(num_nodes=4, quirks=1, commands_per_epoch=50), 64, 3000),
+    "q3_n3_cpe5": (dict(num_nodes=3, quirks=3, commands_per_epoch=5), 64, 1500),
+    "q3_n7_weighted_cpe9": (dict(num_nodes=7, quirks=3, commands_per_epoch=9, voting_rights=[2, 1, 1, 3, 1, 2, 1]), 32, 2000),
+    "q1_n8_lossy": (dict(num_nodes=8, quirks=1, drop_per_million=150000), 16, 1500),
+    "q3_n5_partition_heals": (dict(num_nodes=5, quirks=3, partition_size=2, partition_start=100, partition_end=400, commands_per_epoch=20), 32, 2500),
+    "q3_n36_cpe3": (dict(num_nodes=36, quirks=3, commands_per_epoch=3), 2, 300),
+    "q1_n7_equivocators": (dict(num_nodes=7, quirks=1, equivocate_every=3), 32, 1500),
+}
+
+
+@pytest.mark.parametrize("name", sorted(Q1))
+def test_host_model_q1_fixed(oracle, name):
+    kw, m, max_clock = Q1[name]
+    n = kw["num_nodes"]
+    cfg = oracle.make_config(math_mode=1, **kw)
+    seeds = np.arange(40, 40 + m, dtype=np.uint64)
+    a = oracle.run_batch(cfg, seeds, max_clock, threads=8, history_cap=256)
+    b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=8, history_cap=256, qcap=max(4096, 16 * n * n), scap=max(128, 128 * n),
+                                   bcap=1024, lcap=1024, ql=13, qheap=1 if n > 4 else 0, qcal=1 if max_clock <= 2047 else 0)
+    assert not b["faults"].any()
+    for key in ("commit_counts", "active_rounds", "last_states", "histories"):
+        assert (a[key] == b[key]).all(), key
+    for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
+        assert a["counters"][key] == b["counters"][key], key
+    if name == "q3_n5_partition_heals":
+        # with both quirks fixed a healed partition catches up (the reference semantics never do, see LOSSY partition test)
+        assert (a["commit_counts"].min(axis=1) >= 25).mean() > 0.8

@@ -18,9 +18,10 @@ CONFIGS = {
     "c4_16384x64_longtail_equivocators": dict(instances=16384, nodes=64, max_clock=300, variance=400.0, equivocate_every=5),
     "c5_8192x100_weighted_epochs": dict(instances=8192, nodes=100, max_clock=300, weights=[1 + (i % 4) for i in range(100)],
                                         commands_per_epoch=50),
-    # same with quirk Q2 fixed and a horizon long enough to cross epochs (the reference semantics stall at the first change)
-    "c5b_1024x100_weighted_epochs_q2fixed": dict(instances=1024, nodes=100, max_clock=2000, weights=[1 + (i % 4) for i in range(100)],
-                                                 commands_per_epoch=50, quirks=2),
+    # same in the "fixed" protocol mode (quirks Q1 and Q2 fixed) with a horizon long enough to cross epochs (the reference
+    # semantics stall at the first change)
+    "c5b_1024x100_weighted_epochs_fixed": dict(instances=1024, nodes=100, max_clock=2000, weights=[1 + (i % 4) for i in range(100)],
+                                               commands_per_epoch=50, quirks=3),
 }
 
 
