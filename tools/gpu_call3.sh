@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
 tail -3 gpurun_out/pytest_gpu.log
 timeout 600 python tools/sweep.py --libs ${LIBS:-liblbft_hip.so} --grid ${GRID:-64:-1,32:-1} > gpurun_out/sweep.jsonl 2> gpurun_out/sweep.err
-timeout 300 python tools/sweep.py --libs ${PLIBS:-liblbft_hip_prof.so} --grid 64:-1 >> gpurun_out/sweep.jsonl 2>> gpurun_out/sweep.err
+timeout 300 python tools/sweep.py --libs ${PLIBS:-liblbft_hip_prof.so} --grid ${PGRID:-0:-1} >> gpurun_out/sweep.jsonl 2>> gpurun_out/sweep.err
 python - <<'PY'
 import json
 for line in open("gpurun_out/sweep.jsonl"):
