@@ -78,7 +78,17 @@ def cpu_baseline(args, nodes, max_clock):
     r = oc.run_batch(cfg, seeds, max_clock, threads=cores)
     dt = time.perf_counter() - t0
     c = r["counters"]
+    # BASELINE.json configs[0], the reference's own CPU-runnable case: 1 instance x 3 nodes, fixed delay 10 (mean 10, variance 0),
+    # ~100 rounds (max_clock 2800), one thread
+    c1cfg = oc.make_config(num_nodes=3, mean=10.0, variance=0.0, math_mode=1)
+    t1 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t1 < 0.5:
+        r1 = oc.run_batch(c1cfg, np.array([args.base_seed + reps], dtype=np.uint64), 2800, threads=1)
+        reps += 1
+    c1 = r1["counters"]["rounds"] * reps / (time.perf_counter() - t1)
     return {
+        "c1_single_thread_rounds_per_s": c1,
         "value": c["rounds"] / dt, "unit": "rounds/s", "cores": cores, "kind": "port",
         "sample": "%d instances x %d nodes, LogNormal(10,4), max_clock %d, %d host threads, %.1f s" % (m, nodes, max_clock, cores, dt),
         "events_per_s": sum(c["events"]) / dt, "commits_per_s": c["commits"] / dt,
