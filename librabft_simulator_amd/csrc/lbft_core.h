@@ -1,8 +1,12 @@
 // lbft_core.h -- the batched LibraBFTv2 discrete-event simulation step, written once for the HIP
-// kernels (lbft_kernels.hip).  One GPU lane simulates one independent network ("instance"); the state
-// of all instances lives in HBM as word-interleaved struct-of-arrays rows (row w of instance i is
-// state[w * stride + i]), so a wavefront touching the same field of its 64 instances issues one
-// coalesced 256-byte access.  See DESIGN.md for the layout and the reasoning.
+// kernels (lbft_hip.hip).  One GPU lane simulates one independent network ("instance").  Where its state
+// lives while lbft_k_run executes:
+//   * registers: RNG, clock, counters, the rows of the node the current event is for, a small cache of
+//     hot block records;
+//   * LDS: the front of the event queue (lane-private columns) and the read-only tables of the delay
+//     sampler / pacemaker;
+//   * HBM: everything, in tiles of 64 instances whose rows are word-interleaved (word w of instance i at
+//     tile(i / 64) + w * 256 + (i % 64) * 4 bytes), so a wavefront reads a row as one contiguous segment.
 //
 // The reference keeps records in HashMaps keyed by 64-bit BCS/SipHash values; those hashes are
 // identities only, so this model replaces them with structural ids:
@@ -11,8 +15,9 @@
 //   * per-node knowledge = three node-bitmasks per block (block known / QC in map / state pending);
 //   * timeouts, TCs and votes = author bitmasks (+ the timeout's highest_certified_block_round);
 //   * a notification = a refcounted snapshot slot holding a handful of ids and masks;
-//   * requests/responses are payload-free (the reference answers a request on the requester
-//     itself, so a response can never insert a record -- quirk Q1, asserted by the oracle).
+//   * requests/responses are payload-free under the reference semantics (the reference answers a
+//     request on the requester itself, so a response can never insert a record -- quirk Q1, asserted by
+//     the oracle); with quirks bit 0 they are snapshots of the same kind as notifications.
 //
 // The file also compiles with a host C++ compiler: oracle/host_model.cpp builds it for the CPU-only
 // differential tests (compact model == full-fidelity oracle on thousands of seeds).  That host build

@@ -1,9 +1,9 @@
 // lbft_hip.hip -- HIP kernels (gfx950) and the C ABI of include/lbft.h.
 //
-// Execution model: one lane = one simulated network.  A 64-lane wavefront advances 64 independent
-// discrete-event simulations; all per-instance state is in HBM as word-interleaved rows
-// (state[row * stride + instance]) so that a wavefront reading row r touches one contiguous 256-byte
-// segment.  The simulation step itself is lbft_core.h (device build only in this library).
+// Execution model: one lane = one simulated network; a wavefront advances up to 32 (large batches) independent
+// discrete-event simulations, two wavefronts per SIMD.  The simulation step itself is lbft_core.h (device build only
+// in this library), instantiated per network-size class; this file holds the kernels around it, the LDS / launch
+// geometry, and the host side of the C ABI.
 // No CPU fallback exists: every entry point fails with LBFT_ERR_HIP if the device is unusable.
 #include <hip/hip_runtime.h>
 

@@ -1,4 +1,6 @@
 #!/bin/bash
+# Runs on the GPU box (via gpurun): GPU parity tests, the tuning sweep (tools/sweep.py) for LIBS / GRID, and the phase-timer
+# breakdown of the diagnostic build.  Example: gpurun -- 'GRID=0:-1,64:-1 bash tools/gpu_check.sh'
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
