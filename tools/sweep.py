@@ -21,6 +21,10 @@ def one(args):
     import numpy as np
     from librabft_simulator_amd import BatchSimulator, NodeConfig, RandomDelay, lib
     seeds = np.arange(1, args.instances + 1, dtype=np.uint64)
+    if args.same_seed:  # divergence-free upper bound: every lane of a wavefront simulates the same network
+        seeds = np.full(args.instances, 12345, dtype=np.uint64)
+    elif args.seed_groups:  # every group of `seed_groups` consecutive instances shares a seed
+        seeds = (np.arange(args.instances, dtype=np.uint64) // np.uint64(args.seed_groups)) + np.uint64(1)
     sim = BatchSimulator.new(seeds, args.nodes, RandomDelay.new(10.0, 4.0), NodeConfig(), lanes_per_wavefront=args.lpw,
                              lds_queue_slots=args.ql)
     ms = []
@@ -55,6 +59,8 @@ def main():
     ap.add_argument("--nodes", type=int, default=4)
     ap.add_argument("--max-clock", type=int, default=1000)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--same-seed", action="store_true")
+    ap.add_argument("--seed-groups", type=int, default=0)
     ap.add_argument("--libs", default="liblbft_hip.so")
     ap.add_argument("--grid", default="64:-1,32:-1,16:-1,64:0,32:0")
     args = ap.parse_args()
@@ -69,7 +75,7 @@ def main():
             lpw, ql = item.split(":")
             env = dict(os.environ, LBFT_HIP_LIB=path)
             cmd = [sys.executable, os.path.abspath(__file__), "--one", "--lpw", lpw, "--ql", ql, "--instances", str(args.instances),
-                   "--nodes", str(args.nodes), "--max-clock", str(args.max_clock), "--reps", str(args.reps)]
+                   "--nodes", str(args.nodes), "--max-clock", str(args.max_clock), "--reps", str(args.reps)] + (["--same-seed"] if args.same_seed else []) + (["--seed-groups", str(args.seed_groups)] if args.seed_groups else [])
             r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
             sys.stdout.write(r.stdout)
             if r.returncode != 0:
