@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--base-seed", type=int, default=1)
     ap.add_argument("--lpw", type=int, default=0, help="lanes per wavefront carrying an instance (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses HIP device 0")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the oracle sample")
     return ap.parse_args()
 
@@ -104,12 +106,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from librabft_simulator_amd import BatchSimulator, NodeConfig, RandomDelay
     from librabft_simulator_amd.distributed import shard_seeds
@@ -139,6 +146,8 @@ def main():
     local = torch.tensor([c["rounds"], c["commits"], sum(c["events"]), c["faulted_instances"]], dtype=torch.float64,
                          device="cuda")
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if dist is not None and args.backend != "nccl":  # rehearsal backends reduce host tensors
+        local, tmax = local.cpu(), tmax.cpu()
     if dist is not None:
         dist.all_reduce(local, op=dist.ReduceOp.SUM)  # the single collective of the run: throughput counters
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
