@@ -1489,59 +1489,92 @@ struct SimT {
       push_event(t_new, 3, node, 0, 0);
     }
     LBFT_MARK(12);
-    u32 cnt = 0;
-    if (act.broadcast) cnt = peers_all_but(node);
-    else if (act.send_to >= 0 && (u32)act.send_to != node) { peers_one((u32)act.send_to); cnt = 1; }
-    peers_shuffle(cnt);  // SliceRandom::shuffle
-    i32 slot = -1, slot_twin = -1;
-    u32 refs = 0, refs_twin = 0;
+  }
+
+  // ---- every network message of one event, in the reference's order and with its RNG draws, through ONE loop ----
+  // simulator.rs: the response to a request (:441-453); or, after update_node, the sync request of a notification
+  // (:424-433), the notifications to the shuffled receivers (:326-354) and the requests to the shuffled senders
+  // (:356-377).  The reference has four send sites; lanes of a wavefront usually need different ones, so separate sites
+  // would each run (delay sampler included) for a few lanes.  Here a lane's messages form one list and iteration j of
+  // the loop sends every lane's j-th message: the wavefront pays max(messages per lane) sampler runs instead of one
+  // per site and loop iteration.
+  struct SendPlan {
+    u32 response;      // 1: this event is a request; answer it (slot = response snapshot under quirks bit 0)
+    u32 resp_slot;
+    u32 sync;          // 1: handle_notification asked for a request to the notification's sender
+    u32 sync_stamp;    // its creation stamp, reserved before the timer was scheduled (order of simulator.rs:424-440)
+    u32 sync_epoch, sync_certs;
+    u32 have_actions;  // update_node ran: act is valid
+  };
+  LBFT_HD void send_loop(u32 node, u32 sender, const SendPlan& sp, const Actions& act) {
+    u32 n_a = 0, n_b = 0;
+    if (sp.have_actions) {
+      if (act.broadcast) n_a = P.n - 1;
+      else if (act.send_to >= 0 && (u32)act.send_to != node) n_a = 1;
+      if (act.query_all) n_b = P.n - 1;
+    }
+    u32 first_a = sp.response + sp.sync, first_b = first_a + n_a, total = first_b + n_b;
+    i32 slot = -1, slot_twin = -1, rs = 0;
+    u32 refs = 0, refs_twin = 0, rrefs = 0;
     bool equivocal = false;
-    if (cnt && is_equivocator(node)) {  // (E2): does this notification carry one of the node's own (double) proposals?
-      u32 pb = proposed_block(node);
-      equivocal = pb != 0 && blk_get(pb).author() == node;
-    }
-    for (u32 i = 0; i < cnt; i++) {
-      i64 t = (i64)clock + sample_delay();
-      u32 r = peer(i);
-      if (net_lost(node, r)) { stamp++; continue; }  // a lost message still consumes its creation stamp
-      if (equivocal && (r & 1u) == 0) {
-        if (t <= (i64)P.max_clock && slot_twin == -1) {
-          slot_twin = snap_alloc();
-          if (slot_twin < 0) slot_twin = -2; else write_snapshot(node, (u32)slot_twin, true);
+    for (u32 j = 0; j < total; j++) {
+      if (j == first_a && n_a) {  // receivers.shuffle(rng) (simulator.rs:343): drawn right before their delays
+        if (act.broadcast) peers_all_but(node); else peers_one((u32)act.send_to);
+        peers_shuffle(n_a);
+        if (is_equivocator(node)) {  // (E2): does this notification carry one of the node's own (double) proposals?
+          u32 pb = proposed_block(node);
+          equivocal = pb != 0 && blk_get(pb).author() == node;
         }
-        if (slot_twin >= 0) { if (push_event(t, 0, r, node, (u32)slot_twin)) refs_twin++; }
-        else stamp++;
-        continue;
       }
-      if (t <= (i64)P.max_clock && slot == -1) {
-        slot = snap_alloc();
-        if (slot < 0) slot = -2; else write_snapshot(node, (u32)slot);
+      if (j == first_b && n_b) {  // create_request, senders.shuffle(rng) (simulator.rs:365-370)
+        peers_all_but(node);
+        rs = q1() ? make_request_slot(nf(node, NF_EPOCH), nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16)) : 0;
+        peers_shuffle(n_b);
       }
-      if (slot >= 0) { if (push_event(t, 0, r, node, (u32)slot)) refs++; }
-      else stamp++;  // dropped event still consumes a creation stamp
+      i64 t = (i64)clock + sample_delay();
+      if (j < sp.response) {  // DataSyncResponseEvent back to the requester
+        bool lost = net_lost(node, sender);
+        if (q1()) {
+          i32 rslot = (i32)sp.resp_slot;  // -1 encoded as 0xffffffff: no slot was available
+          if (lost || rslot < 0) { stamp++; if (rslot >= 0) snap_free_slot((u32)rslot); }
+          else if (push_event(t, 2, node, sender, (u32)rslot)) st(P.off_snap_ref + (u32)rslot, 1);
+          else snap_free_slot((u32)rslot);
+        } else {
+          if (lost) stamp++; else push_event(t, 2, node, sender, 0);
+        }
+      } else if (j < first_a) {  // the sync request (its stamp was reserved before the timer's)
+        i32 qs = q1() ? make_request_slot(sp.sync_epoch, sp.sync_certs) : 0;
+        if (net_lost(node, sender) || qs < 0) { if (q1() && qs >= 0) snap_free_slot((u32)qs); }
+        else if (push_event(t, 1, node, sender, (u32)qs, sp.sync_stamp)) { if (q1()) st(P.off_snap_ref + (u32)qs, 1); }
+        else if (q1()) snap_free_slot((u32)qs);
+      } else if (j < first_b) {  // DataSyncNotifyEvent to receiver r
+        u32 r = peer(j - first_a);
+        if (net_lost(node, r)) { stamp++; continue; }  // a lost message still consumes its creation stamp
+        if (equivocal && (r & 1u) == 0) {
+          if (t <= (i64)P.max_clock && slot_twin == -1) {
+            slot_twin = snap_alloc();
+            if (slot_twin < 0) slot_twin = -2; else write_snapshot(node, (u32)slot_twin, true);
+          }
+          if (slot_twin >= 0) { if (push_event(t, 0, r, node, (u32)slot_twin)) refs_twin++; }
+          else stamp++;
+          continue;
+        }
+        if (t <= (i64)P.max_clock && slot == -1) {
+          slot = snap_alloc();
+          if (slot < 0) slot = -2; else write_snapshot(node, (u32)slot);
+        }
+        if (slot >= 0) { if (push_event(t, 0, r, node, (u32)slot)) refs++; }
+        else stamp++;  // dropped event still consumes a creation stamp
+      } else {  // DataSyncRequestEvent to sender s (query_all)
+        u32 sd = peer(j - first_b);
+        if (net_lost(node, sd) || rs < 0) { stamp++; continue; }
+        if (push_event(t, 1, node, sd, (u32)rs)) rrefs++;
+      }
     }
-    if (slot >= 0) {
-      if (refs) st(P.off_snap_ref + (u32)slot, refs);
-      else snap_free_slot((u32)slot);
-    }
-    if (slot_twin >= 0) {
-      if (refs_twin) st(P.off_snap_ref + (u32)slot_twin, refs_twin);
-      else snap_free_slot((u32)slot_twin);
-    }
+    if (slot >= 0) { if (refs) st(P.off_snap_ref + (u32)slot, refs); else snap_free_slot((u32)slot); }
+    if (slot_twin >= 0) { if (refs_twin) st(P.off_snap_ref + (u32)slot_twin, refs_twin); else snap_free_slot((u32)slot_twin); }
+    if (q1() && n_b && rs >= 0) { if (rrefs) st(P.off_snap_ref + (u32)rs, rrefs); else snap_free_slot((u32)rs); }
     LBFT_MARK(13);
-    if (act.query_all) {
-      cnt = peers_all_but(node);
-      i32 rs = q1() ? make_request_slot(nf(node, NF_EPOCH), nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16)) : 0;  // create_request (simulator.rs:365-368)
-      u32 rrefs = 0;
-      peers_shuffle(cnt);
-      for (u32 i = 0; i < cnt; i++) {
-        i64 t = (i64)clock + sample_delay();
-        if (net_lost(node, peer(i)) || rs < 0) { stamp++; continue; }
-        if (push_event(t, 1, node, peer(i), (u32)rs)) rrefs++;
-      }
-      if (q1() && rs >= 0) { if (rrefs) st(P.off_snap_ref + (u32)rs, rrefs); else snap_free_slot((u32)rs); }
-    }
-    LBFT_MARK(14);
   }
 
   // ---- Simulator::new (simulator.rs:200-250) + NodeState::make_initial_state (node.rs:87-114) ----
@@ -1608,7 +1641,8 @@ struct SimT {
       // burst), one for update_node + process_node_actions: lanes of a wavefront that handle different
       // event kinds issue their loads together instead of one serialized round trip per kind.
       bool do_update = true, sync = false;
-      u32 sync_epoch = 0, sync_certs = 0;
+      SendPlan sp;
+      sp.response = 0; sp.resp_slot = 0; sp.sync = 0; sp.sync_stamp = 0; sp.sync_epoch = 0; sp.sync_certs = 0; sp.have_actions = 0;
       begin_node((q1() && kind == 1) ? sender : node);  // Q1 fixed: a request is processed on the peer it was sent to
       Snap sn;
 #if defined(__HIPCC__)
@@ -1639,7 +1673,7 @@ struct SimT {
         ev0++;
         sync = handle_notification(node, sender, slot, sn);
         snap_release(slot);
-        if (q1()) { sync_epoch = nf(node, NF_EPOCH); sync_certs = nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16); }  // the request is created now (data_sync.rs:170-176)
+        if (q1()) { sp.sync_epoch = nf(node, NF_EPOCH); sp.sync_certs = nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16); }  // the request is created now (data_sync.rs:170-176)
         LBFT_MARK(3);
       } else if (kind == 1) {  // DataSyncRequestEvent (simulator.rs:441-453)
         ev1++;
@@ -1654,16 +1688,9 @@ struct SimT {
             write_store_snapshot(sender, rb);
             st(sqw(rb, 0), req_epoch); st(sqw(rb, 1), req_certs);
           }
-          i64 t_resp = (i64)clock + sample_delay();
-          bool lost = net_lost(node, sender);
-          if (lost || rs < 0) { stamp++; if (rs >= 0) snap_free_slot((u32)rs); }
-          else if (push_event(t_resp, 2, node, sender, (u32)rs)) st(P.off_snap_ref + (u32)rs, 1);
-          else snap_free_slot((u32)rs);
-        } else {
-          // Q1: answered by the requester itself; the response carries nothing insertable
-          i64 t_resp = (i64)clock + sample_delay();
-          if (net_lost(node, sender)) stamp++; else push_event(t_resp, 2, node, sender, 0);
-        }
+          sp.resp_slot = (u32)rs;
+        }  // (reference semantics, Q1: answered by the requester itself; the response carries nothing insertable)
+        sp.response = 1;
         do_update = false;
         LBFT_MARK(4);
       } else {  // DataSyncResponseEvent (simulator.rs:454-466): under Q1 handle_response inserts nothing
@@ -1674,17 +1701,17 @@ struct SimT {
         }
         LBFT_MARK(5);
       }
+      Actions a;
+      a.next = LBFT_NEVER; a.send_to = -1; a.broadcast = false; a.query_all = false;
       if (do_update) {
-        Actions a = node_update(node);
-        if (sync) {
-          i32 rs = q1() ? make_request_slot(sync_epoch, sync_certs) : 0;
-          i64 t_req = (i64)clock + sample_delay();
-          if (net_lost(node, sender) || rs < 0) { stamp++; if (q1() && rs >= 0) snap_free_slot((u32)rs); }
-          else if (push_event(t_req, 1, node, sender, (u32)rs)) { if (q1()) st(P.off_snap_ref + (u32)rs, 1); }
-          else if (q1()) snap_free_slot((u32)rs);
-        }
+        a = node_update(node);
+        if (sync) { sp.sync = 1; sp.sync_stamp = stamp++; }  // the request is scheduled before the timer (simulator.rs:424-440)
         LBFT_MARK(11);
         process_node_actions(node, a);
+        sp.have_actions = 1;
+      }
+      send_loop(node, sender, sp, a);
+      if (do_update) {
         LBFT_DRAIN_VMEM();
         LBFT_MARK(14);
         end_node(node);
