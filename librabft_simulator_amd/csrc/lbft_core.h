@@ -1368,19 +1368,29 @@ struct SimT {
     bool should_sync = n_epoch > epoch;
     u32 certs = sn.w[S_CERTS];
     u32 hcc = certs & 0xffffu, hqc = certs >> 16;
-    if (hcc) {
-      Blk r = blk_get(hcc);
+    // The two certificates of a notification (data_sync.rs:125-148), commit certificate first.  A certificate that IS the
+    // receiver's current commit / quorum certificate changes nothing (its QC is in the store, the should_sync tests are
+    // false), which is the usual case; what remains is at most one certificate for most lanes, so the two go through
+    // one loop: the wavefront pays for max(pending per lane) insertions instead of one per certificate kind.
+    const u32 ROLE_HCC = 1u << 31, ROLE_HQC = 1u << 30;
+    u32 p0 = 0, p1 = 0;
+    if (hcc && hcc != nf(node, NF_HCC_BLK)) p0 = hcc | ROLE_HCC;
+    if (hqc && hqc != nf(node, NF_HQC_BLK)) {
+      if ((p0 & 0xffffu) == hqc) p0 |= ROLE_HQC;  // same block in both roles
+      else if (p0) p1 = hqc | ROLE_HQC;
+      else p0 = hqc | ROLE_HQC;
+    }
+    for (u32 k = 0; k < 2; k++) {
+      u32 c = k ? p1 : p0;
+      if (!c) break;
+      u32 b = c & 0xffffu;
+      Blk r = blk_get(b);
       u32 qe = r.epoch();
-      if (qe == epoch) insert_qc(node, hcc, r);
-      should_sync |= (qe > epoch) || (qe == epoch && r.round() > nf(node, NF_HC_ROUND) + 2);
+      if (qe == epoch) insert_qc(node, b, r);
+      if (c & ROLE_HCC) should_sync |= (qe > epoch) || (qe == epoch && r.round() > nf(node, NF_HC_ROUND) + 2);
+      if (c & ROLE_HQC) should_sync |= (qe > epoch) || (qe == epoch && r.round() > nf(node, NF_HQC_ROUND));
     }
     LBFT_MARK(20);
-    if (hqc) {
-      Blk r = blk_get(hqc);
-      u32 qe = r.epoch();
-      if (qe == epoch) insert_qc(node, hqc, r);
-      should_sync |= (qe > epoch) || (qe == epoch && r.round() > nf(node, NF_HQC_ROUND));
-    }
     LBFT_MARK(21);
     if (n_epoch == epoch) {
       u32 pv = sn.w[S_PROP_VOTE];
