@@ -1105,7 +1105,19 @@ struct SimT {
     // committed_states_after (record_store.rs:557-574): from the grandparent of the commit-certificate
     // block back to the first block whose round is <= `after`
     u32 start = blk_get(nf(node, NF_HCC_BLK)).pp(), k = 1;
-    Blk r0 = blk_get(start);  // its round is highest_committed_round > after: at least this block commits
+    // Its round is highest_committed_round > after: at least this block commits.  It is an old block that nothing else
+    // will look at again: fetch the four words the commit needs straight from its row (one burst; the rows are always
+    // current, the cache is write-through) instead of pulling the record through the cache and evicting a hot one.
+    Blk r0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 f = 0; f < BC_WORDS; f++) r0.w[f] = 0;
+    {
+      u32 sb = boff(bfw(start, 0));
+      r0.w[B_LINK] = ldf(sb, B_LINK); r0.w[B_PREV_ROUND] = ldf(sb, B_PREV_ROUND);
+      r0.w[B_DEPTH] = ldf(sb, B_DEPTH); r0.w[B_PEND] = ldf(sb, B_PEND);
+    }
     // the parent's round is denormalised in the record: the usual single-commit case needs no further lookups
     for (u32 x = (r0.prev() && r0.prev_round() > after) ? r0.prev() : 0; x;) {
       Blk rx = blk_get(x);
