@@ -44,7 +44,9 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restr
 //   metas [wave][slot][lane]              u32   (node, sender, snapshot slot)
 // A lane only ever touches its own column (address = slot * lpw + lane), so data-dependent slot
 // indices are bank-conflict free and no workgroup barrier is needed after the table fill.
+#ifndef LBFT_RUN_WAVES
 #define LBFT_RUN_WAVES 4
+#endif
 #define LBFT_RUN_BLOCK (64 * LBFT_RUN_WAVES)
 #define LBFT_LDS_LEADERS 1024  // rounds of the leader table kept in LDS (bytes)
 #define LBFT_LDS_DURS 128      // entries of the duration table kept in LDS (i64)
@@ -703,7 +705,8 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   }
   p.lpw = lpw;
   // LDS queue slots per instance: what one CU's LDS affords when it hosts 64/lpw workgroups
-  u32 wg_per_cu = 64 / lpw ? 64 / lpw : 1;
+  u32 wg_per_cu = (64 / lpw) * 4 / LBFT_RUN_WAVES;  // workgroups of LBFT_RUN_WAVES wavefronts that make up a CU's 256 instances
+  if (wg_per_cu < 1) wg_per_cu = 1;
   if (wg_per_cu > 4) wg_per_cu = 4;
   size_t budget = (160u * 1024u) / wg_per_cu;
   // 2 KiB slack per workgroup: with less, two workgroups of 32-lane wavefronts do not become co-resident on a CU
