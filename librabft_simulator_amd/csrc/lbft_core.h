@@ -374,7 +374,7 @@ struct SimT {
 #endif
 
   LBFT_HD SimT(const Params& p, u32* state, u32 i) : SimT(p, reinterpret_cast<char*>(state) + tile_offset_bytes(p, i), (i & 63u) * 4u, 0) {}
-  LBFT_HD SimT(const Params& p, char* tile_base, u32 lane_byte_offset, int) : P(p), tile(tile_base), lane4(lane_byte_offset), qk(nullptr), qm(nullptr), qstr(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab),
+  LBFT_HD SimT(const Params& p, char* tile_base, u32 lane_byte_offset, int) : P(p), tile(tile_base), lane4(lane_byte_offset), qk(nullptr), qm(nullptr), qstr(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab), plist_lds(nullptr),
         leader_lds(nullptr), dur_lds(nullptr), leader_lds_len(0), dur_lds_len(0) {}
   LBFT_HD void attach_queue(u64* keys, u32* metas, u32 stride, u32 slots) {
     qk = keys; qm = metas; qstr = stride; ql = slots;
@@ -382,6 +382,7 @@ struct SimT {
     LBFT_PIN_VGPR(ql);
   }
   LBFT_HD void attach_tables(const u64* zx, const u64* zf, const u64* et) { zig_x = zx; zig_f = zf; exp_tab = et; }
+  LBFT_HD void attach_peer_list(u8* list) { plist_lds = list; }
   LBFT_HD void attach_round_tables(const u8* leaders, u32 nl, const i64* durs, u32 nd) { leader_lds = leaders; leader_lds_len = nl; dur_lds = durs; dur_lds_len = nd; }
 
   LBFT_HD u32 boff(u32 w) const { return (w << 8) + lane4; }  // tile-relative byte offset of row w (a tile is < 4 GiB)
@@ -1444,12 +1445,14 @@ struct SimT {
   // n <= 16: sixteen 4-bit entries in one 64-bit register (a dynamically indexed array would be a
   // 32-way select chain per access); larger networks keep the list in a per-instance HBM row region.
   u64 plist;
+  u8* plist_lds;  // n > 16: this instance's 128-byte list in LDS (device); nullptr = the HBM row region
   LBFT_HD u32 peer(u32 i) const {
     if (packed()) return (u32)(plist >> (4 * i)) & 15u;
+    if (plist_lds) return plist_lds[i];
     return ld(P.off_list + i);
   }
   LBFT_HD void peers_one(u32 a) {
-    if (packed()) plist = a; else st(P.off_list, a);
+    if (packed()) plist = a; else if (plist_lds) plist_lds[0] = (u8)a; else st(P.off_list, a);
   }
   LBFT_HD u32 peers_all_but(u32 node) {  // all other nodes in index order
     if (packed()) {
@@ -1457,6 +1460,9 @@ struct SimT {
       u64 low = node ? (ident & ((1ULL << (4 * node)) - 1)) : 0;
       u64 high = node < 15 ? ((ident >> (4 * (node + 1))) << (4 * node)) : 0;
       plist = low | high;
+    } else if (plist_lds) {
+      u32 c = 0;
+      for (u32 i = 0; i < P.n; i++) if (i != node) plist_lds[c++] = (u8)i;
     } else {
       u32 c = 0;
       for (u32 i = 0; i < P.n; i++) if (i != node) st(P.off_list + c++, i);
@@ -1469,6 +1475,9 @@ struct SimT {
       if (packed()) {
         u64 x = ((plist >> (4 * i)) ^ (plist >> (4 * j))) & 15ULL;
         plist ^= (x << (4 * i)) | (x << (4 * j));
+      } else if (plist_lds) {
+        u8 a = plist_lds[i], b = plist_lds[j];
+        plist_lds[i] = b; plist_lds[j] = a;
       } else {
         u32 a = ld(P.off_list + i), b = ld(P.off_list + j);
         st(P.off_list + i, b); st(P.off_list + j, a);

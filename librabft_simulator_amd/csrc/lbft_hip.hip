@@ -52,10 +52,15 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restr
 #define LBFT_LDS_DURS 128      // entries of the duration table kept in LDS (i64)
 #define LBFT_TABLE_U64 (257 + 257 + 256 + LBFT_LDS_DURS + LBFT_LDS_LEADERS / 8)
 
-static inline size_t run_lds_bytes(u32 ql, u32 lpw) {
-  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * ql * lpw * 12 + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8;  // + diagnostics
+// [tables][queue keys][queue metas][diagnostics: LBFT_NPHASES u64 per wavefront][n > 16: one 128-byte receiver list per instance]
+static inline size_t run_lds_bytes(u32 ql, u32 lpw, u32 n = 0) {
+  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * ql * lpw * 12 + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8 + 8 +
+         (n > 16 ? (size_t)LBFT_RUN_WAVES * lpw * LBFT_MAX_NODES : 0);
 }
 
+__device__ __forceinline__ size_t run_lds_bytes_dev(u32 ql, u32 lpw) {  // = run_lds_bytes(ql, lpw, 0): where the receiver lists start
+  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * ql * lpw * 12 + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8 + 8;
+}
 template <int CLS>
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) void lbft_k_run(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) {
   extern __shared__ u64 lds[];
@@ -88,6 +93,10 @@ __global__ __launch_bounds__(LBFT_RUN_BLOCK) void lbft_k_run(Params p, u32* __re
       s.attach_queue(keys, metas, p.lpw, p.ql);
       s.attach_tables(t_zx, t_zf, t_et);
       s.attach_round_tables(t_leader, n_leader, t_dur, n_dur);
+      if (p.n > 16) {  // receiver / sender lists of process_node_actions: LDS instead of HBM rows
+        u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw);
+        s.attach_peer_list(lists + ((size_t)wave * p.lpw + lane) * LBFT_MAX_NODES);
+      }
       s.load_scalars();
       s.queue_to_lds();
 #if defined(LBFT_PHASE_TIMERS)
@@ -710,13 +719,13 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   if (wg_per_cu > 4) wg_per_cu = 4;
   size_t budget = (160u * 1024u) / wg_per_cu;
   // 2 KiB slack per workgroup: with less, two workgroups of 32-lane wavefronts do not become co-resident on a CU
-  u32 ql_auto = (u32)((budget - run_lds_bytes(0, lpw) - 2048) / (12u * LBFT_RUN_WAVES * lpw));
+  u32 ql_auto = (u32)((budget - run_lds_bytes(0, lpw, n) - 2048) / (12u * LBFT_RUN_WAVES * lpw));
   u32 ql = b->ql < 0 ? ql_auto : (u32)b->ql;
   if (ql > qcap) ql = qcap;
   if (p.qcal) ql = 0;  // the calendar lives in HBM rows
-  if (run_lds_bytes(ql, lpw) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
+  if (run_lds_bytes(ql, lpw, n) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
   p.ql = ql;
-  b->lds_bytes = run_lds_bytes(ql, lpw);
+  b->lds_bytes = run_lds_bytes(ql, lpw, n);
   p.prof = b->d_prof;
   return LBFT_OK;
 }
