@@ -374,8 +374,8 @@ struct SimT {
 #endif
 
   LBFT_HD SimT(const Params& p, u32* state, u32 i) : SimT(p, reinterpret_cast<char*>(state) + tile_offset_bytes(p, i), (i & 63u) * 4u, 0) {}
-  LBFT_HD SimT(const Params& p, char* tile_base, u32 lane_byte_offset, int) : P(p), tile(tile_base), lane4(lane_byte_offset), qk(nullptr), qm(nullptr), qstr(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab), plist_lds(nullptr),
-        leader_lds(nullptr), dur_lds(nullptr), leader_lds_len(0), dur_lds_len(0) {}
+  LBFT_HD SimT(const Params& p, char* tile_base, u32 lane_byte_offset, int) : P(p), tile(tile_base), lane4(lane_byte_offset), qk(nullptr), qm(nullptr), qstr(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab),
+        leader_lds(nullptr), dur_lds(nullptr), leader_lds_len(0), dur_lds_len(0), plist_lds(nullptr) {}
   LBFT_HD void attach_queue(u64* keys, u32* metas, u32 stride, u32 slots) {
     qk = keys; qm = metas; qstr = stride; ql = slots;
     LBFT_PIN_VGPR(qstr);
