@@ -1275,6 +1275,7 @@ struct SimT {
     u32 x1 = certs >> 16, x2 = certs & 0xffffu, cnt = 0;
     for (;;) {  // util.rs merge_sort of the two chains by descending round, identical certificates once
       Blk r1, r2;
+      for (u32 f = 0; f < BC_WORDS; f++) { r1.w[f] = 0; r2.w[f] = 0; }
       if (x1) { r1 = blk_get(x1); if (filter && known_round(k_hqc, k_hcc, r1.round())) x1 = 0; }
       if (x2) { r2 = blk_get(x2); if (filter && known_round(k_hqc, k_hcc, r2.round())) x2 = 0; }
       if (!x1 && !x2) break;
