@@ -129,6 +129,14 @@ struct Params {
 #define LBFT_MARK(k) do { } while (0)
 #define LBFT_COUNT(k) do { } while (0)
 #endif
+#if defined(LBFT_HOST_STATS) && !defined(__HIPCC__)
+extern unsigned long long lbft_host_stats[64];
+#define LBFT_STAT(k) (lbft_host_stats[k]++)
+#define LBFT_STATN(k, n) (lbft_host_stats[k] += (n))
+#else
+#define LBFT_STAT(k) do { } while (0)
+#define LBFT_STATN(k, n) do { } while (0)
+#endif
 
 // HBM layout: instances are grouped in tiles of 64 (one wavefront's worth); a tile is contiguous and holds
 // its rows word-interleaved: word w of instance i lives at byte (i / 64) * total_words * 256 + w * 256 +
@@ -175,7 +183,7 @@ enum BlockField : u32 {
   B_TIME = BC_WORDS, B_CMD, B_WORDS
 };
 #ifndef LBFT_BLK_CACHE
-#define LBFT_BLK_CACHE 4  // register-resident block records per instance (second-chance FIFO); measured at two wavefronts/SIMD: 3 -> 35.7 ms, 4 -> 35.0, 5 -> 35.6, 6 -> 36.6
+#define LBFT_BLK_CACHE 3  // register-resident block records per instance (second-chance FIFO); measured: 2 -> 29.2 ms, 3 -> 27.9, 4 -> 28.0 (19 spilled registers), 5 -> 29.8
 #endif
 
 // Snapshot (notification, data_sync.rs:16-39) rows; followed by tc_hcbr[n], to_hcbr[n].
@@ -467,13 +475,15 @@ struct SimT {
 #pragma unroll
 #endif
     for (u32 e = 0; e < LBFT_BLK_CACHE; e++) {
-      if (bc_next == e) {
-        bc_id[e] = b;
+      // value selects at fixed entries, NOT `if (hand == e) entry[e] = r`: the compiler sinks such conditional stores
+      // into one store through a phi of entry addresses, and an array addressed that way is no longer promoted to
+      // registers (the whole cache ended up in scratch memory: 32 scratch loads per lookup)
+      bool take = bc_next == e;
+      bc_id[e] = take ? b : bc_id[e];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-        for (u32 f = 0; f < BC_WORDS; f++) bc_w[e][f] = r.w[f];
-      }
+      for (u32 f = 0; f < BC_WORDS; f++) bc_w[e][f] = take ? r.w[f] : bc_w[e][f];
     }
     bc_next = bc_next + 1 == LBFT_BLK_CACHE ? 0 : bc_next + 1;
   }
@@ -530,12 +540,12 @@ struct SimT {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (u32 e = 0; e < LBFT_BLK_CACHE; e++)
-      if (bc_id[e] == b) {
-        if (f == B_KNOWN) bc_w[e][B_KNOWN] = v;
-        else if (f == B_QC) bc_w[e][B_QC] = v;
-        else bc_w[e][B_PEND] = v;
-      }
+    for (u32 e = 0; e < LBFT_BLK_CACHE; e++) {  // (value selects: see blk_cache_insert)
+      bool hit = bc_id[e] == b;
+      if (f == B_KNOWN) bc_w[e][B_KNOWN] = hit ? v : bc_w[e][B_KNOWN];
+      else if (f == B_QC) bc_w[e][B_QC] = hit ? v : bc_w[e][B_QC];
+      else bc_w[e][B_PEND] = hit ? v : bc_w[e][B_PEND];
+    }
   }
   LBFT_HD u32 sfw(u32 slot, u32 f) const { return P.off_snap + slot * P.snap_words + f; }
   // extension word k >= 1 of a snapshot's TC (which = 0) / current-timeout (which = 1) author set
@@ -1103,6 +1113,7 @@ struct SimT {
     // The walk below starts at the grandparent of the commit-certificate block, whose round is exactly
     // highest_committed_round (update_commit_3chain_round sets both together): nothing new to commit.
     if (nf(node, NF_HC_ROUND) <= after) return;
+    LBFT_STAT(11);
     // committed_states_after (record_store.rs:557-574): from the grandparent of the commit-certificate
     // block back to the first block whose round is <= `after`
     u32 start = blk_get(nf(node, NF_HCC_BLK)).pp(), k = 1;
@@ -1173,12 +1184,15 @@ struct SimT {
     Actions act;
     act.next = pa.next; act.send_to = pa.send_to; act.broadcast = pa.broadcast; act.query_all = pa.query_all;
     // process_pacemaker_actions (node.rs:179-202)
+    LBFT_STAT(5);
     if (pa.create_timeout) {
+      LBFT_STAT(6);
       insert_timeout(node, node, pa.timeout_round, nf(node, NF_HQC_ROUND));  // create_timeout record_store.rs:636-649
       u32 lvr = nf(node, NF_LVR);
       if (pa.timeout_round > lvr) nfs(node, NF_LVR, pa.timeout_round);
     }
     if (pa.propose) {
+      LBFT_STAT(7);
       propose_block(node, pa.propose_prev, lclock);
       // extension (E1): an equivocator proposes a second block B on the same previous QC; B = A + 1 becomes its
       // current proposed block, so the twin of an equivocator's own proposal is always "proposed block - 1"
@@ -1188,6 +1202,7 @@ struct SimT {
     // vote
     u32 pb = proposed_block(node);
     if (pb) {
+      LBFT_STAT(8);
       Blk rpb = blk_get(pb);
       u32 br = rpb.round();
       u32 prev_round = rpb.prev_round();  // previous_round (record_store.rs:588-598)
@@ -1196,13 +1211,15 @@ struct SimT {
         nfs(node, NF_LVR, br);
         u32 second_prev = rpb.pp_round();  // second_previous_round (record_store.rs:600-609)
         if (second_prev > locked) nfs(node, NF_LOCKED, second_prev);
+        LBFT_STAT(9);
         if (create_vote(node, pb, rpb)) act.send_to = (i32)rpb.author();
       }
     }
     LBFT_MARK(8);
-    if (check_for_new_qc(node)) { act.broadcast = true; act.next = lclock; }
+    if (check_for_new_qc(node)) { LBFT_STAT(10); act.broadcast = true; act.next = lclock; }
     LBFT_MARK(9);
     process_commits(node);
+    LBFT_MARK(27);
     bool tq; i64 tnext;
     update_tracker(node, lqat, lclock, tq, tnext);
     act.query_all = act.query_all || tq;
@@ -1397,6 +1414,7 @@ struct SimT {
     for (u32 k = 0; k < 2; k++) {
       u32 c = k ? p1 : p0;
       if (!c) break;
+      LBFT_STAT(32 + k);
       u32 b = c & 0xffffu;
       Blk r = blk_get(b);
       u32 qe = r.epoch();
@@ -1409,7 +1427,7 @@ struct SimT {
     if (n_epoch == epoch) {
       u32 pv = sn.w[S_PROP_VOTE];
       u32 pb = pv & 0xffffu, vote = pv >> 16;
-      if (pb) insert_block(node, pb);
+      if (pb) { LBFT_STAT(34); insert_block(node, pb); }
       LBFT_MARK(22);
       u32 tc_round = sn.w[S_TC_ROUND], to_round = sn.w[S_TO_ROUND];
       // A timeout whose round is not the receiver's current round is rejected without side effects
@@ -1417,15 +1435,17 @@ struct SimT {
       // round differs from the current round on entry is skipped as a whole -- which is the common case, because
       // every notification keeps carrying the sender's last timeout certificate (data_sync.rs:93-96).
       if (tc_round == nf(node, NF_CUR_ROUND)) {
+        LBFT_STAT(35);
         insert_timeouts(node, slot, S_FIXED_WORDS, sn.w[S_TC_MASK], tc_round);
         for (u32 k = 1; wide() && k < P.mw; k++) insert_timeouts(node, slot, S_FIXED_WORDS, ld(sxw(slot, 0, k)), tc_round, 32 * k);
       }
       if (to_round == nf(node, NF_CUR_ROUND)) {
+        if (sn.w[S_TO_MASK]) LBFT_STAT(36);
         insert_timeouts(node, slot, S_FIXED_WORDS + P.n, sn.w[S_TO_MASK], to_round);
         for (u32 k = 1; wide() && k < P.mw; k++) insert_timeouts(node, slot, S_FIXED_WORDS + P.n, ld(sxw(slot, 1, k)), to_round, 32 * k);
       }
       LBFT_MARK(23);
-      if (vote) insert_vote(node, sender, vote, blk_get(vote));
+      if (vote) { LBFT_STAT(37); insert_vote(node, sender, vote, blk_get(vote)); }
       LBFT_MARK(24);
     }
     return should_sync;
@@ -1500,6 +1520,7 @@ struct SimT {
     // itself cancelled, and then so are the others.  So if the node's previously scheduled timer has the
     // same time (it is still pending: that time is > clock), only count the duplicate.
     if (t_new <= (i64)P.max_clock && (u32)t_new == nf(node, NF_LAST_TIMER_T)) {
+      LBFT_STAT(40);
       nfs(node, NF_TIMER_DUPS, nf(node, NF_TIMER_DUPS) + 1);
       nfs(node, NF_DUP_STAMP, stamp);
       stamp++;
@@ -1518,6 +1539,7 @@ struct SimT {
         }
         nfs(node, NF_LAST_TIMER_T, (u32)t_new);
       }
+      LBFT_STAT(41); if (t_new > (i64)P.max_clock) LBFT_STAT(42);
       push_event(t_new, 3, node, 0, 0);
     }
     LBFT_MARK(12);
@@ -1546,6 +1568,8 @@ struct SimT {
       if (act.query_all) n_b = P.n - 1;
     }
     u32 first_a = sp.response + sp.sync, first_b = first_a + n_a, total = first_b + n_b;
+    LBFT_STAT(16 + (total > 7 ? 7 : total)); LBFT_STATN(24, total);
+    if (sp.have_actions) { if (act.broadcast) LBFT_STAT(25); else if (n_a) LBFT_STAT(26); if (act.query_all) LBFT_STAT(27); if (sp.sync) LBFT_STAT(28); }
     i32 slot = -1, slot_twin = -1, rs = 0;
     u32 refs = 0, refs_twin = 0, rrefs = 0;
     bool equivocal = false;
@@ -1563,7 +1587,9 @@ struct SimT {
         rs = q1() ? make_request_slot(nf(node, NF_EPOCH), nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16)) : 0;
         peers_shuffle(n_b);
       }
+      LBFT_MARK(16);
       i64 t = (i64)clock + sample_delay();
+      LBFT_MARK(18);
       if (j < sp.response) {  // DataSyncResponseEvent back to the requester
         bool lost = net_lost(node, sender);
         if (q1()) {
@@ -1602,6 +1628,7 @@ struct SimT {
         if (net_lost(node, sd) || rs < 0) { stamp++; continue; }
         if (push_event(t, 1, node, sd, (u32)rs)) rrefs++;
       }
+      LBFT_MARK(19);
     }
     if (slot >= 0) { if (refs) st(P.off_snap_ref + (u32)slot, refs); else snap_free_slot((u32)slot); }
     if (slot_twin >= 0) { if (refs_twin) st(P.off_snap_ref + (u32)slot_twin, refs_twin); else snap_free_slot((u32)slot_twin); }
@@ -1685,6 +1712,7 @@ struct SimT {
       LBFT_DRAIN_VMEM();
       LBFT_MARK(1);
       if (kind == 3) {  // UpdateTimerEvent (simulator.rs:403-415)
+        LBFT_STAT(0);
         ev3 += 1 + slot;  // slot > 0: a materialised group of folded duplicates (see process_node_actions)
         if ((u32)clock == nf(node, NF_LAST_TIMER_T)) {  // folded duplicates of this timer
           if (nf(node, NF_TIMER_DUPS) != 0) {  // their pops follow, interleaved by stamp with the other timers of this time
@@ -1697,18 +1725,19 @@ struct SimT {
           nfs(node, NF_LAST_TIMER_T, 0xffffffffu);
         }
         if (clock <= (i32)nf(node, NF_IGNORE_UNTIL)) {  // cancelled timer
+          LBFT_STAT(1);
           do_update = false;
           end_node(node);
         }
         LBFT_MARK(2);
       } else if (kind == 0) {  // DataSyncNotifyEvent (simulator.rs:416-440)
-        ev0++;
+        ev0++; LBFT_STAT(2);
         sync = handle_notification(node, sender, slot, sn);
         snap_release(slot);
         if (q1()) { sp.sync_epoch = nf(node, NF_EPOCH); sp.sync_certs = nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16); }  // the request is created now (data_sync.rs:170-176)
         LBFT_MARK(3);
       } else if (kind == 1) {  // DataSyncRequestEvent (simulator.rs:441-453)
-        ev1++;
+        ev1++; LBFT_STAT(3);
         if (q1()) {
           // handle_request on the peer `sender` (data_sync.rs:183-207): its store now, plus what the request said
           u32 qb = sfw(slot, 0);
@@ -1726,7 +1755,7 @@ struct SimT {
         do_update = false;
         LBFT_MARK(4);
       } else {  // DataSyncResponseEvent (simulator.rs:454-466): under Q1 handle_response inserts nothing
-        ev2++;
+        ev2++; LBFT_STAT(4);
         if (q1()) {
           handle_response(node, sender, slot, (i64)clock - (i64)(i32)nf(node, NF_STARTUP));
           snap_release(slot);

@@ -61,8 +61,11 @@ static inline size_t run_lds_bytes(u32 ql, u32 lpw, u32 n = 0) {
 __device__ __forceinline__ size_t run_lds_bytes_dev(u32 ql, u32 lpw) {  // = run_lds_bytes(ql, lpw, 0): where the receiver lists start
   return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * ql * lpw * 12 + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8 + 8;
 }
+#ifndef LBFT_RUN_WAVES_PER_SIMD
+#define LBFT_RUN_WAVES_PER_SIMD 2  // register budget of the run kernel: 512 / 2 = 256 VGPRs + AGPRs per lane
+#endif
 template <int CLS>
-__global__ __launch_bounds__(LBFT_RUN_BLOCK) void lbft_k_run(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) {
+__global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD))) void lbft_k_run(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) {
   extern __shared__ u64 lds[];
   u64* t_zx = lds;
   u64* t_zf = lds + 257;
