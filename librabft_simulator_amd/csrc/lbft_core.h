@@ -75,6 +75,7 @@ struct Params {
   const u32* weights;  // voting rights (device table; unit_weights short-cuts it)
   u32 mw;              // mask words = ceil(n / 32)
   u32 qheap;           // event queue is a binary heap in the HBM rows (large networks) instead of the LDS-fronted array
+  u32 qpack;           // event queue entries are single packed 64-bit words (kernel class 0; set by compute_layout)
   u32 qcal;            // event queue is a calendar (one FIFO per (time, kind) bucket) -- needs max_clock <= LBFT_CAL_MAX_CLOCK
   u32 off_cal_head, off_cal_tail, off_cal_bm, cal_buckets;
   u32 total_votes, quorum;
@@ -178,7 +179,7 @@ enum NodeField : u32 {
 // epoch, the ledger depth and the three per-node knowledge masks.  B_TIME / B_CMD are only read when a
 // committed history is exported or hashed.
 enum BlockField : u32 {
-  B_ROUND = 0, B_LINK /* prev | author << 16 */, B_PREV_ROUND, B_PP /* grandparent block id */, B_PP_ROUND, B_EPOCH,
+  B_ROUND = 0, B_LINK /* prev | author << 16 */, B_PREV_ROUND, B_PP /* grandparent | great-grandparent << 16 (block ids) */, B_PP_ROUND, B_EPOCH,
   B_DEPTH /* commands in the ledger after this block */, B_KNOWN, B_QC, B_PEND, BC_WORDS,
   B_TIME = BC_WORDS, B_CMD, B_WORDS
 };
@@ -227,6 +228,7 @@ LBFT_HD int ctz32(u32 x) {
 
 // Rust `f64 as i64` (saturating; NaN -> 0).
 LBFT_HD i64 f64_to_i64_sat(double v) {
+  if (v >= 0.0 && v < 2147483648.0) return (i64)(i32)v;  // every sane delay: one hardware conversion (truncates toward zero)
   if (v != v) return 0;
   if (v >= 9223372036854775808.0) return INT64_MAX;
   if (v <= -9223372036854775808.0) return INT64_MIN;
@@ -351,6 +353,7 @@ struct SimT {
   LBFT_HD bool q1() const { return CLS != 0 && (P.quirks & 1u) != 0; }  // requests are answered by the peer with real payloads
   LBFT_HD bool cal() const { return CLS != 0 && P.qcal != 0; }
   LBFT_HD bool packed() const { return CLS == 0 ? true : (CLS == 2 ? false : P.n <= 16); }
+  LBFT_HD bool qpacked() const { return CLS == 0 ? true : (CLS == 3 ? P.qpack != 0 : false); }  // one-word queue entries
   const Params& P;
   char* tile;
   u32 lane4;
@@ -383,11 +386,36 @@ struct SimT {
 
   LBFT_HD SimT(const Params& p, u32* state, u32 i) : SimT(p, reinterpret_cast<char*>(state) + tile_offset_bytes(p, i), (i & 63u) * 4u, 0) {}
   LBFT_HD SimT(const Params& p, char* tile_base, u32 lane_byte_offset, int) : P(p), tile(tile_base), lane4(lane_byte_offset), qk(nullptr), qm(nullptr), qstr(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab),
-        leader_lds(nullptr), dur_lds(nullptr), leader_lds_len(0), dur_lds_len(0), plist_lds(nullptr) {}
+        leader_lds(nullptr), dur_lds(nullptr), leader_lds_len(0), dur_lds_len(0), hc(nullptr), plist_lds(nullptr) {}
   LBFT_HD void attach_queue(u64* keys, u32* metas, u32 stride, u32 slots) {
-    qk = keys; qm = metas; qstr = stride; ql = slots;
+    qk = keys; qm = metas; qstr = stride; ql = qpacked() ? (slots & ~7u) : slots;  // packed entries are scanned in batches of 8
     LBFT_PIN_VGPR(qstr);
     LBFT_PIN_VGPR(ql);
+  }
+  // highest_certified_block_round buffers of the nodes' timeouts (hcbr[node][2][n], behind the fixed node rows): for
+  // networks of <= 4 nodes in kernel class 0 the device keeps them in LDS for the duration of a launch (32 words per
+  // instance, lane-private column like the queue), because creating a notification copies them out on nearly every
+  // event and a row fetch there is a full memory round trip in the middle of the send loop.
+  u32* hc;  // nullptr = the HBM rows
+  LBFT_HD void attach_hcbr(u32* column) { hc = column; }
+  LBFT_HD bool hc_lds() const { return small_sets() && hc != nullptr; }
+  LBFT_HD u32 hc_get(u32 node, u32 buf, u32 a) const {
+    if (hc_lds()) return hc[(node * 8u + buf * 4u + a) * qstr];
+    return nfm(node, NF_FIXED_WORDS + buf * P.n + a);
+  }
+  LBFT_HD void hc_set(u32 node, u32 buf, u32 a, u32 v) const {
+    if (hc_lds()) hc[(node * 8u + buf * 4u + a) * qstr] = v;
+    else nfms(node, NF_FIXED_WORDS + buf * P.n + a, v);
+  }
+  LBFT_HD void hcbr_to_lds() const {
+    if (!hc_lds()) return;
+    for (u32 node = 0; node < P.n; node++)
+      for (u32 k = 0; k < 2 * P.n; k++) hc[(node * 8u + (k / P.n) * 4u + k % P.n) * qstr] = nfm(node, NF_FIXED_WORDS + k);
+  }
+  LBFT_HD void hcbr_from_lds() const {
+    if (!hc_lds()) return;
+    for (u32 node = 0; node < P.n; node++)
+      for (u32 k = 0; k < 2 * P.n; k++) nfms(node, NF_FIXED_WORDS + k, hc[(node * 8u + (k / P.n) * 4u + k % P.n) * qstr]);
   }
   LBFT_HD void attach_tables(const u64* zx, const u64* zf, const u64* et) { zig_x = zx; zig_f = zf; exp_tab = et; }
   LBFT_HD void attach_peer_list(u8* list) { plist_lds = list; }
@@ -427,11 +455,37 @@ struct SimT {
   }
   LBFT_HD void end_node(u32 node) const {
     u32 nb = boff(P.off_node + node * P.node_words);
+#if !defined(LBFT_END_NODE_PER_ROW)
+    // rows are written back by groups of fields that change together: 6 tests instead of 41 (A/B on the 65536 x 4 batch in
+    // one GPU call: 24.6 ms vs 25.1 ms per-row; writing all rows unconditionally had measured 9 % slower)
+    const u64 G[6] = {
+      (1ULL << NF_IGNORE_UNTIL) | (1ULL << NF_LAST_TIMER_T) | (1ULL << NF_TIMER_DUPS) | (1ULL << NF_DUP_STAMP),
+      (1ULL << NF_PROPOSED_BLK) | (1ULL << NF_CUR_ROUND) | (1ULL << NF_TO_MASK) | (1ULL << NF_TO_WEIGHT) | (1ULL << NF_ELECTION) |
+          (1ULL << NF_BAL0_BLK) | (1ULL << NF_BAL0_WEIGHT) | (1ULL << NF_BAL0_AUTHORS) | (1ULL << NF_BAL1_BLK) | (1ULL << NF_BAL1_WEIGHT) | (1ULL << NF_BAL1_AUTHORS),
+      (1ULL << NF_HQC_ROUND) | (1ULL << NF_HQC_BLK) | (1ULL << NF_HTC_ROUND) | (1ULL << NF_HC_ROUND) | (1ULL << NF_HCC_BLK) | (1ULL << NF_TC_MASK) | (1ULL << NF_TC_SEL),
+      (1ULL << NF_PM_EPOCH) | (1ULL << NF_PM_ROUND) | (1ULL << NF_PM_LEADER) | (1ULL << NF_PM_START) | (1ULL << NF_PM_DUR_LO) | (1ULL << NF_PM_DUR_HI),
+      (1ULL << NF_LVR) | (1ULL << NF_LOCKED) | (1ULL << NF_LQAT) | (1ULL << NF_TR_EPOCH) | (1ULL << NF_TR_HCR) | (1ULL << NF_TR_LCT) |
+          (1ULL << NF_NEXT_CMD) | (1ULL << NF_LAST_COMMITTED_BLK) | (1ULL << NF_NCOMMITS),
+      (1ULL << NF_STARTUP) | (1ULL << NF_EPOCH) | (1ULL << NF_INIT_STATE_BLK) | (1ULL << NF_PREV_EPOCH_HCC)};
+    static_assert(NF_FIXED_WORDS == 41, "field groups of end_node need updating");
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 g = 0; g < 6; g++)
+      if (cdirty & G[g]) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (u32 f = 0; f < NF_FIXED_WORDS; f++)
+          if ((G[g] >> f) & 1ULL) stf(nb, f, cw[f]);
+      }
+#else
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (u32 f = 0; f < NF_FIXED_WORDS; f++)
-      if ((cdirty >> f) & 1ULL) stf(nb, f, cw[f]);  // (storing all 39 rows unconditionally measured 9 % slower)
+      if ((cdirty >> f) & 1ULL) stf(nb, f, cw[f]);
+#endif
   }
   LBFT_HD u32 bfw(u32 b, u32 f) const { return P.off_blk + (b - 1) * P.blk_words + f; }
   LBFT_HD u32 bf(u32 b, u32 f) const { return ld(bfw(b, f)); }   // cold fields (B_TIME, B_CMD) and read-back
@@ -449,7 +503,8 @@ struct SimT {
     LBFT_HD u32 prev() const { return w[B_LINK] & 0xffffu; }
     LBFT_HD u32 author() const { return w[B_LINK] >> 16; }
     LBFT_HD u32 prev_round() const { return w[B_PREV_ROUND]; }
-    LBFT_HD u32 pp() const { return w[B_PP]; }
+    LBFT_HD u32 pp() const { return w[B_PP] & 0xffffu; }
+    LBFT_HD u32 ppp() const { return w[B_PP] >> 16; }
     LBFT_HD u32 pp_round() const { return w[B_PP_ROUND]; }
     LBFT_HD u32 epoch() const { return w[B_EPOCH]; }
     LBFT_HD u32 depth() const { return w[B_DEPTH]; }
@@ -614,11 +669,29 @@ struct SimT {
   //      (ScheduledEvent::cmp, simulator.rs:149-161).  Events scheduled after max_clock can never
   //      run (loop_until breaks at the first one, simulator.rs:389) and are dropped at push time;
   //      they still consume a creation stamp.
+  // Packed entries (kernel class 0: n <= 16, scap <= 256, max_clock < 2^21): one 64-bit word per event,
+  //   [63:43] time  [42:41] 3 - kind  [40:16] creation stamp  [15:12] node  [11:8] sender  [7:0] snapshot slot
+  // Stamps are unique, so comparing whole words orders events exactly like (time, 3 - kind, stamp).  The LDS front then
+  // holds keys only (8 instead of 12 bytes per slot) and a pop reads one word per slot.  Unused LDS slots hold the
+  // sentinel ~0 (larger than any entry), so the scan needs no per-slot bound check and runs in batches of 8 loads.
+#define LBFT_QP_TIME_BITS 21
+#define LBFT_QP_STAMP_BITS 25
   LBFT_HD void q_set(u32 k, u64 key, u32 meta) const {
+    if (qpacked()) {
+      if (k < ql) qk[k * qstr] = key;
+      else { st(P.off_qhi + k, (u32)(key >> 32)); st(P.off_qlo + k, (u32)key); }
+      return;
+    }
     if (k < ql) { qk[k * qstr] = key; qm[k * qstr] = meta; }
     else { st(P.off_qhi + k, (u32)(key >> 32)); st(P.off_qlo + k, (u32)key); st(P.off_qmeta + k, meta); }
   }
   LBFT_HD void q_get(u32 k, u64& key, u32& meta) const {
+    if (qpacked()) {
+      meta = 0;
+      if (k < ql) key = qk[k * qstr];
+      else key = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k);
+      return;
+    }
     if (k < ql) { key = qk[k * qstr]; meta = qm[k * qstr]; }
     else { key = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k); meta = ld(P.off_qmeta + k); }
   }
@@ -627,14 +700,16 @@ struct SimT {
     u32 nl = qlen < ql ? qlen : ql;
     for (u32 k = 0; k < nl; k++) {
       qk[k * qstr] = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k);
-      qm[k * qstr] = ld(P.off_qmeta + k);
+      if (!qpacked()) qm[k * qstr] = ld(P.off_qmeta + k);
     }
+    if (qpacked()) for (u32 k = nl; k < ql; k++) qk[k * qstr] = ~0ULL;
   }
   LBFT_HD void queue_from_lds() const {
     u32 nl = qlen < ql ? qlen : ql;
     for (u32 k = 0; k < nl; k++) {
       u64 key = qk[k * qstr];
-      st(P.off_qhi + k, (u32)(key >> 32)); st(P.off_qlo + k, (u32)key); st(P.off_qmeta + k, qm[k * qstr]);
+      st(P.off_qhi + k, (u32)(key >> 32)); st(P.off_qlo + k, (u32)key);
+      if (!qpacked()) st(P.off_qmeta + k, qm[k * qstr]);
     }
   }
   // `reuse_stamp` != ~0u: the event takes that (already handed out, otherwise unused) creation stamp.
@@ -642,10 +717,12 @@ struct SimT {
     u32 my_stamp = reuse_stamp;
     if (reuse_stamp == ~0u) my_stamp = stamp++;
     if (time > (i64)P.max_clock) return false;
-    if (my_stamp >= (1u << 30)) { fault |= F_STAMP_OVERFLOW; return false; }
+    if (my_stamp >= (qpacked() ? (1u << LBFT_QP_STAMP_BITS) : (1u << 30))) { fault |= F_STAMP_OVERFLOW; return false; }
     if (qlen >= P.qcap) { fault |= F_QUEUE_OVERFLOW; return false; }
     u64 key = ((u64)(u32)time << 32) | ((3u - kind) << 30) | my_stamp;
     u32 meta = node | (sender << 8) | (slot << 16);
+    if (qpacked())
+      key = ((u64)(u32)time << 43) | ((u64)(3u - kind) << 41) | ((u64)my_stamp << 16) | (u64)((node << 12) | (sender << 8) | slot);
     if (cal()) {
       // Calendar queue: bucket = (time, kind) in pop order; creation stamps grow with every push, so appending
       // keeps each bucket sorted by stamp and the key never has to be stored or compared.  O(1), ~1 round trip.
@@ -738,6 +815,39 @@ struct SimT {
     u32 best = 0;
     u64 bkey = ~0ULL;
     u32 nl = qlen < ql ? qlen : ql;
+    if (qpacked()) {
+      // ql is a multiple of 8 and slots >= qlen hold the sentinel: eight independent loads in flight per batch, then a
+      // tree of compare-selects (a sequential min pays one LDS round trip per slot)
+      for (u32 k0 = 0; k0 < nl; k0 += 8) {
+        u64 kk[8];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (u32 j = 0; j < 8; j++) kk[j] = qk[(k0 + j) * qstr];
+        u64 m01 = kk[0] < kk[1] ? kk[0] : kk[1]; u32 i01 = kk[0] < kk[1] ? 0u : 1u;
+        u64 m23 = kk[2] < kk[3] ? kk[2] : kk[3]; u32 i23 = kk[2] < kk[3] ? 2u : 3u;
+        u64 m45 = kk[4] < kk[5] ? kk[4] : kk[5]; u32 i45 = kk[4] < kk[5] ? 4u : 5u;
+        u64 m67 = kk[6] < kk[7] ? kk[6] : kk[7]; u32 i67 = kk[6] < kk[7] ? 6u : 7u;
+        u64 m03 = m01 < m23 ? m01 : m23; u32 i03 = m01 < m23 ? i01 : i23;
+        u64 m47 = m45 < m67 ? m45 : m67; u32 i47 = m45 < m67 ? i45 : i67;
+        u64 m07 = m03 < m47 ? m03 : m47; u32 i07 = m03 < m47 ? i03 : i47;
+        if (m07 < bkey) { bkey = m07; best = k0 + i07; }
+      }
+      for (u32 k = ql; k < qlen; k++) {  // spilled tail (rare when ql covers the high-water mark)
+        u64 key = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k);
+        if (key < bkey) { bkey = key; best = k; }
+      }
+      time = (i32)(u32)(bkey >> 43);
+      kind = 3u - ((u32)(bkey >> 41) & 3u);
+      ev_stamp = (u32)(bkey >> 16) & ((1u << LBFT_QP_STAMP_BITS) - 1u);
+      u32 lo = (u32)bkey;
+      meta = ((lo >> 12) & 15u) | (((lo >> 8) & 15u) << 8) | ((lo & 0xffu) << 16);
+      qlen--;
+      u64 lk = ~0ULL; u32 lm = 0;
+      if (best != qlen) { q_get(qlen, lk, lm); q_set(best, lk, 0); }
+      if (qlen < ql) qk[qlen * qstr] = ~0ULL;  // the vacated last slot becomes a sentinel again
+      return true;
+    }
 #if defined(__HIPCC__)
 #pragma unroll 4
 #endif
@@ -790,8 +900,9 @@ struct SimT {
     if (live > maxsnap) maxsnap = live;
     return (i32)ld(P.off_snap_free + snap_free);
   }
-  LBFT_HD void snap_release(u32 slot) {
-    u32 r = ld(P.off_snap_ref + slot) - 1;
+  LBFT_HD void snap_release(u32 slot) { snap_release(slot, ld(P.off_snap_ref + slot)); }
+  LBFT_HD void snap_release(u32 slot, u32 refs) {  // `refs` = the slot's reference count as loaded by the caller
+    u32 r = refs - 1;
     st(P.off_snap_ref + slot, r);
     if (r == 0) snap_free_slot(slot);
   }
@@ -810,8 +921,14 @@ struct SimT {
 
   // ---- leader / duration ----
   LBFT_HD u32 leader(u32 round) const {
-    if (round < leader_lds_len) return leader_lds[round];
-    if (round < P.leader_len) return P.leader_tab[round];
+    // One load through a SELECTED table pointer, not `if (..) return leader_lds[round]; if (..) return P.leader_tab[round];`:
+    // when the two pointer members happen to sit at the same offset of their structs, the optimiser merges the two
+    // branches into one load through a phi of `this` and `&P`, after which neither struct is promoted to registers any
+    // more (the whole simulator state silently moves to scratch memory; tests/test_abi.py guards the symptom).
+    if (round < P.leader_len) {
+      const u8* tab = round < leader_lds_len ? leader_lds : P.leader_tab;
+      return tab[round];
+    }
     return compute_leader(P.weights, P.n, P.total_votes, round);
   }
 
@@ -820,7 +937,19 @@ struct SimT {
     if (blk == nf(node, NF_LAST_COMMITTED_BLK)) return true;
     if (blk == 0) return false;
     Blk r = blk_get(blk);
-    return bm_test(blk, r, B_PEND, node);
+    return state_pending(node, blk, r);
+  }
+  // pending_ledger_states.contains(state of blk).  B_PEND records that the node has EVER computed the state; a commit
+  // removes the state from the map (simulated_context.rs:160-166), which is not recorded by clearing the bit (that
+  // would cost the commit a read-modify-write of an old block's row) but recognised here: the k-th commit of a node is
+  // the block of ledger depth k + 1 (every commit extends the previous one by one command), so a block has been
+  // committed iff the node's log holds it at its depth.  Only blocks at or below the committed depth -- forks and
+  // stragglers -- ever reach the log lookup.
+  LBFT_HD bool state_pending(u32 node, u32 blk, const Blk& r) const {
+    if (!bm_test(blk, r, B_PEND, node)) return false;
+    u32 d = r.depth();
+    if (d > nf(node, NF_NCOMMITS)) return true;
+    return ld(P.off_log + node * P.lcap + d - 1) != blk;
   }
   // RecordStoreState::compute_state (record_store.rs:426-454) + CommandExecutor::compute.
   // `rb` is the caller's copy of block b's record; its pending mask is updated in place.
@@ -946,7 +1075,7 @@ struct SimT {
     if (am_test(node, NF_TO_MASK, author)) return;
     am_set(node, NF_TO_MASK, author);
     u32 tc_sel = nf(node, NF_TC_SEL);
-    nfms(node, NF_FIXED_WORDS + (1u - tc_sel) * P.n + author, hcbr);
+    hc_set(node, 1u - tc_sel, author, hcbr);
     u32 w = nf(node, NF_TO_WEIGHT) + weight(author);
     nfs(node, NF_TO_WEIGHT, w);
     if (w >= P.quorum) {
@@ -997,7 +1126,7 @@ struct SimT {
     if (base) {  // denormalised ancestry: previous_round / second_previous_round (record_store.rs:588-609)
       Blk rp = blk_get(base);
       rb.w[B_DEPTH] = rp.depth() + 1;
-      if (prev_blk) { rb.w[B_PREV_ROUND] = rp.round(); rb.w[B_PP] = rp.prev(); rb.w[B_PP_ROUND] = rp.prev_round(); }
+      if (prev_blk) { rb.w[B_PREV_ROUND] = rp.round(); rb.w[B_PP] = rp.prev() | (rp.pp() << 16); rb.w[B_PP_ROUND] = rp.prev_round(); }
     }
     rb.w[B_EPOCH] = nf(node, NF_EPOCH);
     rb.w[B_KNOWN] = 0; rb.w[B_QC] = 0; rb.w[B_PEND] = 0;
@@ -1038,8 +1167,8 @@ struct SimT {
     if (round <= hccr) { fault |= F_INTERNAL; return 0; }
     u32 k = round - hccr;
     if (k >= P.dur_len) { fault |= F_DURATION_TABLE; k = P.dur_len - 1; }
-    if (k < dur_lds_len) return dur_lds[k];
-    return P.dur_tab[k];
+    const i64* tab = k < dur_lds_len ? dur_lds : P.dur_tab;  // (a selected pointer: see leader())
+    return tab[k];
   }
   LBFT_HD PmActions update_pacemaker(u32 node, i64 lqat, i64 lclock) {
     PmActions a;
@@ -1116,21 +1245,27 @@ struct SimT {
     LBFT_STAT(11);
     // committed_states_after (record_store.rs:557-574): from the grandparent of the commit-certificate
     // block back to the first block whose round is <= `after`
-    u32 start = blk_get(nf(node, NF_HCC_BLK)).pp(), k = 1;
-    // Its round is highest_committed_round > after: at least this block commits.  It is an old block that nothing else
-    // will look at again: fetch the four words the commit needs straight from its row (one burst; the rows are always
-    // current, the cache is write-through) instead of pulling the record through the cache and evicting a hot one.
+    Blk rh = blk_get(nf(node, NF_HCC_BLK));
+    u32 start = rh.pp(), k = 1;
+    // Its round is highest_committed_round > after: at least this block commits.  The usual case is that it extends the
+    // node's last commit directly -- then everything the commit needs is in the commit-certificate block's record
+    // (grandparent, great-grandparent, depth) and no old block row is touched: its parent IS the last committed block
+    // (so its round is `after` and the walk below would stop at once), and its state is pending (the node computed it
+    // before it could execute the parent, record_store.rs:426-454, and it has not been committed yet).
+    {
+      u32 base0 = rh.ppp() ? rh.ppp() : nf(node, NF_INIT_STATE_BLK);
+      if (base0 == nf(node, NF_LAST_COMMITTED_BLK)) { LBFT_STAT(12); commit_block(node, start, rh.depth() - 2); return; }
+    }
     Blk r0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (u32 f = 0; f < BC_WORDS; f++) r0.w[f] = 0;
-    {
+    {  // an old block that nothing else will look at again: straight from its row, not through the cache
       u32 sb = boff(bfw(start, 0));
       r0.w[B_LINK] = ldf(sb, B_LINK); r0.w[B_PREV_ROUND] = ldf(sb, B_PREV_ROUND);
       r0.w[B_DEPTH] = ldf(sb, B_DEPTH); r0.w[B_PEND] = ldf(sb, B_PEND);
     }
-    // the parent's round is denormalised in the record: the usual single-commit case needs no further lookups
     for (u32 x = (r0.prev() && r0.prev_round() > after) ? r0.prev() : 0; x;) {
       Blk rx = blk_get(x);
       if (rx.round() <= after) break;
@@ -1142,20 +1277,27 @@ struct SimT {
       for (u32 s = 0; s < j; s++) y = blk_get(y).prev();
       Blk ry = j == 0 ? r0 : blk_get(y);
       // SimulatedContext::commit (simulated_context.rs:160-185)
-      if (!bm_test(y, ry, B_PEND, node)) { fault |= F_COMMIT_UNKNOWN_STATE; return; }
+      if (!state_pending(node, y, ry)) { fault |= F_COMMIT_UNKNOWN_STATE; return; }
       u32 prev = ry.prev();
       u32 base = prev ? prev : nf(node, NF_INIT_STATE_BLK);
       if (base != nf(node, NF_LAST_COMMITTED_BLK)) { fault |= F_COMMIT_NOT_SUCCESSOR; return; }
-      bm_clr(y, ry, B_PEND, node);
+      if (commit_block(node, y, ry.depth())) break;
+    }
+  }
+  // The tail of SimulatedContext::commit + the epoch switch of process_commits (node.rs:331-348) for one block whose
+  // state is pending and extends the last commit.  Returns true when no further block may be committed in this call
+  // (epoch change or full log).
+  LBFT_HD bool commit_block(u32 node, u32 y, u32 depth) {
+    {
       nfs(node, NF_LAST_COMMITTED_BLK, y);
       u32 nc = nf(node, NF_NCOMMITS);
-      if (nc >= P.lcap) { fault |= F_LOG_OVERFLOW; return; }
+      if (nc >= P.lcap) { fault |= F_LOG_OVERFLOW; return true; }
       st(P.off_log + node * P.lcap + nc, y);
       nfs(node, NF_NCOMMITS, nc + 1);
       // read_epoch_id (simulated_context.rs:199-207)
       // epoch = depth / commands_per_epoch; the (software) 64-bit division only runs when a boundary is crossed
-      if ((u64)ry.depth() >= ((u64)nf(node, NF_EPOCH) + 1) * P.cpe) {
-        u64 new_epoch = (u64)ry.depth() / P.cpe;
+      if ((u64)depth >= ((u64)nf(node, NF_EPOCH) + 1) * P.cpe) {
+        u64 new_epoch = (u64)depth / P.cpe;
         // fresh RecordStoreState for the new epoch (node.rs:331-348, record_store.rs:169-198)
         if (q1()) {  // the store being retired stays readable for peers that ask later (past_record_stores, node.rs:43,339)
           u32 old_epoch = nf(node, NF_EPOCH);
@@ -1171,9 +1313,10 @@ struct SimT {
         nfs(node, NF_ELECTION, 0);
         clear_ballot(node);
         nfs(node, NF_LVR, 0); nfs(node, NF_LOCKED, 0);
-        break;
+        return true;
       }
     }
+    return false;
   }
 
   // ---- NodeState::update_node (node.rs:240-304) ----
@@ -1232,7 +1375,7 @@ struct SimT {
   // ---- DataSyncNode::create_notification (data_sync.rs:82-111) into snapshot slot ----
   // hcbr words of the authors in `mask` (author = author0 + bit): node buffer -> snapshot, four loads in flight at a
   // time (a load-store-load-store chain would be one memory round trip per author)
-  LBFT_HD void copy_hcbr(u32 node, u32 slot, u32 mask, u32 author0, u32 node_word0, u32 snap_word0) const {
+  LBFT_HD void copy_hcbr(u32 node, u32 slot, u32 mask, u32 author0, u32 buf, u32 snap_word0) const {
     while (mask) {
       u32 a[4], h[4], k = 0;
 #if defined(__HIPCC__)
@@ -1240,7 +1383,7 @@ struct SimT {
 #endif
       for (u32 j = 0; j < 4; j++) {
         a[j] = 0; h[j] = 0;
-        if (mask) { a[j] = author0 + ctz32(mask); mask &= mask - 1; h[j] = nfm(node, node_word0 + a[j]); k = j + 1; }
+        if (mask) { a[j] = author0 + ctz32(mask); mask &= mask - 1; h[j] = hc_get(node, buf, a[j]); k = j + 1; }
       }
 #if defined(__HIPCC__)
 #pragma unroll
@@ -1357,7 +1500,10 @@ struct SimT {
     if (!hcc && (P.quirks & 2u) && nf(node, NF_EPOCH) != 0) hcc = nf(node, NF_PREV_EPOCH_HCC);
     st(sfw(slot, S_CERTS), hcc | (nf(node, NF_HQC_BLK) << 16));
     u32 pb = proposed_block(node);
-    if (pb && blk_get(pb).author() != node) pb = 0;  // "Do not reshare other leaders' proposals."
+    // "Do not reshare other leaders' proposals."  current_proposed_block is only ever set to a block authored by the
+    // leader of its round (record_store.rs:469), and proposed_block() answers for the pacemaker's round: the author is
+    // the pacemaker's leader -- no block lookup.
+    if (pb && nf(node, NF_PM_LEADER) != node) pb = 0;
     if (twin && pb) pb -= 1;
     u32 vote = 0;  // current_vote(local author) (record_store.rs:762-764)
     if (am_test(node, NF_BAL0_AUTHORS, node)) vote = nf(node, NF_BAL0_BLK);
@@ -1371,19 +1517,24 @@ struct SimT {
     st(sfw(slot, S_TC_MASK), tcm);
     st(sfw(slot, S_TO_MASK), tom);
     u32 tc_sel = nf(node, NF_TC_SEL);
-    copy_hcbr(node, slot, tcm, 0, NF_FIXED_WORDS + tc_sel * P.n, S_FIXED_WORDS);
-    copy_hcbr(node, slot, tom, 0, NF_FIXED_WORDS + (1u - tc_sel) * P.n, S_FIXED_WORDS + P.n);
+    copy_hcbr(node, slot, tcm, 0, tc_sel, S_FIXED_WORDS);
+    copy_hcbr(node, slot, tom, 0, 1u - tc_sel, S_FIXED_WORDS + P.n);
     for (u32 k = 1; wide() && k < P.mw; k++) {  // authors >= 32 (n > 32 only): extension words of the two sets + their hcbr entries
       u32 tk = htc ? am_word(node, NF_TC_MASK, k) : 0, ok = am_word(node, NF_TO_MASK, k);
       st(sxw(slot, 0, k), tk);
       st(sxw(slot, 1, k), ok);
-      copy_hcbr(node, slot, tk, 32 * k, NF_FIXED_WORDS + tc_sel * P.n, S_FIXED_WORDS);
-      copy_hcbr(node, slot, ok, 32 * k, NF_FIXED_WORDS + (1u - tc_sel) * P.n, S_FIXED_WORDS + P.n);
+      copy_hcbr(node, slot, tk, 32 * k, tc_sel, S_FIXED_WORDS);
+      copy_hcbr(node, slot, ok, 32 * k, 1u - tc_sel, S_FIXED_WORDS + P.n);
     }
   }
 
   // ---- DataSyncNode::handle_notification (data_sync.rs:113-177); returns should_sync ----
-  struct Snap { u32 w[S_FIXED_WORDS]; };
+  // The words of a notification that the event loop fetches in ONE burst together with the receiver's node rows: the
+  // fixed words, the slot's reference count and (networks of <= 4 nodes) the highest_certified_block_round of the
+  // sender's current timeouts -- every later dependent fetch would be a memory round trip of its own, serialised
+  // with those of the lanes on other paths.
+  struct Snap { u32 w[S_FIXED_WORDS]; u32 refs; u32 to_hcbr[4]; };
+  LBFT_HD bool small_sets() const { return CLS == 0 && P.n <= 4; }
   LBFT_HD Snap load_snapshot(u32 slot) const {
     Snap sn;
     u32 sb = boff(P.off_snap + slot * P.snap_words);
@@ -1391,6 +1542,18 @@ struct SimT {
 #pragma unroll
 #endif
     for (u32 f = 0; f < S_FIXED_WORDS; f++) sn.w[f] = ldf(sb, f);
+    sn.refs = ld(P.off_snap_ref + slot);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 a = 0; a < 4; a++) sn.to_hcbr[a] = 0;
+    if (small_sets()) {
+      u32 hb = boff(P.off_snap + slot * P.snap_words + S_FIXED_WORDS + P.n);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 a = 0; a < 4; a++) sn.to_hcbr[a] = ldf(hb, a < P.n ? a : 0);
+    }
     return sn;
   }
   LBFT_HD bool handle_notification(u32 node, u32 sender, u32 slot, const Snap& sn) {
@@ -1441,6 +1604,13 @@ struct SimT {
       }
       if (to_round == nf(node, NF_CUR_ROUND)) {
         if (sn.w[S_TO_MASK]) LBFT_STAT(36);
+        if (small_sets()) {  // hcbr words already fetched with the notification
+          for (u32 m = sn.w[S_TO_MASK] & 15u; m; m &= m - 1) {  // (one inlined copy of insert_timeout, not one per author)
+            u32 a = ctz32(m);
+            u32 h = a == 0 ? sn.to_hcbr[0] : a == 1 ? sn.to_hcbr[1] : a == 2 ? sn.to_hcbr[2] : sn.to_hcbr[3];
+            insert_timeout(node, a, to_round, h);
+          }
+        } else
         insert_timeouts(node, slot, S_FIXED_WORDS + P.n, sn.w[S_TO_MASK], to_round);
         for (u32 k = 1; wide() && k < P.mw; k++) insert_timeouts(node, slot, S_FIXED_WORDS + P.n, ld(sxw(slot, 1, k)), to_round, 32 * k);
       }
@@ -1466,17 +1636,26 @@ struct SimT {
   // n <= 16: sixteen 4-bit entries in one 64-bit register (a dynamically indexed array would be a
   // 32-way select chain per access); larger networks keep the list in a per-instance HBM row region.
   u64 plist;
+  u32 plist8;     // n <= 8 in kernel class 0: eight 4-bit entries (64-bit variable shifts cost three instructions each)
   u8* plist_lds;  // n > 16: this instance's 128-byte list in LDS (device); nullptr = the HBM row region
+  LBFT_HD bool packed8() const { return CLS == 0 && P.n <= 8; }
   LBFT_HD u32 peer(u32 i) const {
+    if (packed8()) return (plist8 >> (4 * i)) & 15u;
     if (packed()) return (u32)(plist >> (4 * i)) & 15u;
     if (plist_lds) return plist_lds[i];
     return ld(P.off_list + i);
   }
   LBFT_HD void peers_one(u32 a) {
+    if (packed8()) plist8 = a; else
     if (packed()) plist = a; else if (plist_lds) plist_lds[0] = (u8)a; else st(P.off_list, a);
   }
   LBFT_HD u32 peers_all_but(u32 node) {  // all other nodes in index order
-    if (packed()) {
+    if (packed8()) {
+      const u32 ident = 0x76543210u;
+      u32 low = ident & ((1u << (4 * node)) - 1u);
+      u32 high = node < 7 ? ((ident >> (4 * (node + 1))) << (4 * node)) : 0;
+      plist8 = low | high;
+    } else if (packed()) {
       const u64 ident = 0xfedcba9876543210ULL;
       u64 low = node ? (ident & ((1ULL << (4 * node)) - 1)) : 0;
       u64 high = node < 15 ? ((ident >> (4 * (node + 1))) << (4 * node)) : 0;
@@ -1493,7 +1672,10 @@ struct SimT {
   LBFT_HD void peers_shuffle(u32 cnt) {  // rand 0.8 SliceRandom::shuffle (no draws when cnt < 2)
     for (u32 i = cnt; i-- > 1;) {
       u32 j = rng.gen_range_u32(i + 1);
-      if (packed()) {
+      if (packed8()) {
+        u32 x = ((plist8 >> (4 * i)) ^ (plist8 >> (4 * j))) & 15u;
+        plist8 ^= (x << (4 * i)) | (x << (4 * j));
+      } else if (packed()) {
         u64 x = ((plist >> (4 * i)) ^ (plist >> (4 * j))) & 15ULL;
         plist ^= (x << (4 * i)) | (x << (4 * j));
       } else if (plist_lds) {
@@ -1574,59 +1756,66 @@ struct SimT {
     u32 refs = 0, refs_twin = 0, rrefs = 0;
     bool equivocal = false;
     for (u32 j = 0; j < total; j++) {
-      if (j == first_a && n_a) {  // receivers.shuffle(rng) (simulator.rs:343): drawn right before their delays
-        if (act.broadcast) peers_all_but(node); else peers_one((u32)act.send_to);
-        peers_shuffle(n_a);
-        if (is_equivocator(node)) {  // (E2): does this notification carry one of the node's own (double) proposals?
+      // receivers.shuffle(rng) (simulator.rs:343) / create_request + senders.shuffle(rng) (simulator.rs:365-370): each
+      // drawn right before the delays of its list; one site for both lists (they never start at the same j)
+      bool start_a = j == first_a && n_a != 0, start_b = j == first_b && n_b != 0;
+      if (start_a || start_b) {
+        if (start_b || act.broadcast) peers_all_but(node); else peers_one((u32)act.send_to);
+        if (start_b) rs = q1() ? make_request_slot(nf(node, NF_EPOCH), nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16)) : 0;
+        peers_shuffle(start_a ? n_a : n_b);
+        if (start_a && is_equivocator(node)) {  // (E2): does this notification carry one of the node's own (double) proposals?
           u32 pb = proposed_block(node);
           equivocal = pb != 0 && blk_get(pb).author() == node;
         }
       }
-      if (j == first_b && n_b) {  // create_request, senders.shuffle(rng) (simulator.rs:365-370)
-        peers_all_but(node);
-        rs = q1() ? make_request_slot(nf(node, NF_EPOCH), nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16)) : 0;
-        peers_shuffle(n_b);
-      }
       LBFT_MARK(16);
       i64 t = (i64)clock + sample_delay();
       LBFT_MARK(18);
+      // Each kind of message only decides WHAT is scheduled; the event itself is pushed at one site below (four inlined
+      // copies of push_event, one per kind, would each run for the few lanes that need it).
+      // mode: 0 = nothing is scheduled but the creation stamp is consumed, 1 = push, 2 = nothing at all
+      u32 mode, which, pk, pto, pfrom, pslot = 0, preuse = ~0u;
       if (j < sp.response) {  // DataSyncResponseEvent back to the requester
+        which = 0; pk = 2; pto = node; pfrom = sender;
         bool lost = net_lost(node, sender);
-        if (q1()) {
-          i32 rslot = (i32)sp.resp_slot;  // -1 encoded as 0xffffffff: no slot was available
-          if (lost || rslot < 0) { stamp++; if (rslot >= 0) snap_free_slot((u32)rslot); }
-          else if (push_event(t, 2, node, sender, (u32)rslot)) st(P.off_snap_ref + (u32)rslot, 1);
-          else snap_free_slot((u32)rslot);
-        } else {
-          if (lost) stamp++; else push_event(t, 2, node, sender, 0);
-        }
+        if (q1()) { i32 rslot = (i32)sp.resp_slot; mode = (lost || rslot < 0) ? 0u : 1u; pslot = (u32)rslot; }  // -1: no slot was available
+        else mode = lost ? 0u : 1u;
       } else if (j < first_a) {  // the sync request (its stamp was reserved before the timer's)
+        which = 1; pk = 1; pto = node; pfrom = sender; preuse = sp.sync_stamp;
         i32 qs = q1() ? make_request_slot(sp.sync_epoch, sp.sync_certs) : 0;
-        if (net_lost(node, sender) || qs < 0) { if (q1() && qs >= 0) snap_free_slot((u32)qs); }
-        else if (push_event(t, 1, node, sender, (u32)qs, sp.sync_stamp)) { if (q1()) st(P.off_snap_ref + (u32)qs, 1); }
-        else if (q1()) snap_free_slot((u32)qs);
+        mode = (net_lost(node, sender) || qs < 0) ? 2u : 1u;
+        pslot = (u32)qs;
       } else if (j < first_b) {  // DataSyncNotifyEvent to receiver r
         u32 r = peer(j - first_a);
-        if (net_lost(node, r)) { stamp++; continue; }  // a lost message still consumes its creation stamp
-        if (equivocal && (r & 1u) == 0) {
+        pk = 0; pto = r; pfrom = node; which = 2;
+        if (net_lost(node, r)) mode = 0;  // a lost message still consumes its creation stamp
+        else if (equivocal && (r & 1u) == 0) {
+          which = 3;
           if (t <= (i64)P.max_clock && slot_twin == -1) {
             slot_twin = snap_alloc();
             if (slot_twin < 0) slot_twin = -2; else write_snapshot(node, (u32)slot_twin, true);
           }
-          if (slot_twin >= 0) { if (push_event(t, 0, r, node, (u32)slot_twin)) refs_twin++; }
-          else stamp++;
-          continue;
+          mode = slot_twin >= 0 ? 1u : 0u; pslot = (u32)slot_twin;
+        } else {
+          if (t <= (i64)P.max_clock && slot == -1) {
+            slot = snap_alloc();
+            if (slot < 0) slot = -2; else write_snapshot(node, (u32)slot);
+          }
+          mode = slot >= 0 ? 1u : 0u; pslot = (u32)slot;  // a dropped event still consumes a creation stamp
         }
-        if (t <= (i64)P.max_clock && slot == -1) {
-          slot = snap_alloc();
-          if (slot < 0) slot = -2; else write_snapshot(node, (u32)slot);
-        }
-        if (slot >= 0) { if (push_event(t, 0, r, node, (u32)slot)) refs++; }
-        else stamp++;  // dropped event still consumes a creation stamp
       } else {  // DataSyncRequestEvent to sender s (query_all)
         u32 sd = peer(j - first_b);
-        if (net_lost(node, sd) || rs < 0) { stamp++; continue; }
-        if (push_event(t, 1, node, sd, (u32)rs)) rrefs++;
+        which = 4; pk = 1; pto = node; pfrom = sd; pslot = (u32)rs;
+        mode = (net_lost(node, sd) || rs < 0) ? 0u : 1u;
+      }
+      bool pushed = false;
+      if (mode == 1) pushed = push_event(t, pk, pto, pfrom, pslot, preuse);
+      else if (mode == 0) stamp++;
+      if (which == 2) refs += pushed ? 1u : 0u;
+      else if (which == 3) refs_twin += pushed ? 1u : 0u;
+      else if (which == 4) rrefs += pushed ? 1u : 0u;
+      else if (q1() && (i32)pslot >= 0) {  // response / sync request under quirks bit 0: the slot travels with the event
+        if (pushed) st(P.off_snap_ref + pslot, 1); else snap_free_slot(pslot);
       }
       LBFT_MARK(19);
     }
@@ -1708,6 +1897,7 @@ struct SimT {
 #pragma unroll
 #endif
       for (u32 f = 0; f < S_FIXED_WORDS; f++) sn.w[f] = 0;
+      sn.refs = 0; sn.to_hcbr[0] = sn.to_hcbr[1] = sn.to_hcbr[2] = sn.to_hcbr[3] = 0;
       if (kind == 0) sn = load_snapshot(slot);
       LBFT_DRAIN_VMEM();
       LBFT_MARK(1);
@@ -1733,7 +1923,7 @@ struct SimT {
       } else if (kind == 0) {  // DataSyncNotifyEvent (simulator.rs:416-440)
         ev0++; LBFT_STAT(2);
         sync = handle_notification(node, sender, slot, sn);
-        snap_release(slot);
+        snap_release(slot, sn.refs);
         if (q1()) { sp.sync_epoch = nf(node, NF_EPOCH); sp.sync_certs = nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16); }  // the request is created now (data_sync.rs:170-176)
         LBFT_MARK(3);
       } else if (kind == 1) {  // DataSyncRequestEvent (simulator.rs:441-453)
@@ -1788,7 +1978,12 @@ struct SimT {
 
 typedef SimT<3> Sim;
 // The class lbft_k_run (and the host model) executes a batch with.
-inline int sim_class(const Params& p) { return p.n > 32 ? 2 : ((p.n <= 16 && !p.qheap && !p.equiv && !p.rcap && !p.drop_ppm && !p.part_size && !(p.quirks & 1u)) ? 0 : 1); }
+inline int sim_class(const Params& p) {
+  if (p.n > 32) return 2;
+  bool small = p.n <= 16 && !p.qheap && !p.equiv && !p.rcap && !p.drop_ppm && !p.part_size && !(p.quirks & 1u);
+  bool fits_packed_queue = p.max_clock < (1 << LBFT_QP_TIME_BITS) && p.scap <= 256;  // one-word queue entries
+  return small && fits_packed_queue ? 0 : 1;
+}
 
 // Row layout for a batch; fills the offset fields of `p` and returns words per instance.
 inline u32 compute_layout(Params& p) {
@@ -1814,6 +2009,7 @@ inline u32 compute_layout(Params& p) {
   p.off_arch = w; w += (p.quirks & 1u) ? p.n * p.ecap * p.snap_words : 0;
   p.off_sync = w; w += (p.quirks & 1u) ? p.bcap : 0;
   p.total_words = w;
+  p.qpack = sim_class(p) == 0 ? 1u : 0u;
   return w;
 }
 

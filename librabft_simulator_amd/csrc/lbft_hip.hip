@@ -48,24 +48,31 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restr
 #define LBFT_RUN_WAVES 4
 #endif
 #define LBFT_RUN_BLOCK (64 * LBFT_RUN_WAVES)
+#define LBFT_LDS_HCBR_WORDS 32  // class 0, n <= 4: hcbr[node][2][4] per instance
+#ifndef LBFT_PACKED_QL_MAX
+#define LBFT_PACKED_QL_MAX 64  // LDS slots per instance of the packed (class 0) queue: the 4-node bench workload peaks at 53 pending events
+#endif
 #define LBFT_LDS_LEADERS 1024  // rounds of the leader table kept in LDS (bytes)
 #define LBFT_LDS_DURS 128      // entries of the duration table kept in LDS (i64)
 #define LBFT_TABLE_U64 (257 + 257 + 256 + LBFT_LDS_DURS + LBFT_LDS_LEADERS / 8)
 
 // [tables][queue keys][queue metas][diagnostics: LBFT_NPHASES u64 per wavefront][n > 16: one 128-byte receiver list per instance]
-static inline size_t run_lds_bytes(u32 ql, u32 lpw, u32 n = 0) {
-  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * ql * lpw * 12 + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8 + 8 +
-         (n > 16 ? (size_t)LBFT_RUN_WAVES * lpw * LBFT_MAX_NODES : 0);
+// `slot_bytes`: 12 (key + meta) or 8 (packed one-word entries, kernel class 0)
+static inline size_t run_lds_bytes(u32 ql, u32 lpw, u32 n, u32 slot_bytes) {
+  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * ql * lpw * slot_bytes + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8 + 8 +
+         (n > 16 ? (size_t)LBFT_RUN_WAVES * lpw * LBFT_MAX_NODES : 0) +
+         (n <= 4 && slot_bytes == 8 ? (size_t)LBFT_RUN_WAVES * lpw * LBFT_LDS_HCBR_WORDS * 4 : 0);  // class 0, n <= 4: hcbr buffers
 }
 
-__device__ __forceinline__ size_t run_lds_bytes_dev(u32 ql, u32 lpw) {  // = run_lds_bytes(ql, lpw, 0): where the receiver lists start
-  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * ql * lpw * 12 + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8 + 8;
+__device__ __forceinline__ size_t run_lds_bytes_dev(u32 ql, u32 lpw, u32 slot_bytes) {  // = run_lds_bytes(ql, lpw, 0, ..): where the receiver lists start
+  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * ql * lpw * slot_bytes + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8 + 8;
 }
 #ifndef LBFT_RUN_WAVES_PER_SIMD
-#define LBFT_RUN_WAVES_PER_SIMD 2  // register budget of the run kernel: 512 / 2 = 256 VGPRs + AGPRs per lane
+#define LBFT_RUN_WAVES_PER_SIMD 2  // register budget of the class-0 run kernel: 512 / 2 = 256 VGPRs + AGPRs per lane (the
+                                   // large-network classes run one 8- or 16-lane wavefront per SIMD and may use all 512)
 #endif
 template <int CLS>
-__global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD))) void lbft_k_run(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) {
+__device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ state, u32* __restrict__ unfinished) {
   extern __shared__ u64 lds[];
   u64* t_zx = lds;
   u64* t_zf = lds + 257;
@@ -81,7 +88,8 @@ __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(
   __syncthreads();
   u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   u64* keys = lds + LBFT_TABLE_U64 + (size_t)wave * p.ql * p.lpw + lane;
-  u32* metas = reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)LBFT_RUN_WAVES * p.ql * p.lpw) + (size_t)wave * p.ql * p.lpw + lane;
+  u32* metas = reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)LBFT_RUN_WAVES * p.ql * p.lpw) + (size_t)wave * p.ql * p.lpw + lane;  // (CLS 0: unused, not allocated)
+  const u32 meta_words = CLS == 0 ? 0u : LBFT_RUN_WAVES * p.ql * p.lpw;
   // Only the first p.lpw lanes of a wavefront carry an instance (occupancy vs lane-utilisation knob).
   u32 i = (blockIdx.x * LBFT_RUN_WAVES + wave) * p.lpw + lane;
   bool active = lane < p.lpw && i < p.m;
@@ -97,21 +105,27 @@ __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(
       s.attach_tables(t_zx, t_zf, t_et);
       s.attach_round_tables(t_leader, n_leader, t_dur, n_dur);
       if (p.n > 16) {  // receiver / sender lists of process_node_actions: LDS instead of HBM rows
-        u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw);
+        u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, CLS == 0 ? 8u : 12u);
         s.attach_peer_list(lists + ((size_t)wave * p.lpw + lane) * LBFT_MAX_NODES);
+      }
+      if (CLS == 0 && p.n <= 4) {  // the nodes' hcbr buffers (same place as the receiver lists of large networks)
+        u32* hcb = reinterpret_cast<u32*>(reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 8u));
+        s.attach_hcbr(hcb + (size_t)wave * LBFT_LDS_HCBR_WORDS * p.lpw + lane);
       }
       s.load_scalars();
       s.queue_to_lds();
+      s.hcbr_to_lds();
 #if defined(LBFT_PHASE_TIMERS)
       // per-wavefront accumulators behind the queue columns (8-byte aligned: the meta area is a multiple of 8 words)
       u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)LBFT_RUN_WAVES * p.ql * p.lpw) +
-                                          (size_t)LBFT_RUN_WAVES * p.ql * p.lpw + (p.ql * p.lpw & 1u ? 1 : 0)) + wave * LBFT_NPHASES;
+                                          (size_t)meta_words + (meta_words & 1u)) + wave * LBFT_NPHASES;
       if (lane == 0) { for (int k = 0; k < LBFT_NPHASES; k++) wprof[k] = 0; wprof[31] = __builtin_readcyclecounter(); }
       s.wprof = wprof;
       u64 t_begin = __builtin_readcyclecounter();
 #endif
       done = s.run();
       s.queue_from_lds();
+      s.hcbr_from_lds();
       s.store_scalars(done);
 #if defined(LBFT_PHASE_TIMERS)
       // every lane of a wavefront sees the wavefront's clock: the first active lane reports
@@ -126,6 +140,12 @@ __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(
   unsigned long long pending = __ballot(active && !done);
   if (pending && lane == (u32)(__ffsll((long long)pending) - 1)) atomicAdd(unfinished, (u32)__popcll(pending));
 }
+// Class 0 (the headline small-network path) is compiled for two wavefronts per SIMD; classes 1 and 2 run one 8- or 16-lane
+// wavefront per SIMD and may use the whole register file (VGPRs + AGPRs).
+__global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
+void lbft_k_run0(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { run_body<0>(p, state, unfinished); }
+template <int CLS>
+__global__ __launch_bounds__(LBFT_RUN_BLOCK) void lbft_k_run(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { run_body<CLS>(p, state, unfinished); }
 
 __device__ __forceinline__ u64 wave_sum(u64 v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -634,7 +654,7 @@ int lbft_batch_layout(const lbft_batch* b, uint32_t* out) {
   if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
   const Params& p = b->p;
   out[0] = p.node_words * 4;  // bytes of one node's rows (fixed rows + hcbr buffers + extension words)
-  out[1] = 12;                // bytes of one queued event (64-bit key + meta word)
+  out[1] = p.qpack ? 8 : 12;  // bytes of one queued event (packed word / 64-bit key + meta word)
   out[2] = p.snap_words * 4;  // bytes of one notification snapshot
   out[3] = p.blk_words * 4;   // bytes of one block record
   out[4] = p.total_words * 4; // HBM bytes per instance
@@ -722,13 +742,16 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   if (wg_per_cu > 4) wg_per_cu = 4;
   size_t budget = (160u * 1024u) / wg_per_cu;
   // 2 KiB slack per workgroup: with less, two workgroups of 32-lane wavefronts do not become co-resident on a CU
-  u32 ql_auto = (u32)((budget - run_lds_bytes(0, lpw, n) - 2048) / (12u * LBFT_RUN_WAVES * lpw));
+  u32 slot_bytes = p.qpack ? 8u : 12u;  // kernel class 0 keeps one-word entries
+  u32 ql_auto = (u32)((budget - run_lds_bytes(0, lpw, n, slot_bytes) - 2048) / (slot_bytes * LBFT_RUN_WAVES * lpw));
+  if (p.qpack && ql_auto > LBFT_PACKED_QL_MAX) ql_auto = LBFT_PACKED_QL_MAX;
   u32 ql = b->ql < 0 ? ql_auto : (u32)b->ql;
   if (ql > qcap) ql = qcap;
+  if (p.qpack) ql &= ~7u;  // scanned in batches of 8
   if (p.qcal) ql = 0;  // the calendar lives in HBM rows
-  if (run_lds_bytes(ql, lpw, n) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
+  if (run_lds_bytes(ql, lpw, n, slot_bytes) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
   p.ql = ql;
-  b->lds_bytes = run_lds_bytes(ql, lpw, n);
+  b->lds_bytes = run_lds_bytes(ql, lpw, n, slot_bytes);
   p.prof = b->d_prof;
   return LBFT_OK;
 }
@@ -766,12 +789,12 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
 static int launch_run(lbft_batch* b) {
   Params& p = b->p;
   int cls = sim_class(p);
-  const void* run_fn = cls == 0 ? reinterpret_cast<const void*>(lbft_k_run<0>)
+  const void* run_fn = cls == 0 ? reinterpret_cast<const void*>(lbft_k_run0)
                      : cls == 1 ? reinterpret_cast<const void*>(lbft_k_run<1>) : reinterpret_cast<const void*>(lbft_k_run<2>);
   HIP_TRY(hipFuncSetAttribute(run_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
   u32 grid_run = (u32)((b->m + (size_t)LBFT_RUN_WAVES * p.lpw - 1) / ((size_t)LBFT_RUN_WAVES * p.lpw));
   HIP_TRY(hipMemsetAsync(b->d_unfinished, 0, sizeof(u32), b->stream));
-  if (cls == 0) lbft_k_run<0><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  if (cls == 0) lbft_k_run0<<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (cls == 1) lbft_k_run<1><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else lbft_k_run<2><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   HIP_TRY(hipGetLastError());

@@ -87,10 +87,14 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
     std::vector<u64> keys(p.ql ? p.ql : 1);
     std::vector<u32> metas(p.ql ? p.ql : 1);
     s.attach_queue(keys.data(), metas.data(), 1, p.ql);
+    std::vector<u32> hcbr(32);  // the device's LDS copy of the hcbr buffers (class 0, n <= 4)
+    if (p.ql) s.attach_hcbr(hcbr.data());
     s.load_scalars();
     s.queue_to_lds();
+    s.hcbr_to_lds();
     bool done = s.run();
     s.queue_from_lds();
+    s.hcbr_from_lds();
     s.store_scalars(done);
   };
   int cls = caps->force_generic ? 3 : sim_class(p);

@@ -70,3 +70,54 @@ def test_fails_loudly_without_gpu(hiplib):
     with pytest.raises(LbftError) as e:
         Simulator.new(52, 3, RandomDelay.new(10.0, 4.0)).loop_until(1000)
     assert e.value.code == hiplib.LBFT_ERR_HIP
+
+
+def _kernel_metadata(so_path):
+    """name -> {private_segment_fixed_size, vgpr_count, vgpr_spill_count} of every gfx950 kernel in the library
+    (the code object is unbundled from .hip_fatbin and its AMDGPU metadata note read with llvm-readelf)."""
+    import struct
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    with tempfile.TemporaryDirectory() as d:
+        fat = os.path.join(d, "fat.bin")
+        subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", so_path, fat])
+        blob = open(fat, "rb").read()
+        assert blob.startswith(b"__CLANG_OFFLOAD_BUNDLE__")
+        n = struct.unpack_from("<Q", blob, 24)[0]
+        off, code = 32, None
+        for _ in range(n):
+            o, s, ts = struct.unpack_from("<QQQ", blob, off)
+            off += 24
+            triple = blob[off:off + ts].decode()
+            off += ts
+            if "gfx950" in triple:
+                code = blob[o:o + s]
+        assert code is not None, "no gfx950 code object in the library"
+        co = os.path.join(d, "dev.co")
+        open(co, "wb").write(code)
+        notes = subprocess.check_output([os.path.join(llvm, "llvm-readelf"), "--notes", co]).decode()
+    kernels = {}
+    for chunk in notes.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", chunk).group(1)
+        kernels[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, chunk).group(1))
+                         for k in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count")}
+    return kernels
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"), reason="needs the ROCm LLVM binutils")
+def test_run_kernels_keep_their_state_in_registers(hiplib):
+    """The event loop is one fully inlined function whose per-lane state (node cache, block cache, RNG) must be promoted
+    to registers.  Two innocent-looking source patterns have silently moved it to scratch memory before (conditional
+    stores to cache entries sunk into a phi of addresses; two table lookups merged into a load through a phi of `this`
+    and the kernel-argument block), costing 15 % and 3x: the headline kernel may spill a handful of registers (the state
+    itself is > 160 bytes) and must fit two wavefronts per SIMD (<= 256 registers)."""
+    kernels = _kernel_metadata(hiplib.LIB_PATH)
+    run0 = [v for k, v in kernels.items() if "lbft_k_run0" in k]
+    assert len(run0) == 1, sorted(kernels)
+    assert run0[0]["private_segment_fixed_size"] <= 64 and run0[0]["vgpr_spill_count"] <= 16, run0
+    assert run0[0]["vgpr_count"] <= 256, run0
+    big = [v for k, v in kernels.items() if "lbft_k_runILi" in k]
+    assert len(big) == 2, sorted(kernels)
+    for v in big:  # large-network classes: a handful of spilled registers at most, never the whole state
+        assert v["private_segment_fixed_size"] <= 128, big
