@@ -563,13 +563,18 @@ struct SimT {
       }
     }
     LBFT_COUNT(26);
+    LBFT_STAT(44);
     if (!hit) {
       LBFT_COUNT(25);
+      LBFT_STAT(45);
+      LBFT_MARK(28);  // (diagnostic builds: the time since the previous mark, so that 29 is the miss alone)
       u32 bb = boff(bfw(b, 0));
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
       for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = ldf(bb, f);  // one burst of independent loads
+      LBFT_DRAIN_VMEM();
+      LBFT_MARK(29);
       blk_cache_insert(b, r);
     }
     return r;
@@ -762,6 +767,7 @@ struct SimT {
   // Removes the minimum; returns false when the queue is empty.
   LBFT_HD bool pop_event(i32& time, u32& kind, u32& meta) {
     if (qlen == 0) return false;
+    LBFT_STAT(48 + (qlen > 56 ? 7 : qlen / 8));
     if (cal()) {  // first non-empty bucket at or after the cursor, head of its FIFO
       u32 w = cal_cursor >> 5;
       u32 raw = ld(P.off_cal_bm + w);
