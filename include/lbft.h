@@ -84,6 +84,13 @@ typedef struct lbft_config {
   uint32_t drop_per_million;
   uint32_t partition_size;
   int64_t partition_start, partition_end;
+  /* Epoch reconfiguration (extension; "We do not simulate changes in the voting rights yet", simulated_context.rs:209-216;
+   * the oracle is the specification).  EpochReader::configuration(state) gives author i the voting right
+   * voting_rights[(i + e * rights_rotation) % num_nodes] with e = read_epoch_id(state); 0 = the same rights in every epoch.
+   * The record store of epoch e counts votes / timeouts with these weights and elects its leaders over them
+   * (node.rs:331-348, configuration.rs:65-75).  Meaningful with commands_per_epoch small enough to change epochs and
+   * quirks = 3 (with the reference's quirks a network stalls at its first epoch change). */
+  uint32_t rights_rotation;
 } lbft_config;
 
 /* One entry of SimulatedContext::committed_history() (simulated_context.rs:31-35,98-100). */

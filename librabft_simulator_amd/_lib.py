@@ -47,6 +47,7 @@ class LbftConfig(C.Structure):
         ("partition_size", C.c_uint32),
         ("partition_start", C.c_int64),
         ("partition_end", C.c_int64),
+        ("rights_rotation", C.c_uint32),
     ]
 
 

@@ -84,6 +84,8 @@ struct Params {
   u32 drop_ppm, part_size;     // extension "lossy network" (include/lbft.h): random loss per million, partition cut
   i32 part_start, part_end;    // partition active while part_start <= clock < part_end
   u32 unit_weights;  // every voting right is 1 (the reference's SimulatedContext, simulated_context.rs:209-216)
+  u32 rot;           // extension: the voting rights of epoch e are weights[(i + e * rot) % n] (include/lbft.h); the leader table then
+                     // holds one table of leader_len rounds per shift 0..n-1
   u32 dur_len, leader_len;
   const i64* dur_tab;    // dur_tab[k] = (i64)(delta * pow(k, gamma)) computed by the host libm (pacemaker.rs:123)
   const u8* leader_tab;  // leader_tab[r] = PacemakerState::leader(r), filled by lbft_fill_leader_table
@@ -312,13 +314,16 @@ struct Sip13 {
 };
 
 // EpochConfiguration::pick_author(SipHash13(round)) (configuration.rs:65-75, pacemaker.rs:100-109)
-LBFT_HD u32 compute_leader(const u32* weights, u32 n, u32 total_votes, u64 round) {
+// `shift`: author a holds weights[(a + shift) % n] (rotating voting rights; 0 in the reference)
+LBFT_HD u32 compute_leader(const u32* weights, u32 n, u32 total_votes, u64 round, u32 shift = 0) {
   Rng r;
   r.seed(siphash13_u64(round));
   u64 target = r.gen_range_u64(total_votes);
+  u32 i = shift;
   for (u32 a = 0; a < n; a++) {
-    if (weights[a] > target) return a;
-    target -= weights[a];
+    if (weights[i] > target) return a;
+    target -= weights[i];
+    i = i + 1 == n ? 0 : i + 1;
   }
   return 0;  // unreachable
 }
@@ -923,19 +928,26 @@ struct SimT {
     return lost;
   }
   LBFT_HD bool is_equivocator(u32 node) const { return CLS != 0 && P.equiv != 0 && node % P.equiv == 0; }  // class 0: all honest
-  LBFT_HD u32 weight(u32 author) const { return P.unit_weights ? 1u : P.weights[author]; }  // vector load from a small table
+  // EpochConfiguration of the node's current epoch (extension "rotating voting rights": shifted by epoch * rot)
+  LBFT_HD u32 rights_shift(u32 node) const { return P.rot ? (u32)(((u64)nf(node, NF_EPOCH) * P.rot) % P.n) : 0u; }
+  LBFT_HD u32 weight(u32 node, u32 author) const {  // vector load from a small table
+    if (P.unit_weights) return 1u;
+    u32 i = author + rights_shift(node);
+    return P.weights[i >= P.n ? i - P.n : i];
+  }
 
   // ---- leader / duration ----
-  LBFT_HD u32 leader(u32 round) const {
+  LBFT_HD u32 leader(u32 node, u32 round) const {
+    u32 shift = rights_shift(node);
     // One load through a SELECTED table pointer, not `if (..) return leader_lds[round]; if (..) return P.leader_tab[round];`:
     // when the two pointer members happen to sit at the same offset of their structs, the optimiser merges the two
     // branches into one load through a phi of `this` and `&P`, after which neither struct is promoted to registers any
     // more (the whole simulator state silently moves to scratch memory; tests/test_abi.py guards the symptom).
     if (round < P.leader_len) {
-      const u8* tab = round < leader_lds_len ? leader_lds : P.leader_tab;
+      const u8* tab = (round < leader_lds_len && shift == 0) ? leader_lds : P.leader_tab + (size_t)shift * P.leader_len;
       return tab[round];
     }
-    return compute_leader(P.weights, P.n, P.total_votes, round);
+    return compute_leader(P.weights, P.n, P.total_votes, round, shift);
   }
 
   // ---- SimulatedContext (simulated_context.rs:102-158): is the ledger state `blk` available? ----
@@ -1037,7 +1049,7 @@ struct SimT {
       if (!bm_test(p, rp, B_QC, node)) return;
     }
     u32 r = rb.round();
-    if (r == nf(node, NF_CUR_ROUND) && leader(r) == rb.author()) nfs(node, NF_PROPOSED_BLK, b);
+    if (r == nf(node, NF_CUR_ROUND) && leader(node, r) == rb.author()) nfs(node, NF_PROPOSED_BLK, b);
     bm_set(b, rb, B_KNOWN, node);
   }
   LBFT_HD void insert_block(u32 node, u32 b) const {
@@ -1057,7 +1069,7 @@ struct SimT {
       nfs(node, NF_BAL0_BLK, b);
       am_set(node, NF_BAL0_AUTHORS, author);
       if (ongoing) {
-        u32 w = nf(node, NF_BAL0_WEIGHT) + weight(author);
+        u32 w = nf(node, NF_BAL0_WEIGHT) + weight(node, author);
         nfs(node, NF_BAL0_WEIGHT, w);
         if (w >= P.quorum) nfs(node, NF_ELECTION, 1u | (b << 8));
       }
@@ -1065,7 +1077,7 @@ struct SimT {
       nfs(node, NF_BAL1_BLK, b);
       am_set(node, NF_BAL1_AUTHORS, author);
       if (ongoing) {
-        u32 w = nf(node, NF_BAL1_WEIGHT) + weight(author);
+        u32 w = nf(node, NF_BAL1_WEIGHT) + weight(node, author);
         nfs(node, NF_BAL1_WEIGHT, w);
         if (w >= P.quorum) nfs(node, NF_ELECTION, 1u | (b << 8));
       }
@@ -1082,7 +1094,7 @@ struct SimT {
     am_set(node, NF_TO_MASK, author);
     u32 tc_sel = nf(node, NF_TC_SEL);
     hc_set(node, 1u - tc_sel, author, hcbr);
-    u32 w = nf(node, NF_TO_WEIGHT) + weight(author);
+    u32 w = nf(node, NF_TO_WEIGHT) + weight(node, author);
     nfs(node, NF_TO_WEIGHT, w);
     if (w >= P.quorum) {
       // the current timeouts become the timeout certificate (record_store.rs:532-534): swap the buffers
@@ -1189,7 +1201,7 @@ struct SimT {
     i64 dur = (i64)(nf(node, NF_PM_DUR_LO) | ((u64)nf(node, NF_PM_DUR_HI) << 32));
     if (epoch > pe || (epoch == pe && ar > pm_round)) {
       pm_round = ar;
-      pm_leader = leader(ar);
+      pm_leader = leader(node, ar);
       start = lclock;
       dur = duration(node, ar);
       nfs(node, NF_PM_EPOCH, epoch); nfs(node, NF_PM_ROUND, ar); nfs(node, NF_PM_LEADER, pm_leader);

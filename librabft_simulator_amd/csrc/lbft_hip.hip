@@ -279,9 +279,12 @@ __global__ void lbft_k_node_op(Params p, u32* __restrict__ state, u32 op, u32 in
   s.store_scalars(s.ld(I_DONE) != 0);
 }
 
+// out[shift * len + r] = PacemakerState::leader(r) under the voting rights shifted by `shift` (blockIdx.y; one table when the
+// rights do not rotate)
 __global__ void lbft_k_fill_leaders(Params p, u8* __restrict__ out, u32 len) {
   u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < len) out[r] = (u8)compute_leader(p.weights, p.n, p.total_votes, r);
+  u32 shift = blockIdx.y;
+  if (r < len) out[(size_t)shift * len + r] = (u8)compute_leader(p.weights, p.n, p.total_votes, r, shift);
 }
 __global__ void lbft_k_sample_delays(Params p, u64 seed, i64* __restrict__ out, u32 n) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -381,6 +384,7 @@ static int fill_params(const lbft_config* cfg, size_t m, Params& p, std::vector<
   p.part_size = cfg->partition_size;
   p.part_start = (i32)(cfg->partition_start < 0 ? 0 : (cfg->partition_start > 0x7fffffff ? 0x7fffffff : cfg->partition_start));
   p.part_end = (i32)(cfg->partition_end < 0 ? 0 : (cfg->partition_end > 0x7fffffff ? 0x7fffffff : cfg->partition_end));
+  p.rot = cfg->rights_rotation % (cfg->num_nodes ? cfg->num_nodes : 1);
   p.total_votes = 0;
   weights.assign(p.n, 1);
   p.unit_weights = 1;
@@ -392,6 +396,7 @@ static int fill_params(const lbft_config* cfg, size_t m, Params& p, std::vector<
     if (w != 1) p.unit_weights = 0;
   }
   if (p.total_votes == 0) return LBFT_ERR_INVALID;
+  if (p.unit_weights) p.rot = 0;  // rotating equal rights changes nothing
   p.mw = (p.n + 31) / 32;
   p.quorum = 2 * p.total_votes / 3 + 1;  // quorum_threshold (configuration.rs:52-56)
   return LBFT_OK;
@@ -436,15 +441,16 @@ static int upload_tables(lbft_batch* b) {
   HIP_TRY(hipMalloc(&b->d_weights, b->weights.size() * sizeof(u32)));
   HIP_TRY(hipMemcpy(b->d_weights, b->weights.data(), b->weights.size() * sizeof(u32), hipMemcpyHostToDevice));
   b->p.weights = b->d_weights;
-  HIP_TRY(hipMalloc(&b->d_leaders, LBFT_LEADER_TABLE_LEN));
+  u32 leader_tables = b->p.rot ? b->p.n : 1;  // one per shift of the rotating voting rights
+  HIP_TRY(hipMalloc(&b->d_leaders, (size_t)leader_tables * LBFT_LEADER_TABLE_LEN));
   b->p.dur_tab = b->d_dur; b->p.dur_len = LBFT_DUR_TABLE_LEN;
   b->p.leader_tab = b->d_leaders; b->p.leader_len = 0;  // table not valid while it is being filled
   b->p.exp_tab = b->d_et; b->p.zig_x = b->d_zx; b->p.zig_f = b->d_zf;
-  lbft_k_fill_leaders<<<(LBFT_LEADER_TABLE_LEN + 255) / 256, 256, 0, b->stream>>>(b->p, b->d_leaders, LBFT_LEADER_TABLE_LEN);
+  lbft_k_fill_leaders<<<dim3((LBFT_LEADER_TABLE_LEN + 255) / 256, leader_tables), 256, 0, b->stream>>>(b->p, b->d_leaders, LBFT_LEADER_TABLE_LEN);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(b->stream));
   b->p.leader_len = LBFT_LEADER_TABLE_LEN;
-  b->table_bytes = sizeof(H_ZX) + sizeof(H_ZF) + sizeof(H_ET) + dur.size() * sizeof(i64) + LBFT_LEADER_TABLE_LEN;
+  b->table_bytes = sizeof(H_ZX) + sizeof(H_ZF) + sizeof(H_ET) + dur.size() * sizeof(i64) + (size_t)leader_tables * LBFT_LEADER_TABLE_LEN;
   return LBFT_OK;
 }
 
@@ -857,7 +863,7 @@ static void fill_header(const lbft_batch* b, CheckpointHeader& h) {
   h.n = p.n; h.qcap = p.qcap; h.scap = p.scap; h.bcap = p.bcap; h.lcap = p.lcap; h.rcap = p.rcap; h.total_words = p.total_words;
   h.equiv = p.equiv; h.m = b->m; h.cpe = c.commands_per_epoch; h.max_clock = b->started_max_clock; h.tci = c.target_commit_interval;
   h.delta = c.delta; h.uni_lo = c.uniform_lo; h.uni_hi = c.uniform_hi; h.mean = c.mean; h.variance = c.variance; h.gamma = c.gamma;
-  h.lambda = c.lambda; h.delay_model = c.delay_model; h.weights_hash = weights_hash(b->weights);
+  h.lambda = c.lambda; h.delay_model = c.delay_model; h.weights_hash = weights_hash(b->weights) ^ (p.rot * 0x9e3779b9u);
 }
 size_t lbft_batch_checkpoint_bytes(const lbft_batch* b) {
   if (!b || !b->started) return 0;

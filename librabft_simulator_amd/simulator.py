@@ -71,7 +71,7 @@ class NodeConfig:
 
 def make_config(num_nodes, network_delay, node_config, commands_per_epoch=30000, voting_rights=None,
                 queue_capacity=0, snapshot_capacity=0, block_capacity=0, log_capacity=0, equivocate_every=0,
-                drop_per_million=0, partition=None, quirks=0):
+                drop_per_million=0, partition=None, quirks=0, rights_rotation=0):
     cfg = LbftConfig()
     cfg.num_nodes = num_nodes
     cfg.delay_model = network_delay.model
@@ -87,6 +87,7 @@ def make_config(num_nodes, network_delay, node_config, commands_per_epoch=30000,
     cfg.quirks = int(quirks)
     cfg.equivocate_every = int(equivocate_every)
     cfg.drop_per_million = int(drop_per_million)
+    cfg.rights_rotation = int(rights_rotation)  # extension: epoch e uses voting_rights[(i + e * rights_rotation) % n]
     if partition is not None:  # (size of the first side, start, end): nodes [0, size) are cut off during [start, end)
         cfg.partition_size, cfg.partition_start, cfg.partition_end = (int(v) for v in partition)
     cfg.queue_capacity = queue_capacity
@@ -226,14 +227,15 @@ class BatchSimulator:
     def __init__(self, rng_seeds, num_nodes, network_delay, node_config=None, commands_per_epoch=30000,
                  voting_rights=None, device=0, queue_capacity=0, snapshot_capacity=0, block_capacity=0,
                  log_capacity=0, max_steps_per_launch=0, lanes_per_wavefront=0, lds_queue_slots=-1, equivocate_every=0, drop_per_million=0, partition=None,
-                 calendar_queue=True, quirks=0):
+                 calendar_queue=True, quirks=0, rights_rotation=0):
         seeds = np.ascontiguousarray(rng_seeds, dtype=np.uint64)
         self.seeds = seeds
         self.num_instances = int(seeds.shape[0])
         self.num_nodes = int(num_nodes)
         self.device = int(device)
         self._cfg = make_config(num_nodes, network_delay, node_config or NodeConfig(), commands_per_epoch, voting_rights,
-                                queue_capacity, snapshot_capacity, block_capacity, log_capacity, equivocate_every, drop_per_million, partition, quirks)
+                                queue_capacity, snapshot_capacity, block_capacity, log_capacity, equivocate_every, drop_per_million, partition, quirks,
+                                rights_rotation)
         self._h = C.c_void_p()
         check(_lib.lib().lbft_batch_create(C.byref(self._cfg), seeds.ctypes.data, self.num_instances, self.device,
                                            C.byref(self._h)))

@@ -63,6 +63,7 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   p.part_size = cfg->partition_size;
   p.part_start = (i32)(cfg->partition_start < 0 ? 0 : (cfg->partition_start > 0x7fffffff ? 0x7fffffff : cfg->partition_start));
   p.part_end = (i32)(cfg->partition_end < 0 ? 0 : (cfg->partition_end > 0x7fffffff ? 0x7fffffff : cfg->partition_end));
+  p.rot = cfg->rights_rotation % p.n;
   p.total_votes = 0;
   std::vector<u32> weights(p.n);
   for (u32 i = 0; i < p.n; i++) { weights[i] = cfg->voting_rights ? (u32)cfg->voting_rights[i] : 1; p.total_votes += weights[i]; }
@@ -70,12 +71,15 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   p.quorum = 2 * p.total_votes / 3 + 1;
   p.unit_weights = 1;
   for (u32 i = 0; i < p.n; i++) if (p.weights[i] != 1) p.unit_weights = 0;
+  if (p.unit_weights) p.rot = 0;
   std::vector<i64> dur(4096);
   for (size_t k = 0; k < dur.size(); k++) dur[k] = f64_to_i64_sat((double)cfg->delta * std::pow((double)k, cfg->gamma));
-  std::vector<u8> leaders(4096);
-  for (size_t r = 0; r < leaders.size(); r++) leaders[r] = (u8)compute_leader(p.weights, p.n, p.total_votes, r);
+  const u32 leader_len = 4096, leader_tables = p.rot ? p.n : 1;  // one table per shift of the rotating voting rights
+  std::vector<u8> leaders((size_t)leader_len * leader_tables);
+  for (u32 k = 0; k < leader_tables; k++)
+    for (u32 r = 0; r < leader_len; r++) leaders[(size_t)k * leader_len + r] = (u8)compute_leader(p.weights, p.n, p.total_votes, r, k);
   p.dur_tab = dur.data(); p.dur_len = (u32)dur.size();
-  p.leader_tab = leaders.data(); p.leader_len = (u32)leaders.size();
+  p.leader_tab = leaders.data(); p.leader_len = leader_len;
   p.exp_tab = ET; p.zig_x = ZX; p.zig_f = ZF;
   compute_layout(p);
   std::vector<u32> state(state_words(p), 0);

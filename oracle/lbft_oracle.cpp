@@ -351,6 +351,7 @@ struct Context {
   LedgerState last_committed;
   std::unordered_map<u64, LedgerState> pending;
   std::vector<u64> rights;  // extension; all 1 in the reference
+  u64 rights_rotation = 0;  // extension: the rights of epoch e are rights[(i + e * rights_rotation) % n] (lbft_oracle.h)
 
   Context(Author a, size_t n, u64 max_cmd, std::vector<u64> r)
       : author(a), num_nodes(n), max_command_per_epoch(max_cmd), rights(std::move(r)) {
@@ -391,9 +392,10 @@ struct Context {
     if (!s) panic("Read states should be known");
     return s->history.size() / max_command_per_epoch;
   }
-  EpochConfiguration configuration(u64 /*state*/) const {  // :209-216
+  EpochConfiguration configuration(u64 state) const {  // :209-216 ("We do not simulate changes in the voting rights yet.")
     std::vector<std::pair<Author, u64>> v;
-    for (size_t i = 0; i < num_nodes; i++) v.push_back({(Author)i, rights[i]});
+    u64 shift = rights_rotation ? (read_epoch_id(state) * rights_rotation) % num_nodes : 0;
+    for (size_t i = 0; i < num_nodes; i++) v.push_back({(Author)i, rights[(i + shift) % num_nodes]});
     return EpochConfiguration(v);
   }
   // simulated_context.rs:244-261
@@ -1154,6 +1156,7 @@ struct lbft_oracle_sim {
     for (u32 index = 0; index < c.num_nodes; index++) {
       // context_factory (main.rs:23-34): SimulatedContext::new + NodeState::make_initial_state(.., NodeTime(0))
       Context context((Author)index, c.num_nodes, c.commands_per_epoch, rights);
+      context.rights_rotation = c.rights_rotation;
       NodeState node = NodeState::make_initial_state(context, c, 0);
       node.equivocator = c.equivocate_every && index % c.equivocate_every == 0;
       i64 startup_time = clock + network_delay.sample(rng) + 1;

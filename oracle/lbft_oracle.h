@@ -42,6 +42,13 @@ typedef struct lbft_oracle_config {
   int64_t partition_start, partition_end; /* extension: GlobalTime interval [start, end) of the partition */
   uint32_t math_mode;             /* 0 = host libm (what the Rust reference calls); 1 = lbft_math.h (bit-identical to the HIP path) */
   const uint64_t* voting_rights;  /* NULL = all 1 (simulated_context.rs:209-216); else num_nodes weights (extension) */
+  uint32_t rights_rotation;       /* extension "epoch reconfiguration" (the reference: "We do not simulate changes in the voting
+                                     rights yet", simulated_context.rs:209-216).  SPECIFICATION: EpochReader::configuration(state)
+                                     gives author i the voting right voting_rights[(i + e * rights_rotation) % num_nodes], where
+                                     e = read_epoch_id(state); 0 = the same rights in every epoch.  Everything derived from the
+                                     configuration follows: the record store of epoch e counts votes and timeouts with these
+                                     weights (node.rs:331-348) and elects its leaders with pick_author over them
+                                     (configuration.rs:65-75, pacemaker.rs:100-109). */
 } lbft_oracle_config;
 
 /* Equivocators (extension; the reference has no Byzantine behaviour, simulator.rs:25 / data_sync.rs:120-122 only

@@ -34,6 +34,7 @@ class OracleConfig(C.Structure):
         ("partition_end", C.c_int64),
         ("math_mode", C.c_uint32),
         ("voting_rights", C.POINTER(C.c_uint64)),
+        ("rights_rotation", C.c_uint32),
     ]
 
 
@@ -161,7 +162,7 @@ def lib():
 def make_config(num_nodes=3, mean=10.0, variance=4.0, delay_model=0, uniform_lo=5, uniform_hi=15,
                 commands_per_epoch=30000, target_commit_interval=100000, delta=20, gamma=2.0,
                 lambda_=0.5, quirks=0, math_mode=0, voting_rights=None, equivocate_every=0, drop_per_million=0, partition_size=0,
-                partition_start=0, partition_end=0):
+                partition_start=0, partition_end=0, rights_rotation=0):
     """Defaults = the reference CLI defaults (librabft-v2/src/main.rs:73-140)."""
     cfg = OracleConfig()
     cfg.num_nodes = num_nodes
@@ -182,6 +183,7 @@ def make_config(num_nodes=3, mean=10.0, variance=4.0, delay_model=0, uniform_lo=
     cfg.partition_size = partition_size
     cfg.partition_start = partition_start
     cfg.partition_end = partition_end
+    cfg.rights_rotation = rights_rotation
     if voting_rights is not None:
         arr = (C.c_uint64 * num_nodes)(*voting_rights)
         cfg._keepalive = arr

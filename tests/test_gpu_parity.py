@@ -30,6 +30,7 @@ def run_gpu(amd, kw, seeds, max_clock, **sim_kw):
     sim = amd.BatchSimulator.new(seeds, n, delay, nc, commands_per_epoch=kw.get("commands_per_epoch", 30000),
                                  voting_rights=kw.get("voting_rights"), equivocate_every=kw.get("equivocate_every", 0),
                                  drop_per_million=kw.get("drop_per_million", 0), quirks=kw.get("quirks", 0),
+                                 rights_rotation=kw.get("rights_rotation", 0),
                                  partition=(kw["partition_size"], kw["partition_start"], kw["partition_end"]) if "partition_size" in kw else None,
                                  **sim_kw)
     return sim, sim.loop_until(max_clock)
@@ -99,6 +100,12 @@ CASES = {
     "q3fixed_n5_partition_heals": (dict(num_nodes=5, quirks=3, partition_size=2, partition_start=100, partition_end=400, commands_per_epoch=20), 64, 2500),
     "q3fixed_n36_cpe3": (dict(num_nodes=36, quirks=3, commands_per_epoch=3), 4, 300),
     "q1fixed_n7_equivocators_lossy": (dict(num_nodes=7, quirks=1, equivocate_every=3, drop_per_million=100000), 64, 1500),
+    # epoch reconfiguration (extension): the voting rights of epoch e are voting_rights[(i + e * rights_rotation) % n]
+    "rot1_n4_q3_cpe5": (dict(num_nodes=4, quirks=3, commands_per_epoch=5, voting_rights=[1, 2, 3, 4], rights_rotation=1), 128, 2500),
+    "rot3_n7_q3_cpe9": (dict(num_nodes=7, quirks=3, commands_per_epoch=9, voting_rights=[2, 1, 1, 3, 1, 2, 1], rights_rotation=3), 64, 2000),
+    "rot1_n4_q2_cpe7_class0": (dict(num_nodes=4, quirks=2, commands_per_epoch=7, voting_rights=[5, 1, 1, 1], rights_rotation=1), 128, 2000),
+    "rot5_n36_q3_cpe3": (dict(num_nodes=36, quirks=3, commands_per_epoch=3, voting_rights=[1 + (i % 3) for i in range(36)], rights_rotation=5), 4, 300),
+    "rot7_n100_q2_cpe2": (dict(num_nodes=100, quirks=2, commands_per_epoch=2, voting_rights=[1 + (i % 4) for i in range(100)], rights_rotation=7), 2, 200),
     "equiv_n5_weighted_epochs": (dict(num_nodes=5, equivocate_every=2, voting_rights=[1, 3, 1, 2, 2], commands_per_epoch=7), 64, 1500),
     "epoch_change_cpe50": (dict(num_nodes=4, commands_per_epoch=50), 128, 3000),
     "weighted": (dict(num_nodes=5, voting_rights=[5, 1, 1, 2, 3]), 128, 1000),

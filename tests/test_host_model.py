@@ -28,7 +28,7 @@ CASES = {
 # ql = event-queue slots held in the (emulated) LDS front: 0 = HBM rows only, 5 = almost everything
 # spills across the LDS/HBM boundary, 48 = the device default (the front covers the high-water mark at n <= 4)
 # scap = notification snapshot slots: <= 64 uses the register-resident free mask, larger the HBM free stack
-@pytest.mark.parametrize("ql,scap", [(0, 512), (5, 64), (48, 512)])
+@pytest.mark.parametrize("ql,scap", [(0, 512), (5, 64), (16, 64), (48, 64), (48, 512)])  # scap <= 256: packed one-word queue entries (class 0)
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_host_model_equals_oracle(oracle, name, ql, scap):
     kw, m, max_clock = CASES[name]
@@ -271,3 +271,51 @@ def test_host_model_q1_fixed(oracle, name):
     if name == "q3_n5_partition_heals":
         # with both quirks fixed a healed partition catches up (the reference semantics never do, see LOSSY partition test)
         assert (a["commit_counts"].min(axis=1) >= 25).mean() > 0.8
+
+
+# Epoch reconfiguration (extension): the voting rights of epoch e are voting_rights[(i + e * rights_rotation) % n]
+ROT = {
+    "rot1_n4_q3_cpe5": (dict(num_nodes=4, quirks=3, commands_per_epoch=5, voting_rights=[1, 2, 3, 4], rights_rotation=1), 64, 2500),
+    "rot3_n7_q3_cpe9": (dict(num_nodes=7, quirks=3, commands_per_epoch=9, voting_rights=[2, 1, 1, 3, 1, 2, 1], rights_rotation=3), 32, 2000),
+    "rot1_n4_q2_cpe7": (dict(num_nodes=4, quirks=2, commands_per_epoch=7, voting_rights=[5, 1, 1, 1], rights_rotation=1), 64, 2000),
+    "rot2_n5_reference_quirks": (dict(num_nodes=5, quirks=0, commands_per_epoch=10, voting_rights=[1, 1, 2, 2, 3], rights_rotation=2), 32, 1500),
+    "rot5_n36_q3_cpe3": (dict(num_nodes=36, quirks=3, commands_per_epoch=3, voting_rights=[1 + (i % 3) for i in range(36)], rights_rotation=5), 2, 300),
+    "rot1_n4_q3_lossy": (dict(num_nodes=4, quirks=3, commands_per_epoch=6, voting_rights=[1, 2, 3, 4], rights_rotation=1, drop_per_million=100000), 32, 2500),
+}
+
+
+@pytest.mark.parametrize("name", sorted(ROT))
+def test_host_model_rotating_voting_rights(oracle, name):
+    kw, m, max_clock = ROT[name]
+    n = kw["num_nodes"]
+    cfg = oracle.make_config(math_mode=1, **kw)
+    seeds = np.arange(7, 7 + m, dtype=np.uint64)
+    a = oracle.run_batch(cfg, seeds, max_clock, threads=8, history_cap=512)
+    b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=8, history_cap=512, qcap=max(4096, 16 * n * n), scap=max(128, 128 * n),
+                                   bcap=2048, lcap=2048, ql=13, qheap=1 if n > 4 else 0, qcal=1 if n > 4 and max_clock <= 2047 else 0)
+    assert not b["faults"].any()
+    for key in ("commit_counts", "active_rounds", "last_states", "histories"):
+        assert (a[key] == b[key]).all(), key
+    for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
+        assert a["counters"][key] == b["counters"][key], key
+    # the rotation really changes the run (other leaders, other quorums) ...
+    static = oracle.run_batch(oracle.make_config(math_mode=1, **dict(kw, rights_rotation=0)), seeds, max_clock, threads=8, history_cap=512)
+    if kw["quirks"] & 2:
+        assert (static["last_states"] != a["last_states"]).any()
+        # ... the networks cross many epochs ...
+        if n <= 7:
+            assert (a["commit_counts"].min(axis=1) >= 4 * kw["commands_per_epoch"]).mean() > 0.5
+    # ... and safety holds: the committed histories of the nodes of a network are prefixes of one another
+    cc, h = a["commit_counts"], a["histories"]
+    for i in range(m):
+        longest = h[i, int(np.argmax(cc[i]))]
+        for node in range(n):
+            c = min(int(cc[i, node]), 512)
+            assert (h[i, node, :c] == longest[:c]).all()
+
+
+def test_rotating_equal_rights_changes_nothing(oracle):
+    seeds = np.arange(1, 33, dtype=np.uint64)
+    base = oracle.run_batch(oracle.make_config(math_mode=1, num_nodes=4, quirks=3, commands_per_epoch=5), seeds, 1500, threads=8)
+    rot = oracle.run_batch(oracle.make_config(math_mode=1, num_nodes=4, quirks=3, commands_per_epoch=5, rights_rotation=1), seeds, 1500, threads=8)
+    assert (base["last_states"] == rot["last_states"]).all() and (base["commit_counts"] == rot["commit_counts"]).all()
