@@ -929,7 +929,9 @@ struct SimT {
   }
   LBFT_HD bool is_equivocator(u32 node) const { return CLS != 0 && P.equiv != 0 && node % P.equiv == 0; }  // class 0: all honest
   // EpochConfiguration of the node's current epoch (extension "rotating voting rights": shifted by epoch * rot)
-  LBFT_HD u32 rights_shift(u32 node) const { return P.rot ? (u32)(((u64)nf(node, NF_EPOCH) * P.rot) % P.n) : 0u; }
+  // (32-bit arithmetic: epochs are bounded by the block capacity 65534 and rot < n <= 128; a 64-bit modulo is a ~200-instruction
+  // software division inlined at every use)
+  LBFT_HD u32 rights_shift(u32 node) const { return P.rot ? (nf(node, NF_EPOCH) * P.rot) % P.n : 0u; }
   LBFT_HD u32 weight(u32 node, u32 author) const {  // vector load from a small table
     if (P.unit_weights) return 1u;
     u32 i = author + rights_shift(node);
