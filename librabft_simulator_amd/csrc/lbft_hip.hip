@@ -40,8 +40,11 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restr
 // [(g * 4 + w) * lpw, +lpw).  LDS (dynamic, up to the CU's whole 160 KiB):
 //   [zig_x 257][zig_f 257][exp_tab 256]  u64   read-only tables of the delay sampler, one copy per workgroup
 //   [dur 128] i64, [leader 1024] u8            pacemaker duration / leader tables (first rounds)
-//   keys  [wave][slot][lane]              u64   event-queue keys (time, 3-kind, stamp), lane-private columns
-//   metas [wave][slot][lane]              u32   (node, sender, snapshot slot)
+//   keys  [wave][slot][lane]              u64   event-queue keys, lane-private columns: class 0 one packed word per event
+//                                               (time | 3-kind | stamp | node | sender | slot), other classes (time, 3-kind, stamp)
+//   metas [wave][slot][lane]              u32   classes 1-2 only: (node, sender, snapshot slot)
+//   [diagnostic phase counters], then      --   n > 16: one 128-byte receiver list per instance; class 0 with n <= 4: the nodes'
+//                                               hcbr buffers, 32 words per instance ([wave][word][lane])
 // A lane only ever touches its own column (address = slot * lpw + lane), so data-dependent slot
 // indices are bank-conflict free and no workgroup barrier is needed after the table fill.
 #ifndef LBFT_RUN_WAVES
@@ -732,13 +735,14 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
     HIP_TRY(hipMalloc(&b->d_state, b->state_bytes));
   }
   // Lanes per wavefront that carry an instance.  The LDS queue front makes residency LDS-bound: one CU holds
-  // 160 KiB / (12 B * ql) instances however they are spread over wavefronts, so prefer full wavefronts
+  // 160 KiB / (bytes per instance) instances however they are spread over wavefronts, so prefer full wavefronts
   // unless the batch is too small to give every SIMD a wavefront.
   u32 lpw = b->lpw;
   if (lpw == 0) {
     u64 want = (b->m + 1023) / 1024;  // 256 CUs x 4 SIMDs
-    // measured: 8192 x 100 nodes 9.0 s at 16 lanes, 5.9 s at 8, 7.8 s at 4; 65536 x 4 nodes 40.0 ms at 64 lanes (one wavefront
-    // per SIMD), 36.5 ms at 32 (two per SIMD, which the 227-VGPR kernel still allows), 57 ms at 16 (would need four)
+    // measured: 8192 x 100 nodes 9.0 s at 16 lanes, 5.9 s at 8, 7.8 s at 4; 65536 x 4 nodes (r01_s3 build) 27.0 ms at 64 lanes
+    // (one wavefront per SIMD), 24.4 ms at 32 (two per SIMD: the class-0 kernel is compiled for 256 registers), 40.1 ms at
+    // 16 (would need four per SIMD).  A wavefront-step costs nearly the same at 16, 32 or 64 lanes (13.7 / 16.6 / 18.4 us).
     lpw = want <= 8 ? 8 : (want <= 16 ? 16 : 32);
   }
   p.lpw = lpw;
