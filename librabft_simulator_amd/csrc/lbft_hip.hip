@@ -706,7 +706,8 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   u32 qauto = n <= 16 ? 16 * n * n : 8 * n * n;
   u32 qcap = c.queue_capacity ? c.queue_capacity : (qauto < 128 ? 128 : qauto);
   // (quirks bit 0: every request and response in flight holds a slot as well)
-  u32 sauto = (c.quirks & 1u) ? 64 * n : 8 * n;
+  // (measured high-water marks with quirks bit 0: ~n^2 -- 400 at n = 20, 1250 at n = 36 -- and flat over the horizon)
+  u32 sauto = (c.quirks & 1u) ? (n * n + 8 * n > 64 * n ? n * n + 8 * n : 64 * n) : 8 * n;
   u32 scap = c.snapshot_capacity ? c.snapshot_capacity : (sauto < 32 ? 32 : (sauto > 65535 ? 65535 : sauto));
   // one block per round; a 1- or 2-node network can finish a round per time unit
   u64 bauto = n <= 2 ? (u64)max_clock + 64 : (u64)max_clock / 10 + 64;

@@ -51,8 +51,7 @@ def run(name, scale=1.0, reps=1, lpw=0):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    # c5b is opt-in: ~3 minutes of GPU time per run, and with the automatic capacities every instance runs out of
-    # notification snapshots (quirks bit 0 keeps every request / response in flight in a slot)
+    # c5b is opt-in: ~3 minutes of GPU time per run
     ap.add_argument("names", nargs="*", default=[n for n in CONFIGS if not n.startswith("c5b")])
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the configuration's instance count")
     ap.add_argument("--reps", type=int, default=1)
