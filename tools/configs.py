@@ -18,10 +18,11 @@ CONFIGS = {
     "c4_16384x64_longtail_equivocators": dict(instances=16384, nodes=64, max_clock=300, variance=400.0, equivocate_every=5),
     "c5_8192x100_weighted_epochs": dict(instances=8192, nodes=100, max_clock=300, weights=[1 + (i % 4) for i in range(100)],
                                         commands_per_epoch=50),
-    # same in the "fixed" protocol mode (quirks Q1 and Q2 fixed) with a horizon long enough to cross epochs (the reference
-    # semantics stall at the first change)
-    "c5b_1024x100_weighted_epochs_fixed": dict(instances=1024, nodes=100, max_clock=2000, weights=[1 + (i % 4) for i in range(100)],
-                                               commands_per_epoch=50, quirks=3),
+    # config 5 at max_clock 300 never reaches its first epoch change (~8 commits); this variant crosses epochs: the "fixed"
+    # protocol mode (quirks Q1 and Q2 fixed -- the reference semantics stall at the first change), an epoch every 10
+    # commands, and the voting rights rotating by one node per epoch (rights_rotation, the epoch-reconfiguration extension)
+    "c5b_1024x100_rotating_rights_epochs_fixed": dict(instances=1024, nodes=100, max_clock=600, weights=[1 + (i % 4) for i in range(100)],
+                                                      commands_per_epoch=10, quirks=3, rights_rotation=1),
 }
 
 
@@ -33,7 +34,8 @@ def run(name, scale=1.0, reps=1, lpw=0):
     seeds = np.arange(1, m + 1, dtype=np.uint64)
     delay = RandomDelay.uniform(*c["uniform"]) if "uniform" in c else RandomDelay.new(10.0, c.get("variance", 4.0))
     sim = BatchSimulator.new(seeds, c["nodes"], delay, NodeConfig(), commands_per_epoch=c.get("commands_per_epoch", 30000),
-                             voting_rights=c.get("weights"), equivocate_every=c.get("equivocate_every", 0), lanes_per_wavefront=lpw, quirks=c.get("quirks", 0))
+                             voting_rights=c.get("weights"), equivocate_every=c.get("equivocate_every", 0), lanes_per_wavefront=lpw, quirks=c.get("quirks", 0),
+                             rights_rotation=c.get("rights_rotation", 0))
     best = None
     for _ in range(reps):
         sim.reset()
@@ -51,7 +53,7 @@ def run(name, scale=1.0, reps=1, lpw=0):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    # c5b is opt-in: ~3 minutes of GPU time per run
+    # c5b is opt-in: about a minute of GPU time per run
     ap.add_argument("names", nargs="*", default=[n for n in CONFIGS if not n.startswith("c5b")])
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the configuration's instance count")
     ap.add_argument("--reps", type=int, default=1)
