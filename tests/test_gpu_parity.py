@@ -106,6 +106,7 @@ CASES = {
     "rot1_n4_q2_cpe7_class0": (dict(num_nodes=4, quirks=2, commands_per_epoch=7, voting_rights=[5, 1, 1, 1], rights_rotation=1), 128, 2000),
     "rot5_n36_q3_cpe3": (dict(num_nodes=36, quirks=3, commands_per_epoch=3, voting_rights=[1 + (i % 3) for i in range(36)], rights_rotation=5), 4, 300),
     "rot7_n100_q2_cpe2": (dict(num_nodes=100, quirks=2, commands_per_epoch=2, voting_rights=[1 + (i % 4) for i in range(100)], rights_rotation=7), 2, 200),
+    "rot7_n100_q3_cpe2": (dict(num_nodes=100, quirks=3, commands_per_epoch=2, voting_rights=[1 + (i % 4) for i in range(100)], rights_rotation=7), 2, 260),
     "equiv_n5_weighted_epochs": (dict(num_nodes=5, equivocate_every=2, voting_rights=[1, 3, 1, 2, 2], commands_per_epoch=7), 64, 1500),
     "epoch_change_cpe50": (dict(num_nodes=4, commands_per_epoch=50), 128, 3000),
     "weighted": (dict(num_nodes=5, voting_rights=[5, 1, 1, 2, 3]), 128, 1000),

@@ -280,6 +280,7 @@ ROT = {
     "rot1_n4_q2_cpe7": (dict(num_nodes=4, quirks=2, commands_per_epoch=7, voting_rights=[5, 1, 1, 1], rights_rotation=1), 64, 2000),
     "rot2_n5_reference_quirks": (dict(num_nodes=5, quirks=0, commands_per_epoch=10, voting_rights=[1, 1, 2, 2, 3], rights_rotation=2), 32, 1500),
     "rot5_n36_q3_cpe3": (dict(num_nodes=36, quirks=3, commands_per_epoch=3, voting_rights=[1 + (i % 3) for i in range(36)], rights_rotation=5), 2, 300),
+    "rot7_n100_q3_cpe2": (dict(num_nodes=100, quirks=3, commands_per_epoch=2, voting_rights=[1 + (i % 4) for i in range(100)], rights_rotation=7), 2, 260),
     "rot1_n4_q3_lossy": (dict(num_nodes=4, quirks=3, commands_per_epoch=6, voting_rights=[1, 2, 3, 4], rights_rotation=1, drop_per_million=100000), 32, 2500),
 }
 
