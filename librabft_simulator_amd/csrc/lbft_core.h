@@ -1867,7 +1867,11 @@ struct SimT {
       nfms(node, NF_PM_LEADER, LBFT_NO_LEADER);
       nfms(node, NF_LAST_TIMER_T, 0xffffffffu);
       i64 startup = 0 + sample_delay() + 1;
-      if (startup > (i64)P.max_clock + 1) startup = (i64)P.max_clock + 1;  // node never starts; equivalent
+      // A node whose startup lies beyond max_clock never runs its own timer, but it still receives notifications and may
+      // even propose: its NodeTime (clock - startup, negative) goes into its blocks, so the startup time must be exact
+      // (clamping it to max_clock + 1 changed the committed commands' times under long-tailed delays).  Only the 32-bit
+      // storage bounds it.
+      if (startup > 0x3fffffffLL) startup = 0x3fffffffLL;
       nfms(node, NF_STARTUP, (u32)(i32)startup);
       nfms(node, NF_IGNORE_UNTIL, (u32)(i32)(startup - 1));
       push_event(startup, 3, node, 0, 0);

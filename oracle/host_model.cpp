@@ -46,7 +46,11 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   p.ql = caps->ql;
   p.qheap = caps->qheap;
   p.rcap = caps->rcap;
-  p.ecap = 64;
+  {  // as the device host code: epochs a node can go through are bounded by its commits
+    u64 eauto = (u64)caps->bcap / (cfg->commands_per_epoch ? cfg->commands_per_epoch : 1) + 2;
+    p.ecap = (u32)(eauto > 4096 ? 4096 : eauto);
+    if (p.ecap < 64) p.ecap = 64;
+  }
   p.qcal = caps->qcal;
   if (p.qcal) { if (max_clock > LBFT_CAL_MAX_CLOCK || p.rcap) return -11; p.qheap = 1; p.ql = 0; }
   p.delay_model = cfg->delay_model;

@@ -34,7 +34,7 @@ def draw_config(rng):
     return kw
 
 
-@pytest.mark.parametrize("chunk", range(12))
+@pytest.mark.parametrize("chunk", range(18))
 def test_random_configurations_match_the_oracle(oracle, chunk):
     rng = np.random.default_rng(20240 + chunk)
     for _ in range(16):
@@ -49,7 +49,9 @@ def test_random_configurations_match_the_oracle(oracle, chunk):
         big = n > 4
         qheap = 1 if (big or rng.random() < 0.3) else 0
         qcal = 1 if (rng.random() < 0.5 and (qheap or special or n > 16)) else 0
-        b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=4, history_cap=96, qcap=max(4096, 24 * n * n), scap=max(128, 128 * n),
+        # <= 64 snapshot slots: the register-resident free mask (what the device picks for small honest networks)
+        scap = 64 if (n <= 4 and not special and rng.random() < 0.5) else max(128, 128 * n)
+        b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=4, history_cap=96, qcap=max(4096, 24 * n * n), scap=scap,
                                        bcap=1024, lcap=1024, ql=int(rng.choice([0, 3, 11, 48])), qheap=qheap, qcal=qcal,
                                        force_generic=int(rng.random() < 0.2))
         assert not b["faults"].any(), kw
