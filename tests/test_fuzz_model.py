@@ -31,6 +31,8 @@ def draw_config(rng):
         kw.update(partition_size=int(rng.integers(1, n)), partition_start=start, partition_end=start + int(rng.integers(50, 400)))
     if rng.random() < 0.45:
         kw["quirks"] = int(rng.choice([1, 2, 3]))
+    if "voting_rights" in kw and "commands_per_epoch" in kw and n >= 2 and rng.random() < 0.6:
+        kw["rights_rotation"] = int(rng.integers(1, n))  # epoch reconfiguration: the rights rotate with the epoch
     return kw
 
 
