@@ -740,11 +740,15 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   // unless the batch is too small to give every SIMD a wavefront.
   u32 lpw = b->lpw;
   if (lpw == 0) {
-    u64 want = (b->m + 1023) / 1024;  // 256 CUs x 4 SIMDs
-    // measured: 8192 x 100 nodes 9.0 s at 16 lanes, 5.9 s at 8, 7.8 s at 4; 65536 x 4 nodes (r01_s3 build) 27.0 ms at 64 lanes
-    // (one wavefront per SIMD), 24.4 ms at 32 (two per SIMD: the class-0 kernel is compiled for 256 registers), 40.1 ms at
-    // 16 (would need four per SIMD).  A wavefront-step costs nearly the same at 16, 32 or 64 lanes (13.7 / 16.6 / 18.4 us).
-    lpw = want <= 8 ? 8 : (want <= 16 ? 16 : 32);
+    // Wavefronts that can be resident at once: 256 CUs x 4 SIMDs, two per SIMD for kernel class 0 (256 registers), one for
+    // the large-network classes.  The fewest lanes per wavefront that still fit the batch in one residency win: a
+    // wavefront-step costs the union of its lanes' paths (65536 x 4 nodes, r01_s3 build: 27.0 ms at 64 lanes = one wavefront
+    // per SIMD, 24.4 ms at 32 = two per SIMD, 40.1 ms at 16 = two rounds; 1024 x 4 nodes: 22.9 ms at 8 lanes, 17.6 at 4,
+    // 13.2 at 2, 9.4 ms at ONE network per wavefront; 8192 x 100 nodes: 9.0 s at 16 lanes, 5.9 s at 8, 7.8 s at 4 = two rounds).
+    u64 resident = sim_class(p) == 0 ? 2048 : 1024;
+    u64 want = (b->m + resident - 1) / resident;
+    lpw = 1;
+    while (lpw < want && lpw < 32) lpw <<= 1;
   }
   p.lpw = lpw;
   // LDS queue slots per instance: what one CU's LDS affords when it hosts 64/lpw workgroups
