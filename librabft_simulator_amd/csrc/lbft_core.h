@@ -375,11 +375,11 @@ struct SimT {
   Rng rng;
 
   // Front of the event queue: slots [0, ql) live in LDS on the device (lane-private column: element k of
-  // this instance is qk[k * qstr], so any per-lane slot index is bank-conflict free); slots >= ql spill to
+  // this instance is qk[k << qsh], so any per-lane slot index is bank-conflict free); slots >= ql spill to
   // the HBM rows.  The host build (oracle/host_model.cpp) passes plain arrays.  ql == 0: HBM rows only.
   u64* qk;
   u32* qm;
-  u32 qstr, ql;
+  u32 qstr, qsh, ql;  // column stride (lanes per wavefront, a power of two) and its log2: element k of a column is [k << qsh]
   // read-only tables (LDS copies on the device)
   const u64 *zig_x, *zig_f, *exp_tab;
   const u8* leader_lds;   // first leader_lds_len rounds of the leader table
@@ -390,11 +390,13 @@ struct SimT {
 #endif
 
   LBFT_HD SimT(const Params& p, u32* state, u32 i) : SimT(p, reinterpret_cast<char*>(state) + tile_offset_bytes(p, i), (i & 63u) * 4u, 0) {}
-  LBFT_HD SimT(const Params& p, char* tile_base, u32 lane_byte_offset, int) : P(p), tile(tile_base), lane4(lane_byte_offset), qk(nullptr), qm(nullptr), qstr(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab),
+  LBFT_HD SimT(const Params& p, char* tile_base, u32 lane_byte_offset, int) : P(p), tile(tile_base), lane4(lane_byte_offset), qk(nullptr), qm(nullptr), qstr(0), qsh(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab),
         leader_lds(nullptr), dur_lds(nullptr), leader_lds_len(0), dur_lds_len(0), hc(nullptr), plist_lds(nullptr) {}
   LBFT_HD void attach_queue(u64* keys, u32* metas, u32 stride, u32 slots) {
     qk = keys; qm = metas; qstr = stride; ql = qpacked() ? (slots & ~7u) : slots;  // packed entries are scanned in batches of 8
-    LBFT_PIN_VGPR(qstr);
+    qsh = 0;
+    while ((1u << qsh) < stride) qsh++;  // (a shift instead of a quarter-rate 32-bit multiply per slot access)
+    LBFT_PIN_VGPR(qsh);
     LBFT_PIN_VGPR(ql);
   }
   // highest_certified_block_round buffers of the nodes' timeouts (hcbr[node][2][n], behind the fixed node rows): for
@@ -405,22 +407,22 @@ struct SimT {
   LBFT_HD void attach_hcbr(u32* column) { hc = column; }
   LBFT_HD bool hc_lds() const { return small_sets() && hc != nullptr; }
   LBFT_HD u32 hc_get(u32 node, u32 buf, u32 a) const {
-    if (hc_lds()) return hc[(node * 8u + buf * 4u + a) * qstr];
+    if (hc_lds()) return hc[(node * 8u + buf * 4u + a) << qsh];
     return nfm(node, NF_FIXED_WORDS + buf * P.n + a);
   }
   LBFT_HD void hc_set(u32 node, u32 buf, u32 a, u32 v) const {
-    if (hc_lds()) hc[(node * 8u + buf * 4u + a) * qstr] = v;
+    if (hc_lds()) hc[(node * 8u + buf * 4u + a) << qsh] = v;
     else nfms(node, NF_FIXED_WORDS + buf * P.n + a, v);
   }
   LBFT_HD void hcbr_to_lds() const {
     if (!hc_lds()) return;
     for (u32 node = 0; node < P.n; node++)
-      for (u32 k = 0; k < 2 * P.n; k++) hc[(node * 8u + (k / P.n) * 4u + k % P.n) * qstr] = nfm(node, NF_FIXED_WORDS + k);
+      for (u32 k = 0; k < 2 * P.n; k++) hc[(node * 8u + (k / P.n) * 4u + k % P.n) << qsh] = nfm(node, NF_FIXED_WORDS + k);
   }
   LBFT_HD void hcbr_from_lds() const {
     if (!hc_lds()) return;
     for (u32 node = 0; node < P.n; node++)
-      for (u32 k = 0; k < 2 * P.n; k++) nfms(node, NF_FIXED_WORDS + k, hc[(node * 8u + (k / P.n) * 4u + k % P.n) * qstr]);
+      for (u32 k = 0; k < 2 * P.n; k++) nfms(node, NF_FIXED_WORDS + k, hc[(node * 8u + (k / P.n) * 4u + k % P.n) << qsh]);
   }
   LBFT_HD void attach_tables(const u64* zx, const u64* zf, const u64* et) { zig_x = zx; zig_f = zf; exp_tab = et; }
   LBFT_HD void attach_peer_list(u8* list) { plist_lds = list; }
@@ -688,38 +690,38 @@ struct SimT {
 #define LBFT_QP_STAMP_BITS 25
   LBFT_HD void q_set(u32 k, u64 key, u32 meta) const {
     if (qpacked()) {
-      if (k < ql) qk[k * qstr] = key;
+      if (k < ql) qk[k << qsh] = key;
       else { st(P.off_qhi + k, (u32)(key >> 32)); st(P.off_qlo + k, (u32)key); }
       return;
     }
-    if (k < ql) { qk[k * qstr] = key; qm[k * qstr] = meta; }
+    if (k < ql) { qk[k << qsh] = key; qm[k << qsh] = meta; }
     else { st(P.off_qhi + k, (u32)(key >> 32)); st(P.off_qlo + k, (u32)key); st(P.off_qmeta + k, meta); }
   }
   LBFT_HD void q_get(u32 k, u64& key, u32& meta) const {
     if (qpacked()) {
       meta = 0;
-      if (k < ql) key = qk[k * qstr];
+      if (k < ql) key = qk[k << qsh];
       else key = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k);
       return;
     }
-    if (k < ql) { key = qk[k * qstr]; meta = qm[k * qstr]; }
+    if (k < ql) { key = qk[k << qsh]; meta = qm[k << qsh]; }
     else { key = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k); meta = ld(P.off_qmeta + k); }
   }
   // The LDS front is a cache of the HBM rows between launches.
   LBFT_HD void queue_to_lds() const {
     u32 nl = qlen < ql ? qlen : ql;
     for (u32 k = 0; k < nl; k++) {
-      qk[k * qstr] = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k);
-      if (!qpacked()) qm[k * qstr] = ld(P.off_qmeta + k);
+      qk[k << qsh] = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k);
+      if (!qpacked()) qm[k << qsh] = ld(P.off_qmeta + k);
     }
-    if (qpacked()) for (u32 k = nl; k < ql; k++) qk[k * qstr] = ~0ULL;
+    if (qpacked()) for (u32 k = nl; k < ql; k++) qk[k << qsh] = ~0ULL;
   }
   LBFT_HD void queue_from_lds() const {
     u32 nl = qlen < ql ? qlen : ql;
     for (u32 k = 0; k < nl; k++) {
-      u64 key = qk[k * qstr];
+      u64 key = qk[k << qsh];
       st(P.off_qhi + k, (u32)(key >> 32)); st(P.off_qlo + k, (u32)key);
-      if (!qpacked()) st(P.off_qmeta + k, qm[k * qstr]);
+      if (!qpacked()) st(P.off_qmeta + k, qm[k << qsh]);
     }
   }
   // `reuse_stamp` != ~0u: the event takes that (already handed out, otherwise unused) creation stamp.
@@ -834,7 +836,7 @@ struct SimT {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-        for (u32 j = 0; j < 8; j++) kk[j] = qk[(k0 + j) * qstr];
+        for (u32 j = 0; j < 8; j++) kk[j] = qk[(k0 + j) << qsh];
         u64 m01 = kk[0] < kk[1] ? kk[0] : kk[1]; u32 i01 = kk[0] < kk[1] ? 0u : 1u;
         u64 m23 = kk[2] < kk[3] ? kk[2] : kk[3]; u32 i23 = kk[2] < kk[3] ? 2u : 3u;
         u64 m45 = kk[4] < kk[5] ? kk[4] : kk[5]; u32 i45 = kk[4] < kk[5] ? 4u : 5u;
@@ -856,14 +858,14 @@ struct SimT {
       qlen--;
       u64 lk = ~0ULL; u32 lm = 0;
       if (best != qlen) { q_get(qlen, lk, lm); q_set(best, lk, 0); }
-      if (qlen < ql) qk[qlen * qstr] = ~0ULL;  // the vacated last slot becomes a sentinel again
+      if (qlen < ql) qk[qlen << qsh] = ~0ULL;  // the vacated last slot becomes a sentinel again
       return true;
     }
 #if defined(__HIPCC__)
 #pragma unroll 4
 #endif
     for (u32 k = 0; k < nl; k++) {
-      u64 key = qk[k * qstr];
+      u64 key = qk[k << qsh];
       if (key < bkey) { bkey = key; best = k; }
     }
     for (u32 k = ql; k < qlen; k++) {  // spilled tail (rare when ql covers the high-water mark)
@@ -873,7 +875,7 @@ struct SimT {
     time = (i32)(u32)(bkey >> 32);
     kind = 3u - ((u32)bkey >> 30);
     ev_stamp = (u32)bkey & 0x3fffffffu;
-    meta = best < ql ? qm[best * qstr] : ld(P.off_qmeta + best);
+    meta = best < ql ? qm[best << qsh] : ld(P.off_qmeta + best);
     qlen--;
     if (best != qlen) {
       u64 lk; u32 lm;
