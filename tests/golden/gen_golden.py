@@ -3,13 +3,13 @@
 path, transcribed with their source locations (they are what pins the oracle); (2) oracle_fixtures.json -- outputs of
 the pinned oracle on small seeded configurations, so that the HIP path can also be checked against committed vectors
 (tests/test_golden_fixtures.py) independently of building the oracle.  Re-run after changing the oracle:
-    python tools/gen_golden.py
+    python tests/golden/gen_golden.py
 """
 import json
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np  # noqa: E402
 import oracle_ctypes as oc  # noqa: E402

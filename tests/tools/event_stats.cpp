@@ -1,10 +1,10 @@
 // event_stats.cpp -- TEST / ANALYSIS INFRASTRUCTURE (CPU only): per-instance statistics of the event loop, counted by the
 // LBFT_STAT points of librabft_simulator_amd/csrc/lbft_core.h in a host build of the kernel logic (oracle/host_model.cpp).
 // These numbers decide which paths of a wavefront-step are "always taken by some lane" (DESIGN.md section 5):
-//   g++ -O2 -std=c++17 -Ioracle tools/event_stats.cpp -o /tmp/event_stats -lpthread && /tmp/event_stats [nodes] [instances]
+//   g++ -O2 -std=c++17 -Ioracle tests/tools/event_stats.cpp -o /tmp/event_stats -lpthread && /tmp/event_stats [nodes] [instances]
 #define LBFT_HOST_STATS 1
 namespace lbft { unsigned long long lbft_host_stats[64]; }
-#include "../oracle/host_model.cpp"
+#include "../../oracle/host_model.cpp"
 #include <cstdio>
 #include <cstdlib>
 

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Offline randomised differential sweep (CPU only; test infrastructure): the kernel logic compiled for the host against the
 full-fidelity oracle on `chunks x 16` configurations drawn like tests/test_fuzz_model.py does, with other seeds.
-    python tools/fuzz_sweep.py 0 400      # chunks [0, 400): 6 400 configurations, ~4 minutes on 8 cores
+    python tests/tools/fuzz_sweep.py 0 400      # chunks [0, 400): 6 400 configurations, ~4 minutes on 8 cores
 Prints every configuration whose commit logs / States / rounds / counters differ or that raised a fault word (capacity
 overflows of this harness show up as faults = 2: snapshot slots with quirks bit 0 and a very short query period)."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
