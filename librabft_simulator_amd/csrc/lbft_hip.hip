@@ -147,8 +147,17 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
 // wavefront per SIMD and may use the whole register file (VGPRs + AGPRs).
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run0(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { run_body<0>(p, state, unfinished); }
+#ifndef LBFT_BIG_WAVES_PER_SIMD
+#define LBFT_BIG_WAVES_PER_SIMD 1  // classes 1-2: wavefronts per SIMD the kernels are compiled for (1 = the whole register file;
+                                   // measured with 2 -- half the lanes per wavefront, 167 spilled registers: 16384 x 64 nodes
+                                   // 1.23 s instead of 1.01 s, 8192 x 100 nodes 7.0 s instead of 5.5 s)
+#endif
 template <int CLS>
-__global__ __launch_bounds__(LBFT_RUN_BLOCK) void lbft_k_run(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { run_body<CLS>(p, state, unfinished); }
+__global__ __launch_bounds__(LBFT_RUN_BLOCK)
+#if LBFT_BIG_WAVES_PER_SIMD > 1
+__attribute__((amdgpu_waves_per_eu(LBFT_BIG_WAVES_PER_SIMD, LBFT_BIG_WAVES_PER_SIMD)))
+#endif
+void lbft_k_run(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { run_body<CLS>(p, state, unfinished); }
 
 __device__ __forceinline__ u64 wave_sum(u64 v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -745,7 +754,7 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
     // wavefront-step costs the union of its lanes' paths (65536 x 4 nodes, r01_s3 build: 27.0 ms at 64 lanes = one wavefront
     // per SIMD, 24.4 ms at 32 = two per SIMD, 40.1 ms at 16 = two rounds; 1024 x 4 nodes: 22.9 ms at 8 lanes, 17.6 at 4,
     // 13.2 at 2, 9.4 ms at ONE network per wavefront; 8192 x 100 nodes: 9.0 s at 16 lanes, 5.9 s at 8, 7.8 s at 4 = two rounds).
-    u64 resident = sim_class(p) == 0 ? 2048 : 1024;
+    u64 resident = sim_class(p) == 0 ? 2048 : 1024 * LBFT_BIG_WAVES_PER_SIMD;
     u64 want = (b->m + resident - 1) / resident;
     lpw = 1;
     while (lpw < want && lpw < 32) lpw <<= 1;
