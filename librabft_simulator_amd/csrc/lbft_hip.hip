@@ -174,27 +174,40 @@ enum CounterSlot { C_EV0 = 0, C_EV1, C_EV2, C_EV3, C_DRAWS, C_ROUNDS, C_COMMITS,
 // reductions, one atomic per wavefront and counter).
 __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_finalize(Params p, const u32* __restrict__ state, u64* __restrict__ states_out,
                                                               unsigned long long* __restrict__ counters) {
+  // grid = (instances / 64, nodes): lane = instance (row accesses stay coalesced), blockIdx.y = the node whose State is hashed;
+  // the y == 0 blocks also reduce the batch counters.
   u32 i = blockIdx.x * LBFT_BLOCK + threadIdx.x;
+  u32 n = blockIdx.y;
+  if (i < p.m) {
+    Sim s(p, const_cast<u32*>(state), i);
+    u32 nc = s.nfm(n, NF_NCOMMITS);
+    Sip13 h;
+    h.init();
+    h.word(nc);
+    for (u32 k0 = 0; k0 < nc; k0 += 4) {  // four commits per round trip: their block ids, then their three fields each
+      u32 b[4], link[4], cmd[4], tm[4];
+#pragma unroll
+      for (u32 j = 0; j < 4; j++) b[j] = k0 + j < nc ? s.ld(p.off_log + n * p.lcap + k0 + j) : 0;
+#pragma unroll
+      for (u32 j = 0; j < 4; j++) {
+        link[j] = b[j] ? s.bf(b[j], B_LINK) : 0; cmd[j] = b[j] ? s.bf(b[j], B_CMD) : 0; tm[j] = b[j] ? s.bf(b[j], B_TIME) : 0;
+      }
+#pragma unroll
+      for (u32 j = 0; j < 4; j++)
+        if (k0 + j < nc) { h.word(link[j] >> 16); h.word(cmd[j]); h.word((u64)(i64)(i32)tm[j]); }
+    }
+    states_out[(size_t)i * p.n + n] = h.finish();
+  }
+  if (n != 0) return;
   u64 c[C_WORDS];
   for (int k = 0; k < C_WORDS; k++) c[k] = 0;
   if (i < p.m) {
     Sim s(p, const_cast<u32*>(state), i);
     u64 min_round = ~0ULL, min_commits = ~0ULL;
-    for (u32 n = 0; n < p.n; n++) {
-      u32 nc = s.nfm(n, NF_NCOMMITS);
-      u64 ar = s.nfm(n, NF_PM_ROUND);
+    for (u32 q = 0; q < p.n; q++) {
+      u64 nc = s.nfm(q, NF_NCOMMITS), ar = s.nfm(q, NF_PM_ROUND);
       min_round = ar < min_round ? ar : min_round;
       min_commits = nc < min_commits ? nc : min_commits;
-      Sip13 h;
-      h.init();
-      h.word(nc);
-      for (u32 k = 0; k < nc; k++) {
-        u32 b = s.ld(p.off_log + n * p.lcap + k);
-        h.word(s.blk_author(b));
-        h.word(s.bf(b, B_CMD));
-        h.word((u64)(i64)(i32)s.bf(b, B_TIME));
-      }
-      states_out[(size_t)i * p.n + n] = h.finish();
     }
     c[C_EV0] = s.ld(I_EV0); c[C_EV1] = s.ld(I_EV1); c[C_EV2] = s.ld(I_EV2); c[C_EV3] = s.ld(I_EV3);
     c[C_DRAWS] = s.ld(I_DRAWS); c[C_ROUNDS] = min_round; c[C_COMMITS] = min_commits; c[C_SCHED] = s.ld(I_STAMP);
@@ -924,7 +937,7 @@ int lbft_batch_checkpoint_load(lbft_batch* b, const void* buf, size_t len) {
 static int finalize_run(lbft_batch* b, u32 grid_full, u64 launches) {
   Params& p = b->p;
   HIP_TRY(hipMemsetAsync(b->d_counters, 0, C_WORDS * sizeof(unsigned long long), b->stream));
-  lbft_k_finalize<<<grid_full, LBFT_BLOCK, 0, b->stream>>>(p, b->d_state, b->d_states_out, b->d_counters);
+  lbft_k_finalize<<<dim3(grid_full, p.n), LBFT_BLOCK, 0, b->stream>>>(p, b->d_state, b->d_states_out, b->d_counters);
   HIP_TRY(hipGetLastError());
   unsigned long long hc[C_WORDS];
   HIP_TRY(hipMemcpyAsync(hc, b->d_counters, sizeof(hc), hipMemcpyDeviceToHost, b->stream));
