@@ -136,6 +136,22 @@ int lbft_batch_commit_counts(const lbft_batch* b, uint32_t* out);
 int lbft_batch_active_rounds(const lbft_batch* b, uint64_t* out);
 /* SimulatedContext::committed_history() of one node (simulated_context.rs:98-100); copies min(cap, *len) entries. */
 int lbft_batch_committed_history(const lbft_batch* b, size_t inst, uint32_t node, lbft_commit* out, size_t cap, size_t* len);
+/* The records behind one node's committed history with the hashes the reference gives them: SmrContext::hash = SipHash-1-3
+ * (Rust DefaultHasher) of "Name::" + BCS bytes (smr_context.rs:84-95, simulated_context.rs:238-242).  Entry k describes the
+ * Block_ that carried the k-th committed command (record.rs:45-60), the State after executing it (simulated_context.rs:51-55)
+ * and the QuorumCertificate_ certifying the block (record.rs:79-100; its Vote_s, record.rs:62-77, in author order).  The event
+ * loop never needs these hashes (records are identified structurally); they are recomputed on the device
+ * from the block pool, so that simulated state can be related to what a reference node would store or put on the wire
+ * (first half).  flags: bit 0 = no QC recorded for the block, bit 1 = internal inconsistency.
+ * Copies min(cap, *len) entries. */
+typedef struct lbft_record_hash {
+  uint64_t block_hash; /* context.hash(&Block_ { command, time, previous_quorum_certificate_hash, round, author }) */
+  uint64_t state;      /* State(..) of the ledger after the block's command */
+  uint64_t qc_hash;    /* context.hash(&QuorumCertificate_ { epoch_id, round, certified_block_hash, state, committed_state, votes, author }) */
+  uint32_t num_votes;  /* votes in the QC */
+  uint32_t flags;
+} lbft_record_hash;
+int lbft_batch_committed_record_hashes(const lbft_batch* b, size_t inst, uint32_t node, lbft_record_hash* out, size_t cap, size_t* len);
 /* All histories: out[(inst * num_nodes + node) * cap_per_node + k], first min(len, cap_per_node) entries each. */
 int lbft_batch_committed_histories(const lbft_batch* b, lbft_commit* out, size_t cap_per_node);
 /* StateFinalizer::last_committed_state() (simulated_context.rs:194-196; State = SipHash-1-3 of the

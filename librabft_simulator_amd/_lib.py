@@ -95,11 +95,12 @@ class LbftNodeView(C.Structure):
 
 
 COMMIT_DTYPE = np.dtype([("proposer", "<u8"), ("index", "<u8"), ("time", "<i8")])
+RECORD_HASH_DTYPE = np.dtype([("block_hash", "<u8"), ("state", "<u8"), ("qc_hash", "<u8"), ("num_votes", "<u4"), ("flags", "<u4")])
 
 # every symbol include/lbft.h declares (tests check that the library exports all of them)
 ABI_SYMBOLS = [
     "lbft_batch_create", "lbft_batch_run_until", "lbft_batch_reset", "lbft_batch_commit_counts",
-    "lbft_batch_active_rounds", "lbft_batch_committed_history", "lbft_batch_committed_histories",
+    "lbft_batch_active_rounds", "lbft_batch_committed_history", "lbft_batch_committed_histories", "lbft_batch_committed_record_hashes",
     "lbft_batch_last_committed_states", "lbft_batch_startup_times", "lbft_batch_epochs", "lbft_batch_counters",
     "lbft_batch_faults", "lbft_batch_destroy", "lbft_batch_stream", "lbft_batch_last_run_ms",
     "lbft_batch_device_bytes", "lbft_batch_set_max_steps", "lbft_batch_set_lanes_per_wavefront",
@@ -142,6 +143,8 @@ def lib():
         f.restype = C.c_int
     L.lbft_batch_committed_history.argtypes = [vp, C.c_size_t, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.lbft_batch_committed_history.restype = C.c_int
+    L.lbft_batch_committed_record_hashes.argtypes = [vp, C.c_size_t, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.lbft_batch_committed_record_hashes.restype = C.c_int
     L.lbft_batch_committed_histories.argtypes = [vp, vp, C.c_size_t]
     L.lbft_batch_committed_histories.restype = C.c_int
     L.lbft_batch_counters.argtypes = [vp, C.POINTER(LbftCounters)]

@@ -179,11 +179,13 @@ enum NodeField : u32 {
 // grandparent (denormalised at proposal time, so the 3-chain commit rule record_store.rs:221-235 and the
 // voting constraints node.rs:256-276 need one record instead of a pointer chase through three), the
 // epoch, the ledger depth and the three per-node knowledge masks.  B_TIME / B_CMD are only read when a
-// committed history is exported or hashed.
+// committed history is exported or hashed, B_VOTERS when record hashes are exported (committed_record_hashes).
 enum BlockField : u32 {
   B_ROUND = 0, B_LINK /* prev | author << 16 */, B_PREV_ROUND, B_PP /* grandparent | great-grandparent << 16 (block ids) */, B_PP_ROUND, B_EPOCH,
   B_DEPTH /* commands in the ledger after this block */, B_KNOWN, B_QC, B_PEND, BC_WORDS,
-  B_TIME = BC_WORDS, B_CMD, B_WORDS
+  B_TIME = BC_WORDS, B_CMD,
+  B_VOTERS,  // authors 0..31 whose votes the block's QuorumCertificate contains (written once, by the author, when it forms the QC)
+  B_WORDS
 };
 #ifndef LBFT_BLK_CACHE
 #define LBFT_BLK_CACHE 3  // register-resident block records per instance (second-chance FIFO); measured: 2 -> 29.2 ms, 3 -> 27.9, 4 -> 28.0 (19 spilled registers), 5 -> 29.8
@@ -312,6 +314,59 @@ struct Sip13 {
     return v0 ^ v1 ^ v2 ^ v3;
   }
 };
+
+// SipHash-1-3 (keys 0,0) over a byte stream: the reference hashes a record as DefaultHasher over "Name::" followed by its BCS
+// bytes (smr_context.rs:84-95, simulated_context.rs:238-242).  Only the export of record hashes uses it.
+struct SipBytes {
+  u64 v0, v1, v2, v3, buf, total;
+  u32 nbuf;
+  LBFT_HD void init() {
+    v0 = 0x736f6d6570736575ULL; v1 = 0x646f72616e646f6dULL; v2 = 0x6c7967656e657261ULL; v3 = 0x7465646279746573ULL;
+    buf = 0; total = 0; nbuf = 0;
+  }
+  LBFT_HD void byte(u32 c) {
+    buf |= (u64)(c & 0xffu) << (8 * nbuf);
+    total++;
+    if (++nbuf == 8) { u64 m = buf; v3 ^= m; LBFT_SIPROUND v0 ^= m; buf = 0; nbuf = 0; }
+  }
+  LBFT_HD void u64le(u64 v) { for (u32 i = 0; i < 8; i++) byte((u32)(v >> (8 * i))); }  // BCS u64 / usize
+  LBFT_HD void uleb(u64 v) {  // BCS sequence length
+    while (v >= 0x80) { byte((u32)v | 0x80u); v >>= 7; }
+    byte((u32)v);
+  }
+  LBFT_HD void option(bool some, u64 v) { byte(some ? 1u : 0u); if (some) u64le(v); }  // BCS Option<u64>
+  LBFT_HD u64 finish() {
+    u64 b = (total << 56) | buf;
+    v3 ^= b; LBFT_SIPROUND v0 ^= b;
+    v2 ^= 0xff;
+    LBFT_SIPROUND LBFT_SIPROUND LBFT_SIPROUND
+    return v0 ^ v1 ^ v2 ^ v3;
+  }
+};
+// context.hash(&EpochId(e)) (node.rs:116-118): the initial hash of an epoch's record store
+LBFT_HD u64 record_hash_epoch_id(u64 e) {
+  SipBytes h; h.init();
+  const char name[] = "EpochId::";
+  for (u32 i = 0; i < sizeof(name) - 1; i++) h.byte((u32)name[i]);
+  h.u64le(e);
+  return h.finish();
+}
+// Block_ (record.rs:45-60): command (proposer, index), time, previous_quorum_certificate_hash, round, author
+LBFT_HD u64 record_hash_block(u64 proposer, u64 index, i64 time, u64 prev_qc_hash, u64 round, u64 author) {
+  SipBytes h; h.init();
+  const char name[] = "Block_::";
+  for (u32 i = 0; i < sizeof(name) - 1; i++) h.byte((u32)name[i]);
+  h.u64le(proposer); h.u64le(index); h.u64le((u64)time); h.u64le(prev_qc_hash); h.u64le(round); h.u64le(author);
+  return h.finish();
+}
+// Vote_ (record.rs:62-77): epoch_id, round, certified_block_hash, state, committed_state, author
+LBFT_HD u64 record_hash_vote(u64 epoch, u64 round, u64 block_hash, u64 state, bool has_cs, u64 cs, u64 author) {
+  SipBytes h; h.init();
+  const char name[] = "Vote_::";
+  for (u32 i = 0; i < sizeof(name) - 1; i++) h.byte((u32)name[i]);
+  h.u64le(epoch); h.u64le(round); h.u64le(block_hash); h.u64le(state); h.option(has_cs, cs); h.u64le(author);
+  return h.finish();
+}
 
 // EpochConfiguration::pick_author(SipHash13(round)) (configuration.rs:65-75, pacemaker.rs:100-109)
 // `shift`: author a holds weights[(a + shift) % n] (rotating voting rights; 0 in the reference)
@@ -1158,7 +1213,8 @@ struct SimT {
     for (u32 f = 0; f < BC_WORDS; f++) bfs(b, f, rb.w[f]);
     bfs(b, B_TIME, (u32)(i32)local_clock);
     bfs(b, B_CMD, cmd);
-    for (u32 k = 0; wide() && k < 3 * (P.mw - 1); k++) bfs(b, B_WORDS + k, 0);
+    bfs(b, B_VOTERS, 0);
+    for (u32 k = 0; wide() && k < 4 * (P.mw - 1); k++) bfs(b, B_WORDS + k, 0);
     blk_cache_insert(b, rb);
     insert_block(node, b, rb);
   }
@@ -1176,6 +1232,12 @@ struct SimT {
     Blk rb = blk_get(b);
     if (rb.author() != node) return false;
     nfs(node, NF_ELECTION, 2);
+    // the QC's votes = the current votes for the winning (block, state) (record_store.rs:716-727): the ballot entry of b
+    bool first = nf(node, NF_BAL0_BLK) == b;  // (field indices stay compile-time constants: the node cache lives in registers)
+    for (u32 k = 0; k < P.mw; k++) {
+      u32 v = first ? am_word(node, NF_BAL0_AUTHORS, k) : am_word(node, NF_BAL1_AUTHORS, k);
+      st(k == 0 ? bfw(b, B_VOTERS) : bfw(b, B_WORDS + 3 * (P.mw - 1) + k - 1), v);
+    }
     insert_qc(node, b, rb);
     return true;
   }
@@ -1847,6 +1909,58 @@ struct SimT {
     LBFT_MARK(13);
   }
 
+  // ---- record hashes of a node's committed chain (first half: byte-exact record hashing) ----
+  // For the k-th committed command of `node`: out[4k] = hash of the Block that carried it, [4k+1] = the State after it,
+  // [4k+2] = hash of the QuorumCertificate certifying the block (votes in author order, as the oracle canonicalises the
+  // reference's HashMap order), [4k+3] = number of votes | flags << 32 (bit 0: no QC recorded, bit 1: the block's
+  // predecessor is not the previous commit -- cannot happen, commits extend one another).  Everything is recomputed from the
+  // block pool: the structural ids the event loop works with never carried these hashes.  Returns the number of commits.
+  LBFT_HD u32 committed_record_hashes(u32 node, u64* out, u32 cap) const {
+    u32 nc = nfm(node, NF_NCOMMITS);
+    u64 qc_prev = 0, state_prev = 0, state_prev2 = 0;
+    u32 y_prev = 0, y_prev2 = 0;
+    for (u32 k = 0; k < nc && k < cap; k++) {
+      u32 y = ld(P.off_log + node * P.lcap + k);
+      u32 link = bf(y, B_LINK), prev = link & 0xffffu, author = link >> 16;
+      u32 round = bf(y, B_ROUND), prev_round = bf(y, B_PREV_ROUND), pp = bf(y, B_PP) & 0xffffu, pp_round = bf(y, B_PP_ROUND);
+      u32 epoch = bf(y, B_EPOCH);
+      u64 flags = 0;
+      // State = DefaultHasher over Vec<(Command, NodeTime)> (simulated_context.rs:51-55): length, then (proposer, index, time)
+      Sip13 hs; hs.init(); hs.word(k + 1);
+      for (u32 j = 0; j <= k; j++) {
+        u32 b = ld(P.off_log + node * P.lcap + j);
+        hs.word(blk_author(b)); hs.word(bf(b, B_CMD)); hs.word((u64)(i64)(i32)bf(b, B_TIME));
+      }
+      u64 state = hs.finish();
+      if (prev && prev != y_prev) flags |= 2;
+      u64 prev_qc_hash = prev ? qc_prev : record_hash_epoch_id(epoch);
+      u64 bh = record_hash_block(author, bf(y, B_CMD), (i64)(i32)bf(y, B_TIME), prev_qc_hash, round, author);
+      // vote_committed_state (record_store.rs:237-255): three contiguous rounds commit the grandparent's state
+      bool has_cs = prev && pp && round == prev_round + 1 && prev_round == pp_round + 1;
+      if (has_cs && pp != y_prev2) flags |= 2;
+      u64 cs = has_cs ? state_prev2 : 0;
+      // QuorumCertificate_ (record.rs:79-100): epoch_id, round, certified_block_hash, state, committed_state, votes, author
+      SipBytes hq; hq.init();
+      const char name[] = "QuorumCertificate_::";
+      for (u32 i = 0; i < sizeof(name) - 1; i++) hq.byte((u32)name[i]);
+      hq.u64le(epoch); hq.u64le(round); hq.u64le(bh); hq.u64le(state); hq.option(has_cs, cs);
+      u32 votes = 0;
+      for (u32 w = 0; w < P.mw; w++) votes += popc64(ld(w == 0 ? bfw(y, B_VOTERS) : bfw(y, B_WORDS + 3 * (P.mw - 1) + w - 1)));
+      hq.uleb(votes);
+      for (u32 w = 0; w < P.mw; w++)
+        for (u32 m = ld(w == 0 ? bfw(y, B_VOTERS) : bfw(y, B_WORDS + 3 * (P.mw - 1) + w - 1)); m; m &= m - 1) {
+          u64 a = 32 * w + ctz32(m);  // (Author, Signature{author, hash of the vote}) (simulated_context.rs:22-23,259-261)
+          hq.u64le(a); hq.u64le(a); hq.u64le(record_hash_vote(epoch, round, bh, state, has_cs, cs, a));
+        }
+      hq.u64le(author);
+      u64 qh = hq.finish();
+      if (!votes) { flags |= 1; qh = 0; }
+      out[4 * (size_t)k] = bh; out[4 * (size_t)k + 1] = state; out[4 * (size_t)k + 2] = qh; out[4 * (size_t)k + 3] = votes | (flags << 32);
+      y_prev2 = y_prev; y_prev = y; state_prev2 = state_prev; state_prev = state; qc_prev = qh;
+    }
+    return nc;
+  }
+
   // ---- Simulator::new (simulator.rs:200-250) + NodeState::make_initial_state (node.rs:87-114) ----
   LBFT_HD void init(u64 seed) {
     for (u32 w = 0; w < I_WORDS; w++) st(w, 0);
@@ -2027,7 +2141,7 @@ inline u32 compute_layout(Params& p) {
   p.off_snap = w; w += p.scap * p.snap_words;
   p.off_snap_ref = w; w += p.scap;
   p.off_snap_free = w; w += p.scap;
-  p.blk_words = B_WORDS + 3 * (p.mw - 1);
+  p.blk_words = B_WORDS + 4 * (p.mw - 1);  // + extension words (nodes / authors >= 32) of KNOWN, QC, PEND and VOTERS
   p.off_blk = w; w += p.bcap * p.blk_words;
   p.off_log = w; w += p.n * p.lcap;
   p.off_list = w; w += p.n > 16 ? p.n : 0;

@@ -1039,6 +1039,37 @@ int lbft_batch_committed_history(const lbft_batch* b, size_t inst, uint32_t node
   return LBFT_OK;
 }
 
+// SimT::committed_record_hashes for one (instance, node): a single lane walks the node's log
+__global__ void lbft_k_record_hashes(Params p, const u32* __restrict__ state, u32 inst, u32 node, u64* __restrict__ out, u32 cap) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  Sim s(p, const_cast<u32*>(state), inst);
+  s.committed_record_hashes(node, out, cap);
+}
+
+int lbft_batch_committed_record_hashes(const lbft_batch* b, size_t inst, uint32_t node, lbft_record_hash* out, size_t cap, size_t* len) {
+  if (!b || !len || inst >= b->m || node >= b->p.n) return LBFT_ERR_INVALID;
+  if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
+  HIP_TRY(hipSetDevice(b->device));
+  u32 nc = 0;
+  HIP_TRY(hipMemcpy(&nc, b->d_state + word_offset(b->p, (u32)inst, b->p.off_node + node * b->p.node_words + NF_NCOMMITS), sizeof(u32),
+                    hipMemcpyDeviceToHost));
+  *len = nc;
+  size_t k = nc < cap ? nc : cap;
+  if (!k || !out) return LBFT_OK;
+  u64* d_out = nullptr;
+  HIP_TRY(hipMalloc(&d_out, k * 4 * sizeof(u64)));
+  lbft_k_record_hashes<<<1, 64, 0, b->stream>>>(b->p, b->d_state, (u32)inst, node, d_out, (u32)k);
+  hipError_t e = hipGetLastError();
+  std::vector<u64> h(k * 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(h.data(), d_out, k * 4 * sizeof(u64), hipMemcpyDeviceToHost, b->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+  hipFree(d_out);
+  if (e != hipSuccess) return hip_fail(e, "lbft_batch_committed_record_hashes");
+  for (size_t i = 0; i < k; i++)
+    out[i] = lbft_record_hash{h[4 * i], h[4 * i + 1], h[4 * i + 2], (uint32_t)h[4 * i + 3], (uint32_t)(h[4 * i + 3] >> 32)};
+  return LBFT_OK;
+}
+
 int lbft_batch_counters(const lbft_batch* b, lbft_counters* out) {
   if (!b || !out) return LBFT_ERR_INVALID;
   if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }

@@ -18,7 +18,7 @@ from collections import namedtuple
 import numpy as np
 
 from . import _lib
-from ._lib import COMMIT_DTYPE, LbftActions, LbftConfig, LbftCounters, LbftError, LbftNodeView, check
+from ._lib import COMMIT_DTYPE, RECORD_HASH_DTYPE, LbftActions, LbftConfig, LbftCounters, LbftError, LbftNodeView, check
 
 Command = namedtuple("Command", ["proposer", "index"])  # simulated_context.rs:31-35
 Author = int
@@ -187,6 +187,15 @@ class BatchResult:
         out = np.zeros(max(n, 1), dtype=COMMIT_DTYPE)
         ln = C.c_size_t()
         check(_lib.lib().lbft_batch_committed_history(self._sim._h, instance, node, out.ctypes.data, n, C.byref(ln)))
+        return out[:n]
+
+    def committed_record_hashes(self, instance, node):
+        """(block_hash, state, qc_hash, num_votes, flags) of the Block_ / QuorumCertificate_ records behind
+        committed_history(instance, node), hashed like the reference's SmrContext::hash (BCS + SipHash-1-3)."""
+        n = int(self.commit_counts[instance, node])
+        out = np.zeros(max(n, 1), dtype=RECORD_HASH_DTYPE)
+        ln = C.c_size_t()
+        check(_lib.lib().lbft_batch_committed_record_hashes(self._sim._h, instance, node, out.ctypes.data, n, C.byref(ln)))
         return out[:n]
 
     def round_switches(self, instance=0, cap_rounds=None):

@@ -34,7 +34,8 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
                              uint64_t* active_rounds, uint64_t* last_states, lbft_oracle_commit* histories,
                              size_t history_cap, lbft_oracle_counters* counters, uint32_t* faults,
                              uint32_t* maxq_out, uint32_t* maxsnap_out, int64_t* round_switches /* [inst][rcap][n], INT64_MIN = none */,
-                             uint32_t* max_rounds /* [inst] */) {
+                             uint32_t* max_rounds /* [inst] */,
+                             uint64_t* record_hashes /* [inst][node][hash_cap][4]: SimT::committed_record_hashes, or NULL */, size_t hash_cap) {
   if ((cfg->quirks & ~3u) != 0 || cfg->num_nodes > LBFT_MAX_NODES) return -10;
   Params p;
   memset(&p, 0, sizeof(p));
@@ -140,6 +141,8 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
           round_switches[((size_t)i * p.rcap + r) * p.n + k] = t == 0xffffffffu ? INT64_MIN : (int64_t)(i32)t;
         }
     }
+    if (record_hashes && hash_cap)
+      for (u32 n = 0; n < p.n; n++) s.committed_record_hashes(n, record_hashes + ((size_t)i * p.n + n) * hash_cap * 4, (u32)hash_cap);
     u64 min_round = UINT64_MAX, min_commits = UINT64_MAX;
     for (u32 n = 0; n < p.n; n++) {
       size_t o = i * p.n + n;

@@ -1338,6 +1338,30 @@ size_t lbft_oracle_committed_history(const lbft_oracle_sim* sim, uint32_t node, 
 uint64_t lbft_oracle_last_committed_state(const lbft_oracle_sim* sim, uint32_t node) {
   return sim->nodes[node].context.last_committed_state();
 }
+size_t lbft_oracle_committed_record_hashes(const lbft_oracle_sim* sim, uint32_t node, lbft_oracle_record_hash* out, size_t cap) {
+  const SimNode& n = sim->nodes[node];
+  auto& h = n.context.last_committed.history;
+  // the node's record stores, oldest epoch first (a Command (proposer, index) identifies its block: one fetch per proposal)
+  std::vector<const RecordStore*> stores;
+  for (auto& kv : n.node.past_record_stores) stores.push_back(kv.second.get());
+  stores.push_back(n.node.record_store.get());
+  for (size_t k = 0; k < h.size() && k < cap; k++) {
+    lbft_oracle_record_hash r{0, 0, 0, 0, 0};
+    for (const RecordStore* s : stores) {
+      for (auto& kv : s->blocks) {
+        const Block& b = kv.second;
+        if (b.cmd_proposer != h[k].proposer || b.cmd_index != h[k].index) continue;
+        r.block_hash = kv.first;
+        for (auto& q : s->quorum_certificates)
+          if (q.second.certified_block_hash == kv.first) {
+            r.qc_hash = q.first; r.state = q.second.state; r.has_qc = 1; r.num_votes = (uint32_t)q.second.votes.size();
+          }
+      }
+    }
+    out[k] = r;
+  }
+  return h.size();
+}
 int lbft_oracle_node_update(lbft_oracle_sim* sim, uint32_t node, int64_t node_time, lbft_oracle_actions* out) {
   if (!sim || !out || node >= sim->nodes.size()) return -1;
   try {

@@ -62,6 +62,7 @@ class OracleCounters(C.Structure):
 
 
 COMMIT_DTYPE = np.dtype([("proposer", "<u8"), ("index", "<u8"), ("time", "<i8")])
+RECORD_HASH_DTYPE = np.dtype([("block_hash", "<u8"), ("state", "<u8"), ("qc_hash", "<u8"), ("has_qc", "<u4"), ("num_votes", "<u4")])
 
 class OracleActions(C.Structure):
     _fields_ = [("next_scheduled_update", C.c_int64), ("should_send", C.c_uint64 * 2), ("should_broadcast", C.c_uint32),
@@ -111,6 +112,8 @@ def lib():
         L.lbft_oracle_commit_count.restype = C.c_size_t
         L.lbft_oracle_committed_history.argtypes = [vp, C.c_uint32, vp, C.c_size_t]
         L.lbft_oracle_committed_history.restype = C.c_size_t
+        L.lbft_oracle_committed_record_hashes.argtypes = [vp, C.c_uint32, vp, C.c_size_t]
+        L.lbft_oracle_committed_record_hashes.restype = C.c_size_t
         for name in ("last_committed_state", "active_round", "epoch"):
             f = getattr(L, "lbft_oracle_" + name)
             f.argtypes = [vp, C.c_uint32]
@@ -214,6 +217,13 @@ class OracleSim:
         n = lib().lbft_oracle_commit_count(self.h, node)
         out = np.zeros(n, dtype=COMMIT_DTYPE)
         lib().lbft_oracle_committed_history(self.h, node, out.ctypes.data, n)
+        return out
+
+    def committed_record_hashes(self, node):
+        """(block_hash, state, qc_hash, has_qc, num_votes) of the records behind committed_history(node)."""
+        n = lib().lbft_oracle_commit_count(self.h, node)
+        out = np.zeros(n, dtype=RECORD_HASH_DTYPE)
+        lib().lbft_oracle_committed_record_hashes(self.h, node, out.ctypes.data, n)
         return out
 
     def last_committed_states(self):
@@ -331,13 +341,14 @@ def hostmodel_lib():
         vp = C.c_void_p
         L.lbft_hostmodel_run_batch.argtypes = [
             C.POINTER(OracleConfig), C.POINTER(HostModelCaps), vp, C.c_size_t, C.c_int64, C.c_uint32, vp, vp, vp,
-            vp, C.c_size_t, C.POINTER(OracleCounters), vp, vp, vp, vp, vp]
+            vp, C.c_size_t, C.POINTER(OracleCounters), vp, vp, vp, vp, vp, vp, C.c_size_t]
         L.lbft_hostmodel_run_batch.restype = C.c_int
         _hm = L
     return _hm
 
 
-def hostmodel_run_batch(cfg, seeds, max_clock, threads=1, history_cap=0, qcap=256, scap=128, bcap=256, lcap=256, ql=0, qheap=0, force_generic=0, rcap=0, qcal=0):
+def hostmodel_run_batch(cfg, seeds, max_clock, threads=1, history_cap=0, qcap=256, scap=128, bcap=256, lcap=256, ql=0, qheap=0, force_generic=0, rcap=0, qcal=0,
+                        hash_cap=0):
     seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
     m, nn = len(seeds), cfg.num_nodes
     caps = HostModelCaps(qcap, scap, bcap, lcap, ql, qheap, force_generic, rcap, qcal)
@@ -350,13 +361,15 @@ def hostmodel_run_batch(cfg, seeds, max_clock, threads=1, history_cap=0, qcap=25
     faults = np.zeros(m, dtype=np.uint32)
     maxq = np.zeros(m, dtype=np.uint32)
     maxsnap = np.zeros(m, dtype=np.uint32)
+    rh = np.zeros((m, nn, hash_cap, 4), dtype=np.uint64) if hash_cap else None  # (block hash, State, QC hash, votes | flags << 32)
     ctr = OracleCounters()
     rc = hostmodel_lib().lbft_hostmodel_run_batch(
         C.byref(cfg), C.byref(caps), seeds.ctypes.data, m, max_clock, threads, commit_counts.ctypes.data,
         active_rounds.ctypes.data, last_states.ctypes.data, hist.ctypes.data if hist is not None else None,
-        history_cap, C.byref(ctr), faults.ctypes.data, maxq.ctypes.data, maxsnap.ctypes.data, rs.ctypes.data, mr.ctypes.data)
+        history_cap, C.byref(ctr), faults.ctypes.data, maxq.ctypes.data, maxsnap.ctypes.data, rs.ctypes.data, mr.ctypes.data,
+        rh.ctypes.data if rh is not None else None, hash_cap)
     if rc < 0:
         raise RuntimeError("host model failed: %d" % rc)
     return {"commit_counts": commit_counts, "active_rounds": active_rounds, "last_states": last_states,
             "histories": hist, "counters": ctr.as_dict(), "faults": faults, "maxq": maxq, "maxsnap": maxsnap,
-            "round_switches": rs, "max_rounds": mr}
+            "round_switches": rs, "max_rounds": mr, "record_hashes": rh}

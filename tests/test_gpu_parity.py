@@ -368,3 +368,35 @@ def test_full_size_config5_8192x100_weighted_epochs_properties(amd, oracle):
     ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds[idx], max_clock, threads=2, history_cap=hist.shape[2])
     assert (cc[idx] == ref["commit_counts"]).all() and (res.active_rounds[idx] == ref["active_rounds"]).all()
     assert (res.last_committed_states[idx] == ref["last_states"]).all() and (hist[idx] == ref["histories"]).all()
+
+
+# Byte-exact record hashing (first half): lbft_batch_committed_record_hashes against the oracle's own records
+RECORD_HASHES = {
+    "golden_n3": (dict(num_nodes=3), 1000),
+    "n4": (dict(num_nodes=4), 1000),
+    "n7_weighted_epochs_q2": (dict(num_nodes=7, voting_rights=[2, 1, 1, 3, 1, 2, 1], commands_per_epoch=9, quirks=2), 2000),
+    "n4_rotating_rights_q3": (dict(num_nodes=4, commands_per_epoch=5, quirks=3, voting_rights=[1, 2, 3, 4], rights_rotation=1), 1500),
+    "n7_equivocators": (dict(num_nodes=7, equivocate_every=3), 1000),
+    "n40_long_tail": (dict(num_nodes=40, mean=10.0, variance=400.0), 300),
+}
+
+
+@pytest.mark.parametrize("name", sorted(RECORD_HASHES))
+def test_committed_record_hashes_equal_the_oracle(amd, oracle, name):
+    kw, max_clock = RECORD_HASHES[name]
+    n = kw["num_nodes"]
+    seeds = np.array([52, 7, 1234567], dtype=np.uint64)
+    _, res = run_gpu(amd, kw, seeds, max_clock)
+    assert not res.faults.any()
+    cfg = oracle.make_config(math_mode=1, **kw)
+    for i, seed in enumerate(seeds):
+        sim = oracle.OracleSim(cfg, int(seed)).run_until(max_clock)
+        for node in range(n):
+            ref = sim.committed_record_hashes(node)
+            got = res.committed_record_hashes(i, node)
+            assert len(got) == len(ref)
+            assert (got["block_hash"] == ref["block_hash"]).all() and (got["state"] == ref["state"]).all()
+            assert (got["qc_hash"] == ref["qc_hash"]).all() and (got["num_votes"] == ref["num_votes"]).all()
+            assert not got["flags"].any() and ref["has_qc"].all()
+            if len(ref):
+                assert int(got["state"][-1]) == int(res.last_committed_states[i, node])

@@ -320,3 +320,49 @@ def test_rotating_equal_rights_changes_nothing(oracle):
     base = oracle.run_batch(oracle.make_config(math_mode=1, num_nodes=4, quirks=3, commands_per_epoch=5), seeds, 1500, threads=8)
     rot = oracle.run_batch(oracle.make_config(math_mode=1, num_nodes=4, quirks=3, commands_per_epoch=5, rights_rotation=1), seeds, 1500, threads=8)
     assert (base["last_states"] == rot["last_states"]).all() and (base["commit_counts"] == rot["commit_counts"]).all()
+
+
+# Byte-exact record hashing (first half): the Block_ / QuorumCertificate_ records behind a node's committed
+# history, hashed like the reference's SmrContext::hash (SipHash-1-3 of "Name::" + BCS).  The oracle keeps real records in maps
+# keyed by these hashes; the compact model recomputes them from its block pool (structural ids, recorded QC voter sets).
+HASHES = {
+    "golden_n3": (dict(num_nodes=3), 52, 1000),
+    "n4": (dict(num_nodes=4), 7, 1000),
+    "n7_weighted_epochs_q2": (dict(num_nodes=7, voting_rights=[2, 1, 1, 3, 1, 2, 1], commands_per_epoch=9, quirks=2), 3, 2000),
+    "n4_rotating_rights_q3": (dict(num_nodes=4, commands_per_epoch=5, quirks=3, voting_rights=[1, 2, 3, 4], rights_rotation=1), 11, 1500),
+    "n7_equivocators": (dict(num_nodes=7, equivocate_every=3), 5, 1000),
+    "n40_long_tail": (dict(num_nodes=40, mean=10.0, variance=400.0), 9, 300),
+    "n4_lossy_long_tail": (dict(num_nodes=4, mean=10.0, variance=400.0, drop_per_million=50000), 4, 1500),
+    "n5_q1_partition": (dict(num_nodes=5, quirks=3, partition_size=2, partition_start=100, partition_end=400, commands_per_epoch=20), 8, 2000),
+}
+
+
+def assert_record_hashes_equal(oracle, cfg, seed, max_clock, n, device_hashes):
+    """device_hashes(node) -> structured or [k][4] array for that node; compared with the oracle's own records."""
+    sim = oracle.OracleSim(cfg, int(seed)).run_until(max_clock)
+    total = 0
+    for node in range(n):
+        ref = sim.committed_record_hashes(node)
+        got = device_hashes(node, len(ref))
+        assert ref["has_qc"].all()
+        assert (got[:, 0] == ref["block_hash"]).all(), node
+        assert (got[:, 1] == ref["state"]).all(), node
+        assert (got[:, 2] == ref["qc_hash"]).all(), node
+        assert ((got[:, 3] & 0xffffffff) == ref["num_votes"]).all() and ((got[:, 3] >> 32) == 0).all(), node
+        if len(ref):
+            assert int(ref["state"][-1]) == sim.last_committed_states()[node]
+        total += len(ref)
+    return total
+
+
+@pytest.mark.parametrize("name", sorted(HASHES))
+def test_committed_record_hashes_equal_the_oracle(oracle, name):
+    kw, seed, max_clock = HASHES[name]
+    n = kw["num_nodes"]
+    cfg = oracle.make_config(math_mode=1, **kw)
+    b = oracle.hostmodel_run_batch(cfg, np.array([seed], dtype=np.uint64), max_clock, qcap=max(4096, 16 * n * n),
+                                   scap=max(128, 128 * n) if kw.get("quirks", 0) & 1 else 64 if n <= 4 else 8 * n, bcap=1024, lcap=1024,
+                                   ql=16 if n <= 4 else 0, qheap=1 if n > 4 else 0, hash_cap=512)
+    assert not b["faults"].any()
+    total = assert_record_hashes_equal(oracle, cfg, seed, max_clock, n, lambda node, c: b["record_hashes"][0, node, :c])
+    assert total >= n // 2  # something was committed
