@@ -57,12 +57,19 @@ def test_random_configurations_match_the_oracle(oracle, chunk):
         scap = 64 if (n <= 4 and not special and rng.random() < 0.5) else max(128, 128 * n)
         b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=4, history_cap=96, qcap=max(4096, 24 * n * n), scap=scap,
                                        bcap=1024, lcap=1024, ql=int(rng.choice([0, 3, 11, 48])), qheap=qheap, qcal=qcal,
-                                       force_generic=int(rng.random() < 0.2))
+                                       force_generic=int(rng.random() < 0.2), hash_cap=1024 if n <= 16 else 0)
         assert not b["faults"].any(), kw
         for key in ("commit_counts", "active_rounds", "last_states", "histories"):
             assert (a[key] == b[key]).all(), (key, kw)
         for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
             assert a["counters"][key] == b["counters"][key], (key, kw)
+        if n <= 16:  # the reference's record hashes of the first network's committed chains (block, State, QC with its votes)
+            sim = oracle.OracleSim(cfg, int(seeds[0])).run_until(max_clock)
+            for node in range(n):
+                ref = sim.committed_record_hashes(node)
+                got = b["record_hashes"][0, node, :len(ref)]
+                assert (got[:, 0] == ref["block_hash"]).all() and (got[:, 1] == ref["state"]).all(), kw
+                assert (got[:, 2] == ref["qc_hash"]).all() and ((got[:, 3] >> 32) == 0).all() and ref["has_qc"].all(), kw
 
 
 # LBFT_FUZZ_GPU_CHUNKS=n widens the device run (10 configurations per chunk; the default keeps `pytest -m gpu` short)
