@@ -243,6 +243,16 @@ int lbft_node_create_notification(lbft_batch* b, size_t inst, uint32_t node, uin
  * reference would return Some(Request). */
 int lbft_node_handle_notification(lbft_batch* b, size_t inst, uint32_t receiver, uint32_t sender, uint32_t handle, uint32_t* should_sync);
 int lbft_node_release_notification(lbft_batch* b, size_t inst, uint32_t handle);
+/* The other half of the DataSyncNode trait (interfaces.rs:54-86), for batches created with quirks bit 0 (the record-exchange
+ * layout; LBFT_ERR_UNSUPPORTED otherwise).  Handles are snapshot slots like notification handles and are released with
+ * lbft_node_release_notification.
+ *   create_request  (data_sync.rs:66-71,179-181): the requester's epoch and known_quorum_certificate_rounds (record_store.rs:766-799)
+ *   handle_request  (data_sync.rs:183-207) on the node it was sent to: the records the requester lacks (unknown_records,
+ *                   record_store.rs:801-831), for every epoch from the requester's to the node's own -> a response handle
+ *   handle_response (data_sync.rs:209-240) on the requester: inserts them epoch by epoch, processing commits in between */
+int lbft_node_create_request(lbft_batch* b, size_t inst, uint32_t node, uint32_t* handle);
+int lbft_node_handle_request(lbft_batch* b, size_t inst, uint32_t node, uint32_t request, uint32_t* response);
+int lbft_node_handle_response(lbft_batch* b, size_t inst, uint32_t node, uint32_t peer, uint32_t response, int64_t node_time);
 int lbft_node_view_get(lbft_batch* b, size_t inst, uint32_t node, lbft_node_view* out);
 
 /* Stand-alone device checks of the third-party arithmetic (tests): each runs a tiny kernel.

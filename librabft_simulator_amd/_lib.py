@@ -107,7 +107,8 @@ ABI_SYMBOLS = [
     "lbft_batch_set_lds_queue_slots", "lbft_batch_set_calendar_queue", "lbft_batch_phase_cycles", "lbft_batch_layout",
     "lbft_batch_run_steps", "lbft_batch_checkpoint_bytes", "lbft_batch_checkpoint_save", "lbft_batch_checkpoint_load",
     "lbft_batch_enable_round_trace", "lbft_batch_round_switches", "lbft_batch_manual_begin", "lbft_batch_manual_finalize", "lbft_node_update", "lbft_node_create_notification",
-    "lbft_node_handle_notification", "lbft_node_release_notification", "lbft_node_view_get", "lbft_device_leaders", "lbft_device_sample_delays",
+    "lbft_node_handle_notification", "lbft_node_release_notification", "lbft_node_create_request", "lbft_node_handle_request",
+    "lbft_node_handle_response", "lbft_node_view_get", "lbft_device_leaders", "lbft_device_sample_delays",
     "lbft_device_exp_log", "lbft_last_error", "lbft_build_info",
 ]
 
@@ -187,6 +188,12 @@ def lib():
     L.lbft_node_handle_notification.restype = C.c_int
     L.lbft_node_release_notification.argtypes = [vp, C.c_size_t, C.c_uint32]
     L.lbft_node_release_notification.restype = C.c_int
+    L.lbft_node_create_request.argtypes = [vp, C.c_size_t, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.lbft_node_create_request.restype = C.c_int
+    L.lbft_node_handle_request.argtypes = [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.lbft_node_handle_request.restype = C.c_int
+    L.lbft_node_handle_response.argtypes = [vp, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int64]
+    L.lbft_node_handle_response.restype = C.c_int
     L.lbft_node_view_get.argtypes = [vp, C.c_size_t, C.c_uint32, C.POINTER(LbftNodeView)]
     L.lbft_node_view_get.restype = C.c_int
     L.lbft_batch_set_calendar_queue.argtypes = [vp, C.c_int]

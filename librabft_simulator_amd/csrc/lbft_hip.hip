@@ -256,7 +256,8 @@ __global__ void lbft_k_export_histories(Params p, const u32* __restrict__ state,
 }
 
 // Node-level interface (include/lbft.h lbft_node_*): one lane applies one trait call to one node.
-enum NodeOp : u32 { OP_UPDATE = 0, OP_CREATE_NOTIFICATION, OP_HANDLE_NOTIFICATION, OP_RELEASE_NOTIFICATION, OP_VIEW };
+enum NodeOp : u32 { OP_UPDATE = 0, OP_CREATE_NOTIFICATION, OP_HANDLE_NOTIFICATION, OP_RELEASE_NOTIFICATION, OP_VIEW,
+                    OP_CREATE_REQUEST, OP_HANDLE_REQUEST, OP_HANDLE_RESPONSE };
 __global__ void lbft_k_node_op(Params p, u32* __restrict__ state, u32 op, u32 inst, u32 node, u32 arg0, u32 arg1, i64 node_time,
                                unsigned long long* __restrict__ out) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -284,6 +285,27 @@ __global__ void lbft_k_node_op(Params p, u32* __restrict__ state, u32 op, u32 in
     out[0] = sync ? 1 : 0;
   } else if (op == OP_RELEASE_NOTIFICATION) {
     s.snap_release(arg1);
+  } else if (op == OP_CREATE_REQUEST) {  // DataSyncNode::create_request (data_sync.rs:66-71,179-181): epoch + the chains' heads
+    s.begin_node(node);
+    i32 slot = s.make_request_slot(s.nf(node, NF_EPOCH), s.nf(node, NF_HCC_BLK) | (s.nf(node, NF_HQC_BLK) << 16));
+    if (slot >= 0) s.st(p.off_snap_ref + (u32)slot, 1);
+    out[0] = (unsigned long long)(long long)slot;
+  } else if (op == OP_HANDLE_REQUEST) {  // DataSyncNode::handle_request on `node` (data_sync.rs:183-207): its store now + the request
+    s.begin_node(node);
+    u32 qb = s.sfw(arg1, 0);
+    u32 req_epoch = s.ld(qb + S_EPOCH), req_certs = s.ld(qb + S_CERTS);
+    i32 slot = s.snap_alloc();
+    if (slot >= 0) {
+      u32 rb = s.sfw((u32)slot, 0);
+      s.write_store_snapshot(node, rb);
+      s.st(s.sqw(rb, 0), req_epoch); s.st(s.sqw(rb, 1), req_certs);
+      s.st(p.off_snap_ref + (u32)slot, 1);
+    }
+    out[0] = (unsigned long long)(long long)slot;
+  } else if (op == OP_HANDLE_RESPONSE) {  // DataSyncNode::handle_response(response from peer arg0, clock) (data_sync.rs:209-240)
+    s.begin_node(node);
+    s.handle_response(node, arg0, arg1, node_time);
+    s.end_node(node);
   } else {  // OP_VIEW
     s.begin_node(node);
     out[0] = s.nf(node, NF_EPOCH); out[1] = s.nf(node, NF_CUR_ROUND); out[2] = s.nf(node, NF_HQC_ROUND);
@@ -602,6 +624,40 @@ int lbft_node_handle_notification(lbft_batch* b, size_t inst, uint32_t receiver,
   if (rc != LBFT_OK) return rc;
   if (should_sync) *should_sync = (uint32_t)h[0];
   return LBFT_OK;
+}
+// The request / response half of DataSyncNode needs the record-exchange layout of quirks bit 0 (request words in the
+// snapshot slots, archive of retired record stores).
+static int need_exchange_layout(const lbft_batch* b) {
+  if (b && !(b->p.quirks & 1u)) { g_err = "node-level requests / responses need a batch created with quirks bit 0"; return LBFT_ERR_UNSUPPORTED; }
+  return LBFT_OK;
+}
+int lbft_node_create_request(lbft_batch* b, size_t inst, uint32_t node, uint32_t* handle) {
+  if (!handle) return LBFT_ERR_INVALID;
+  int rc = need_exchange_layout(b);
+  if (rc != LBFT_OK) return rc;
+  unsigned long long h[1];
+  rc = node_op(b, OP_CREATE_REQUEST, inst, node, 0, 0, 0, h, 1);
+  if (rc != LBFT_OK) return rc;
+  if ((long long)h[0] < 0) { g_err = "no free snapshot slot (snapshot_capacity)"; return LBFT_ERR_FAULT; }
+  *handle = (uint32_t)h[0];
+  return LBFT_OK;
+}
+int lbft_node_handle_request(lbft_batch* b, size_t inst, uint32_t node, uint32_t request, uint32_t* response) {
+  if (!response || (b && request >= b->p.scap)) return LBFT_ERR_INVALID;
+  int rc = need_exchange_layout(b);
+  if (rc != LBFT_OK) return rc;
+  unsigned long long h[1];
+  rc = node_op(b, OP_HANDLE_REQUEST, inst, node, 0, request, 0, h, 1);
+  if (rc != LBFT_OK) return rc;
+  if ((long long)h[0] < 0) { g_err = "no free snapshot slot (snapshot_capacity)"; return LBFT_ERR_FAULT; }
+  *response = (uint32_t)h[0];
+  return LBFT_OK;
+}
+int lbft_node_handle_response(lbft_batch* b, size_t inst, uint32_t node, uint32_t peer, uint32_t response, int64_t node_time) {
+  if (b && (peer >= b->p.n || response >= b->p.scap)) return LBFT_ERR_INVALID;
+  int rc = need_exchange_layout(b);
+  if (rc != LBFT_OK) return rc;
+  return node_op(b, OP_HANDLE_RESPONSE, inst, node, peer, response, node_time, nullptr, 0);
 }
 int lbft_node_release_notification(lbft_batch* b, size_t inst, uint32_t handle) {
   if (b && handle >= b->p.scap) return LBFT_ERR_INVALID;

@@ -378,6 +378,28 @@ class NodeHandle:
         check(_lib.lib().lbft_node_handle_notification(self._sim._h, self.instance, self.author, sender, handle, C.byref(sync)))
         return bool(sync.value)
 
+    def create_request(self):
+        """DataSyncNode::create_request (data_sync.rs:66-71,179-181) -> opaque handle (batches with quirks bit 0)."""
+        h = C.c_uint32()
+        check(_lib.lib().lbft_node_create_request(self._sim._h, self.instance, self.author, C.byref(h)))
+        return (self.author, int(h.value))
+
+    def handle_request(self, request):
+        """DataSyncNode::handle_request (data_sync.rs:183-207): the records the requester lacks -> opaque response handle."""
+        _, handle = request
+        h = C.c_uint32()
+        check(_lib.lib().lbft_node_handle_request(self._sim._h, self.instance, self.author, handle, C.byref(h)))
+        return (self.author, int(h.value))
+
+    def handle_response(self, response, clock):
+        """DataSyncNode::handle_response(response, clock) (data_sync.rs:209-240)."""
+        peer, handle = response
+        check(_lib.lib().lbft_node_handle_response(self._sim._h, self.instance, self.author, peer, handle, int(clock)))
+
+    def release(self, message):
+        """Drops a notification / request / response handle."""
+        check(_lib.lib().lbft_node_release_notification(self._sim._h, self.instance, message[1]))
+
     def view(self):
         v = LbftNodeView()
         check(_lib.lib().lbft_node_view_get(self._sim._h, self.instance, self.author, C.byref(v)))

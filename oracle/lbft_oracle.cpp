@@ -1141,6 +1141,8 @@ struct lbft_oracle_sim {
   lbft_oracle_counters counters{};
   std::string error;
   std::vector<std::shared_ptr<Notification>> manual_notifications;  // node-level interface
+  std::vector<Request> manual_requests;
+  std::vector<Response> manual_responses;
   // DataWriter (bft-lib/src/data_writer.rs:10-60): first pop time at which each node was seen in each round
   bool data_writer = false;
   std::vector<u64> dw_max_round;
@@ -1389,6 +1391,28 @@ int lbft_oracle_node_handle_notification(lbft_oracle_sim* sim, uint32_t receiver
     SimNode& n = sim->nodes[receiver];
     std::optional<Request> r = n.node.handle_notification(n.context, *sim->manual_notifications[handle]);
     if (should_sync) *should_sync = r ? 1 : 0;
+    return 0;
+  } catch (const Panic& p) { sim->error = p.msg; return -2; }
+}
+int lbft_oracle_node_create_request(lbft_oracle_sim* sim, uint32_t node) {
+  if (!sim || node >= sim->nodes.size()) return -1;
+  try {
+    sim->manual_requests.push_back(sim->nodes[node].node.create_request_internal());
+    return (int)sim->manual_requests.size() - 1;
+  } catch (const Panic& p) { sim->error = p.msg; return -2; }
+}
+int lbft_oracle_node_handle_request(lbft_oracle_sim* sim, uint32_t node, int request) {
+  if (!sim || node >= sim->nodes.size() || request < 0 || (size_t)request >= sim->manual_requests.size()) return -1;
+  try {
+    sim->manual_responses.push_back(sim->nodes[node].node.handle_request(sim->manual_requests[request]));
+    return (int)sim->manual_responses.size() - 1;
+  } catch (const Panic& p) { sim->error = p.msg; return -2; }
+}
+int lbft_oracle_node_handle_response(lbft_oracle_sim* sim, uint32_t node, int response, int64_t node_time) {
+  if (!sim || node >= sim->nodes.size() || response < 0 || (size_t)response >= sim->manual_responses.size()) return -1;
+  try {
+    SimNode& n = sim->nodes[node];
+    n.node.handle_response(n.context, sim->manual_responses[response], node_time);
     return 0;
   } catch (const Panic& p) { sim->error = p.msg; return -2; }
 }

@@ -142,6 +142,10 @@ int lbft_oracle_node_update(lbft_oracle_sim* sim, uint32_t node, int64_t node_ti
 int lbft_oracle_node_create_notification(lbft_oracle_sim* sim, uint32_t node);
 /* DataSyncNode::handle_notification (data_sync.rs:113-177); *should_sync = a request was produced */
 int lbft_oracle_node_handle_notification(lbft_oracle_sim* sim, uint32_t receiver, int handle, uint32_t* should_sync);
+/* DataSyncNode::create_request (data_sync.rs:66-71,179-181) / handle_request (:183-207) / handle_response (:209-240); handles >= 0 */
+int lbft_oracle_node_create_request(lbft_oracle_sim* sim, uint32_t node);
+int lbft_oracle_node_handle_request(lbft_oracle_sim* sim, uint32_t node, int request);
+int lbft_oracle_node_handle_response(lbft_oracle_sim* sim, uint32_t node, int response, int64_t node_time);
 int lbft_oracle_node_view_get(const lbft_oracle_sim* sim, uint32_t node, lbft_oracle_node_view* out);
 
 /* DataWriter of the reference (bft-lib/src/data_writer.rs; `--create_csv`): enable before lbft_oracle_run_until.

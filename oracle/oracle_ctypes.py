@@ -134,6 +134,12 @@ def lib():
         L.lbft_oracle_node_create_notification.restype = C.c_int
         L.lbft_oracle_node_handle_notification.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
         L.lbft_oracle_node_handle_notification.restype = C.c_int
+        L.lbft_oracle_node_create_request.argtypes = [vp, C.c_uint32]
+        L.lbft_oracle_node_create_request.restype = C.c_int
+        L.lbft_oracle_node_handle_request.argtypes = [vp, C.c_uint32, C.c_int]
+        L.lbft_oracle_node_handle_request.restype = C.c_int
+        L.lbft_oracle_node_handle_response.argtypes = [vp, C.c_uint32, C.c_int, C.c_int64]
+        L.lbft_oracle_node_handle_response.restype = C.c_int
         L.lbft_oracle_node_view_get.argtypes = [vp, C.c_uint32, C.POINTER(OracleNodeView)]
         L.lbft_oracle_node_view_get.restype = C.c_int
         L.lbft_oracle_enable_data_writer.argtypes = [vp]
@@ -276,6 +282,23 @@ class OracleSim:
         if rc != 0:
             raise RuntimeError("oracle handle_notification failed: %d %s" % (rc, lib().lbft_oracle_last_error(self.h).decode()))
         return bool(sync.value)
+
+    def node_create_request(self, node):
+        h = lib().lbft_oracle_node_create_request(self.h, node)
+        if h < 0:
+            raise RuntimeError("oracle create_request failed: %d" % h)
+        return h
+
+    def node_handle_request(self, node, request):
+        h = lib().lbft_oracle_node_handle_request(self.h, node, request)
+        if h < 0:
+            raise RuntimeError("oracle handle_request failed: %d %s" % (h, lib().lbft_oracle_last_error(self.h).decode()))
+        return h
+
+    def node_handle_response(self, node, response, clock):
+        rc = lib().lbft_oracle_node_handle_response(self.h, node, response, clock)
+        if rc != 0:
+            raise RuntimeError("oracle handle_response failed: %d %s" % (rc, lib().lbft_oracle_last_error(self.h).decode()))
 
     def node_view(self, node):
         v = OracleNodeView()

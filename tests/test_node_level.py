@@ -34,13 +34,23 @@ class OracleDriver:
     def release(self, notification):
         pass
 
+    # DataSyncNode::create_request / handle_request / handle_response
+    def request(self, node):
+        return self.sim.node_create_request(node)
+
+    def respond(self, node, request):
+        return self.sim.node_handle_request(node, request)
+
+    def absorb(self, node, response, clock):
+        self.sim.node_handle_response(node, response, clock)
+
 
 class DeviceDriver:
     def __init__(self, amd, n, **kw):
         nc = amd.NodeConfig(kw.get("target_commit_interval", 100000), kw.get("delta", 20), kw.get("gamma", 2.0), kw.get("lambda_", 0.5))
         self.sim = amd.BatchSimulator.new(np.array([1, 2], dtype=np.uint64), n, amd.RandomDelay.new(10.0, 4.0), nc,
                                           commands_per_epoch=kw.get("commands_per_epoch", 30000),
-                                          voting_rights=kw.get("voting_rights"), snapshot_capacity=64)
+                                          voting_rights=kw.get("voting_rights"), snapshot_capacity=64, quirks=kw.get("quirks", 0))
         self.nodes = self.sim.manual(100000)[1]  # instance 1 (instance 0 stays untouched)
         self.n = n
 
@@ -59,11 +69,22 @@ class DeviceDriver:
     def release(self, notification):
         self.sim.release_notification(1, notification)
 
+    def request(self, node):
+        return self.nodes[node].create_request()
 
-def full_exchange(d, clock, trace, rounds=1):
+    def respond(self, node, request):
+        return self.nodes[node].handle_request(request)
+
+    def absorb(self, node, response, clock):
+        self.nodes[node].handle_response(response, clock)
+
+
+def full_exchange(d, clock, trace, rounds=1, members=None):
     """Every node updates at `clock`; each node whose actions ask for it sends its notification to the named
-    receivers (broadcast = everybody else) and those update again -- repeated until nothing is sent."""
-    pending = list(range(d.n))
+    receivers (broadcast = everybody else) and those update again -- repeated until nothing is sent.
+    `members`: only these nodes take part (the others neither run nor receive anything)."""
+    members = list(range(d.n)) if members is None else list(members)
+    pending = list(members)
     for _ in range(200):
         if not pending:
             break
@@ -71,7 +92,7 @@ def full_exchange(d, clock, trace, rounds=1):
         for node in pending:
             a = d.update(node, clock)
             trace.append(("update", node, clock, a, d.view(node)))
-            receivers = [r for r in range(d.n) if r != node] if a["should_broadcast"] else [r for r in a["should_send"] if r != node]
+            receivers = [r for r in members if r != node] if a["should_broadcast"] else [r for r in a["should_send"] if r != node and r in members]
             if receivers:
                 note = d.notify(node)
                 for r in receivers:
@@ -182,7 +203,52 @@ def test_oracle_commit_needs_three_contiguous_certified_rounds(oracle):
         assert v["commit_count"] == v["highest_committed_round"] - 1
 
 
+def scenario_catch_up(d, clocks=400):
+    """Nodes 0-2 (a quorum of 4) run on their own; node 3 hears nothing.  Then node 3 asks node 0 for what it lacks
+    (create_request -> handle_request -> handle_response, data_sync.rs:66-71,183-240) and catches up: the other half of the
+    DataSyncNode trait.  Rounds led by node 3 end in timeouts of the others."""
+    trace = []
+    for clock in range(0, clocks):
+        full_exchange(d, clock, trace, members=[0, 1, 2])
+    behind = d.view(3)
+    trace.append(("behind", 3, behind))
+    req = d.request(3)
+    resp = d.respond(0, req)
+    d.absorb(3, resp, clocks)
+    trace.append(("absorbed", 3, d.view(3)))
+    trace.append(("update", 3, clocks, d.update(3, clocks), d.view(3)))
+    d.release(req)
+    d.release(resp)
+    # a second exchange brings nothing new
+    req = d.request(3)
+    resp = d.respond(1, req)
+    d.absorb(3, resp, clocks)
+    trace.append(("absorbed again", 3, d.view(3)))
+    d.release(req)
+    d.release(resp)
+    for clock in range(clocks, clocks + 4):  # and node 3 takes part from now on
+        full_exchange(d, clock, trace)
+    return trace
+
+
+def test_oracle_lagging_node_catches_up_through_request_and_response(oracle):
+    d = OracleDriver(oracle, 4, quirks=1)
+    trace = scenario_catch_up(d)
+    behind = [t for t in trace if t[0] == "behind"][0][2]
+    caught = [t for t in trace if t[0] == "absorbed"][0][2]
+    ahead = d.view(0)
+    assert behind["highest_quorum_certificate_round"] == 0 and behind["commit_count"] == 0
+    assert caught["highest_quorum_certificate_round"] >= 4 and caught["highest_committed_round"] >= 2
+    again = [t for t in trace if t[0] == "absorbed again"][0][2]
+    updated = [t for t in trace if t[0] == "update" and t[1] == 3][0][4]
+    assert again == updated  # nothing new in the second response
+    assert d.view(3)["commit_count"] >= ahead["commit_count"] - 3
+
+
 SESSIONS = {
+    "catch_up_4": (4, dict(quirks=1), lambda d: scenario_catch_up(d)),
+    "catch_up_4_across_epochs": (4, dict(quirks=3, commands_per_epoch=3), lambda d: scenario_catch_up(d)),
+    "catch_up_7_weighted": (7, dict(quirks=1, voting_rights=[3, 1, 1, 2, 1, 1, 2]), lambda d: scenario_catch_up(d, 500)),
     "healthy_4": (4, {}, lambda d: scenario_healthy_rounds(d)),
     "healthy_7_weighted": (7, dict(voting_rights=[3, 1, 1, 2, 1, 1, 2]), lambda d: scenario_healthy_rounds(d)),
     "timeouts_4": (4, {}, lambda d: scenario_timeouts(d)[0]),
