@@ -173,7 +173,7 @@ int lbft_batch_last_run_ms(const lbft_batch* b, float* init_ms, float* run_ms);
 size_t lbft_batch_device_bytes(const lbft_batch* b);
 /* Sizes behind the roofline arithmetic (bench.py): out[8] = bytes of one node's rows, of one queued event, of one
  * notification snapshot, of one block record, HBM bytes per instance, LDS-resident queue slots, lanes per wavefront,
- * kernel size class | heap-queue flag << 8 | calendar-queue flag << 9. */
+ * kernel size class | heap-queue flag << 8 | calendar-queue flag << 9 | lean-large-network-kernel flag << 10. */
 int lbft_batch_layout(const lbft_batch* b, uint32_t* out);
 /* Events processed per run-kernel launch (0 = whole simulation in one launch). */
 int lbft_batch_set_max_steps(lbft_batch* b, uint32_t max_steps);

@@ -405,14 +405,18 @@ struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at
 //   2  n <= 128, multi-word node/author sets (extension rows), heap event queue, receiver list in HBM rows
 //   3  everything decided at run time (init / read-back kernels)
 // sim_class() picks the class a batch runs with.
+//   5  class 2 without the record exchange of quirks bit 0, the round-switch trace and the lossy network (sim_lean()): the
+//      plain large-network path fits 256 registers (21 spilled) and runs two wavefronts per SIMD with half the lanes each
 template <int CLS>
 struct SimT {
-  LBFT_HD bool wide() const { return CLS == 2 ? true : (CLS == 3 ? P.n > 32 : false); }
-  LBFT_HD bool heap() const { return CLS == 0 ? false : (CLS == 2 ? true : P.qheap != 0); }
-  LBFT_HD bool tracing() const { return CLS != 0 && P.rcap != 0; }  // round-switch trace (DataWriter); class 0 never traces
-  LBFT_HD bool q1() const { return CLS != 0 && (P.quirks & 1u) != 0; }  // requests are answered by the peer with real payloads
+  static constexpr bool BIG = CLS == 2 || CLS == 5;   // multi-word node / author sets
+  static constexpr bool LEAN = CLS == 5;
+  LBFT_HD bool wide() const { return BIG ? true : (CLS == 3 ? P.n > 32 : false); }
+  LBFT_HD bool heap() const { return CLS == 0 ? false : (BIG ? true : P.qheap != 0); }
+  LBFT_HD bool tracing() const { return CLS != 0 && !LEAN && P.rcap != 0; }  // round-switch trace (DataWriter); class 0 never traces
+  LBFT_HD bool q1() const { return CLS != 0 && !LEAN && (P.quirks & 1u) != 0; }  // requests are answered by the peer with real payloads
   LBFT_HD bool cal() const { return CLS != 0 && P.qcal != 0; }
-  LBFT_HD bool packed() const { return CLS == 0 ? true : (CLS == 2 ? false : P.n <= 16); }
+  LBFT_HD bool packed() const { return CLS == 0 ? true : (BIG ? false : P.n <= 16); }
   LBFT_HD bool qpacked() const { return CLS == 0 ? true : (CLS == 3 ? P.qpack != 0 : false); }  // one-word queue entries
   const Params& P;
   char* tile;
@@ -976,7 +980,7 @@ struct SimT {
   }
 
   // extension "lossy network": called right after a message's delay draw; true = the message is lost
-  LBFT_HD bool lossy() const { return CLS != 0 && (P.drop_ppm | P.part_size) != 0; }
+  LBFT_HD bool lossy() const { return CLS != 0 && !LEAN && (P.drop_ppm | P.part_size) != 0; }
   LBFT_HD bool net_lost(u32 a, u32 b) {
     if (!lossy()) return false;
     bool lost = false;
@@ -2124,6 +2128,9 @@ inline int sim_class(const Params& p) {
   bool fits_packed_queue = p.max_clock < (1 << LBFT_QP_TIME_BITS) && p.scap <= 256;  // one-word queue entries
   return small && fits_packed_queue ? 0 : 1;
 }
+
+// Does a class-2 batch qualify for the lean large-network kernel (SimT<5>)?
+inline bool sim_lean(const Params& p) { return sim_class(p) == 2 && !(p.quirks & 1u) && !p.rcap && !p.drop_ppm && !p.part_size; }
 
 // Row layout for a batch; fills the offset fields of `p` and returns words per instance.
 inline u32 compute_layout(Params& p) {

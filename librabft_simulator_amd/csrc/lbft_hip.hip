@@ -147,6 +147,9 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
 // wavefront per SIMD and may use the whole register file (VGPRs + AGPRs).
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run0(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { run_body<0>(p, state, unfinished); }
+// Large networks without record exchange / trace / lossy network (sim_lean()): also two wavefronts per SIMD (21 spilled registers)
+__global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
+void lbft_k_run2l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { run_body<5>(p, state, unfinished); }
 #ifndef LBFT_BIG_WAVES_PER_SIMD
 #define LBFT_BIG_WAVES_PER_SIMD 1  // classes 1-2: wavefronts per SIMD the kernels are compiled for (1 = the whole register file;
                                    // measured with 2 -- half the lanes per wavefront, 167 spilled registers: 16384 x 64 nodes
@@ -747,7 +750,7 @@ int lbft_batch_layout(const lbft_batch* b, uint32_t* out) {
   out[4] = p.total_words * 4; // HBM bytes per instance
   out[5] = p.ql;              // event-queue slots per instance resident in LDS
   out[6] = p.lpw;             // lanes per wavefront carrying an instance
-  out[7] = (uint32_t)sim_class(p) | (p.qheap << 8) | (p.qcal << 9);
+  out[7] = (uint32_t)sim_class(p) | (p.qheap << 8) | (p.qcal << 9) | ((sim_lean(p) ? 1u : 0u) << 10);
   return LBFT_OK;
 }
 
@@ -823,7 +826,7 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
     // wavefront-step costs the union of its lanes' paths (65536 x 4 nodes, r01_s3 build: 27.0 ms at 64 lanes = one wavefront
     // per SIMD, 24.4 ms at 32 = two per SIMD, 40.1 ms at 16 = two rounds; 1024 x 4 nodes: 22.9 ms at 8 lanes, 17.6 at 4,
     // 13.2 at 2, 9.4 ms at ONE network per wavefront; 8192 x 100 nodes: 9.0 s at 16 lanes, 5.9 s at 8, 7.8 s at 4 = two rounds).
-    u64 resident = sim_class(p) == 0 ? 2048 : 1024 * LBFT_BIG_WAVES_PER_SIMD;
+    u64 resident = (sim_class(p) == 0 || sim_lean(p)) ? 2048 : 1024 * LBFT_BIG_WAVES_PER_SIMD;
     u64 want = (b->m + resident - 1) / resident;
     lpw = 1;
     while (lpw < want && lpw < 32) lpw <<= 1;
@@ -882,12 +885,14 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
 static int launch_run(lbft_batch* b) {
   Params& p = b->p;
   int cls = sim_class(p);
-  const void* run_fn = cls == 0 ? reinterpret_cast<const void*>(lbft_k_run0)
+  bool lean = sim_lean(p);
+  const void* run_fn = lean ? reinterpret_cast<const void*>(lbft_k_run2l) : cls == 0 ? reinterpret_cast<const void*>(lbft_k_run0)
                      : cls == 1 ? reinterpret_cast<const void*>(lbft_k_run<1>) : reinterpret_cast<const void*>(lbft_k_run<2>);
   HIP_TRY(hipFuncSetAttribute(run_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
   u32 grid_run = (u32)((b->m + (size_t)LBFT_RUN_WAVES * p.lpw - 1) / ((size_t)LBFT_RUN_WAVES * p.lpw));
   HIP_TRY(hipMemsetAsync(b->d_unfinished, 0, sizeof(u32), b->stream));
-  if (cls == 0) lbft_k_run0<<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  if (lean) lbft_k_run2l<<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  else if (cls == 0) lbft_k_run0<<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (cls == 1) lbft_k_run<1><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else lbft_k_run<2><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   HIP_TRY(hipGetLastError());
