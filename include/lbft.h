@@ -138,8 +138,8 @@ int lbft_batch_active_rounds(const lbft_batch* b, uint64_t* out);
 int lbft_batch_committed_history(const lbft_batch* b, size_t inst, uint32_t node, lbft_commit* out, size_t cap, size_t* len);
 /* The records behind one node's committed history with the hashes the reference gives them: SmrContext::hash = SipHash-1-3
  * (Rust DefaultHasher) of "Name::" + BCS bytes (smr_context.rs:84-95, simulated_context.rs:238-242).  Entry k describes the
- * Block_ that carried the k-th committed command (record.rs:45-60), the State after executing it (simulated_context.rs:51-55)
- * and the QuorumCertificate_ certifying the block (record.rs:79-100; its Vote_s, record.rs:62-77, in author order).  The event
+ * Block_ that carried the k-th committed command (record.rs:51-63), the State after executing it (simulated_context.rs:51-55)
+ * and the QuorumCertificate_ certifying the block (record.rs:82-99; its Vote_s, record.rs:65-80, in author order).  The event
  * loop never needs these hashes (records are identified structurally); they are recomputed on the device
  * from the block pool, so that simulated state can be related to what a reference node would store or put on the wire
  * (first half).  flags: bit 0 = no QC recorded for the block, bit 1 = internal inconsistency.

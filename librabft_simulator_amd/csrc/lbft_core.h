@@ -351,7 +351,7 @@ LBFT_HD u64 record_hash_epoch_id(u64 e) {
   h.u64le(e);
   return h.finish();
 }
-// Block_ (record.rs:45-60): command (proposer, index), time, previous_quorum_certificate_hash, round, author
+// Block_ (record.rs:51-63): command (proposer, index), time, previous_quorum_certificate_hash, round, author
 LBFT_HD u64 record_hash_block(u64 proposer, u64 index, i64 time, u64 prev_qc_hash, u64 round, u64 author) {
   SipBytes h; h.init();
   const char name[] = "Block_::";
@@ -359,7 +359,7 @@ LBFT_HD u64 record_hash_block(u64 proposer, u64 index, i64 time, u64 prev_qc_has
   h.u64le(proposer); h.u64le(index); h.u64le((u64)time); h.u64le(prev_qc_hash); h.u64le(round); h.u64le(author);
   return h.finish();
 }
-// Vote_ (record.rs:62-77): epoch_id, round, certified_block_hash, state, committed_state, author
+// Vote_ (record.rs:65-80): epoch_id, round, certified_block_hash, state, committed_state, author
 LBFT_HD u64 record_hash_vote(u64 epoch, u64 round, u64 block_hash, u64 state, bool has_cs, u64 cs, u64 author) {
   SipBytes h; h.init();
   const char name[] = "Vote_::";
@@ -1943,7 +1943,7 @@ struct SimT {
       bool has_cs = prev && pp && round == prev_round + 1 && prev_round == pp_round + 1;
       if (has_cs && pp != y_prev2) flags |= 2;
       u64 cs = has_cs ? state_prev2 : 0;
-      // QuorumCertificate_ (record.rs:79-100): epoch_id, round, certified_block_hash, state, committed_state, votes, author
+      // QuorumCertificate_ (record.rs:82-99): epoch_id, round, certified_block_hash, state, committed_state, votes, author
       SipBytes hq; hq.init();
       const char name[] = "QuorumCertificate_::";
       for (u32 i = 0; i < sizeof(name) - 1; i++) hq.byte((u32)name[i]);

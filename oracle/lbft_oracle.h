@@ -96,8 +96,8 @@ size_t lbft_oracle_commit_count(const lbft_oracle_sim* sim, uint32_t node);
 size_t lbft_oracle_committed_history(const lbft_oracle_sim* sim, uint32_t node, lbft_oracle_commit* out, size_t cap);
 uint64_t lbft_oracle_last_committed_state(const lbft_oracle_sim* sim, uint32_t node);
 /* The records behind a node's committed history, as the reference would hash them (smr_context.rs:84-95: SipHash-1-3 of
- * "Name::" + BCS): entry k = the Block that carried the k-th committed command (record.rs:45-60), the State after executing it
- * and the QuorumCertificate (record.rs:79-100) that certified the block, all taken from the node's own record stores.
+ * "Name::" + BCS): entry k = the Block that carried the k-th committed command (record.rs:51-63), the State after executing it
+ * and the QuorumCertificate (record.rs:82-99) that certified the block, all taken from the node's own record stores.
  * qc_hash == 0 with has_qc == 0: the node holds no QC for the block (cannot happen for a committed block).
  * Copies min(cap, len) entries, returns len. */
 typedef struct lbft_oracle_record_hash { uint64_t block_hash, state, qc_hash; uint32_t has_qc, num_votes; } lbft_oracle_record_hash;
