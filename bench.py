@@ -173,7 +173,7 @@ def main():
             "faulted_instances": faulted,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["gb_corrected"] if traffic else None, "traffic_unit": "GB per launch",
-                         "traffic_detail": traffic, "kernel": "lbft_k_run0" if layout.get("kernel_class", 0) == 0 else "lbft_k_run2l" if layout["kernel_class"] & 1024 else "lbft_k_run<%d>" % (layout["kernel_class"] & 255), "kernel_ms": k_ms,
+                         "traffic_detail": traffic, "kernel": "lbft_k_run0" if layout.get("kernel_class", 0) == 0 else ("lbft_k_run2l" if (layout["kernel_class"] & 255) == 2 else "lbft_k_run1l") if layout["kernel_class"] & 1024 else "lbft_k_run<%d>" % (layout["kernel_class"] & 255), "kernel_ms": k_ms,
                          "algorithmic_bytes_per_event": bpe, "algorithmic_gb_per_launch": local_events * bpe / 1e9,
                          "events_per_launch": local_events, "layout": layout},
         }

@@ -410,7 +410,7 @@ struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at
 template <int CLS>
 struct SimT {
   static constexpr bool BIG = CLS == 2 || CLS == 5;   // multi-word node / author sets
-  static constexpr bool LEAN = CLS == 5;
+  static constexpr bool LEAN = CLS == 5 || CLS == 6;  // 6 = class 1 without those three (13 spilled registers at 256)
   LBFT_HD bool wide() const { return BIG ? true : (CLS == 3 ? P.n > 32 : false); }
   LBFT_HD bool heap() const { return CLS == 0 ? false : (BIG ? true : P.qheap != 0); }
   LBFT_HD bool tracing() const { return CLS != 0 && !LEAN && P.rcap != 0; }  // round-switch trace (DataWriter); class 0 never traces
@@ -2129,8 +2129,10 @@ inline int sim_class(const Params& p) {
   return small && fits_packed_queue ? 0 : 1;
 }
 
-// Does a class-2 batch qualify for the lean large-network kernel (SimT<5>)?
-inline bool sim_lean(const Params& p) { return sim_class(p) == 2 && !(p.quirks & 1u) && !p.rcap && !p.drop_ppm && !p.part_size; }
+// Does a class-2 / class-1 batch qualify for the lean kernel of its class (SimT<5> / SimT<6>)?
+inline bool sim_lean_features(const Params& p) { return !(p.quirks & 1u) && !p.rcap && !p.drop_ppm && !p.part_size; }
+inline bool sim_lean(const Params& p) { return sim_class(p) == 2 && sim_lean_features(p); }
+inline bool sim_lean1(const Params& p) { return sim_class(p) == 1 && sim_lean_features(p); }
 
 // Row layout for a batch; fills the offset fields of `p` and returns words per instance.
 inline u32 compute_layout(Params& p) {

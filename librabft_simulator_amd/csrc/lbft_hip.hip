@@ -150,6 +150,9 @@ void lbft_k_run0(Params p, u32* __restrict__ state, u32* __restrict__ unfinished
 // Large networks without record exchange / trace / lossy network (sim_lean()): also two wavefronts per SIMD (21 spilled registers)
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run2l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { run_body<5>(p, state, unfinished); }
+// ... and class 1 without them (networks of <= 32 nodes with equivocators, a heap / calendar queue, ...): 13 spilled registers
+__global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
+void lbft_k_run1l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { run_body<6>(p, state, unfinished); }
 #ifndef LBFT_BIG_WAVES_PER_SIMD
 #define LBFT_BIG_WAVES_PER_SIMD 1  // classes 1-2: wavefronts per SIMD the kernels are compiled for (1 = the whole register file;
                                    // measured with 2 -- half the lanes per wavefront, 167 spilled registers: 16384 x 64 nodes
@@ -750,7 +753,7 @@ int lbft_batch_layout(const lbft_batch* b, uint32_t* out) {
   out[4] = p.total_words * 4; // HBM bytes per instance
   out[5] = p.ql;              // event-queue slots per instance resident in LDS
   out[6] = p.lpw;             // lanes per wavefront carrying an instance
-  out[7] = (uint32_t)sim_class(p) | (p.qheap << 8) | (p.qcal << 9) | ((sim_lean(p) ? 1u : 0u) << 10);
+  out[7] = (uint32_t)sim_class(p) | (p.qheap << 8) | (p.qcal << 9) | (((sim_lean(p) || sim_lean1(p)) ? 1u : 0u) << 10);
   return LBFT_OK;
 }
 
@@ -804,7 +807,9 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   // epochs a node can go through are bounded by its commits: the archive of retired record stores (quirks bit 0) is exact
   u64 eauto = (u64)bcap / (c.commands_per_epoch ? c.commands_per_epoch : 1) + 2;
   u32 ecap = (p.quirks & 1u) ? (u32)(eauto > 4096 ? 4096 : eauto) : 0;
-  u32 qcal = (!class0 && !b->rcap && b->allow_calendar && max_clock <= LBFT_CAL_MAX_CLOCK) ? 1u : 0u;
+  // (the calendar replaces the HEAP: a small network outside class 0 -- e.g. 4 nodes with an equivocator -- keeps the LDS-fronted
+  // array; 65536 x 4 nodes with one equivocator each: 28.6 ms on the array, 43.6 ms on the HBM calendar)
+  u32 qcal = (!class0 && big && !b->rcap && b->allow_calendar && max_clock <= LBFT_CAL_MAX_CLOCK) ? 1u : 0u;
   bool relayout = !(p.qcap == qcap && p.scap == scap && p.bcap == bcap && p.lcap == lcap && p.rcap == b->rcap && p.qcal == qcal && p.ecap == ecap &&
                     p.max_clock == (i32)max_clock && b->d_state);
   p.qcap = qcap; p.scap = scap; p.bcap = bcap; p.lcap = lcap; p.rcap = b->rcap; p.qcal = qcal; p.qheap = qheap; p.ecap = ecap;
@@ -826,7 +831,7 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
     // wavefront-step costs the union of its lanes' paths (65536 x 4 nodes, r01_s3 build: 27.0 ms at 64 lanes = one wavefront
     // per SIMD, 24.4 ms at 32 = two per SIMD, 40.1 ms at 16 = two rounds; 1024 x 4 nodes: 22.9 ms at 8 lanes, 17.6 at 4,
     // 13.2 at 2, 9.4 ms at ONE network per wavefront; 8192 x 100 nodes: 9.0 s at 16 lanes, 5.9 s at 8, 7.8 s at 4 = two rounds).
-    u64 resident = (sim_class(p) == 0 || sim_lean(p)) ? 2048 : 1024 * LBFT_BIG_WAVES_PER_SIMD;
+    u64 resident = (sim_class(p) == 0 || sim_lean(p) || sim_lean1(p)) ? 2048 : 1024 * LBFT_BIG_WAVES_PER_SIMD;
     u64 want = (b->m + resident - 1) / resident;
     lpw = 1;
     while (lpw < want && lpw < 32) lpw <<= 1;
@@ -885,13 +890,14 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
 static int launch_run(lbft_batch* b) {
   Params& p = b->p;
   int cls = sim_class(p);
-  bool lean = sim_lean(p);
-  const void* run_fn = lean ? reinterpret_cast<const void*>(lbft_k_run2l) : cls == 0 ? reinterpret_cast<const void*>(lbft_k_run0)
+  bool lean = sim_lean(p), lean1 = sim_lean1(p);
+  const void* run_fn = lean ? reinterpret_cast<const void*>(lbft_k_run2l) : lean1 ? reinterpret_cast<const void*>(lbft_k_run1l) : cls == 0 ? reinterpret_cast<const void*>(lbft_k_run0)
                      : cls == 1 ? reinterpret_cast<const void*>(lbft_k_run<1>) : reinterpret_cast<const void*>(lbft_k_run<2>);
   HIP_TRY(hipFuncSetAttribute(run_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
   u32 grid_run = (u32)((b->m + (size_t)LBFT_RUN_WAVES * p.lpw - 1) / ((size_t)LBFT_RUN_WAVES * p.lpw));
   HIP_TRY(hipMemsetAsync(b->d_unfinished, 0, sizeof(u32), b->stream));
   if (lean) lbft_k_run2l<<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  else if (lean1) lbft_k_run1l<<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (cls == 0) lbft_k_run0<<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (cls == 1) lbft_k_run<1><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else lbft_k_run<2><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);

@@ -112,6 +112,7 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
       { Sim s0(p, state.data(), (u32)i); s0.init(seeds[i]); }
       // emulate the device's launch structure: the LDS front of the queue is a cache of the HBM rows
       if (cls == 0) { SimT<0> s(p, state.data(), (u32)i); run_one(s, i); }
+      else if (cls == 1 && sim_lean1(p)) { SimT<6> s(p, state.data(), (u32)i); run_one(s, i); }  // as the device dispatches
       else if (cls == 1) { SimT<1> s(p, state.data(), (u32)i); run_one(s, i); }
       else if (cls == 2 && sim_lean(p)) { SimT<5> s(p, state.data(), (u32)i); run_one(s, i); }  // as the device dispatches
       else if (cls == 2) { SimT<2> s(p, state.data(), (u32)i); run_one(s, i); }

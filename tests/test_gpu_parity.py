@@ -124,10 +124,10 @@ def test_gpu_equals_oracle(amd, oracle, name):
     assert_equal_to_oracle(oracle, res, kw, seeds, max_clock, cap=512 if max_clock > 3000 else 256)
 
 
-@pytest.mark.parametrize("name", ["n8", "n64_long_tail", "equiv_n4", "lossy_drop_partition_n40"])
+@pytest.mark.parametrize("name", ["n8", "n64_long_tail", "equiv_n7_every_third", "lossy_drop_partition_n40"])
 def test_heap_queue_equals_calendar_queue(amd, oracle, name):
-    """Outside kernel class 0 the event queue is a calendar when max_clock <= 2047 (default in CASES above) and a binary
-    heap otherwise; both must give the oracle's results."""
+    """Outside kernel class 0, networks whose queue capacity exceeds 256 events use a calendar when max_clock <= 2047 (default in
+    CASES above) and a binary heap otherwise (smaller ones keep the LDS-fronted array); both must give the oracle's results."""
     kw, m, max_clock = CASES[name]
     seeds = np.arange(1, m + 1, dtype=np.uint64) * 104729 + 17
     sim, res = run_gpu(amd, kw, seeds, max_clock, calendar_queue=False)
