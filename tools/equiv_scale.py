@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Runs on the GPU box: the headline batch shape with one equivocating leader per network (kernel class 1, lean kernel
+lbft_k_run1l), with the automatic queue discipline and with the calendar switched off."""
 import sys, json
 sys.path.insert(0, '.')
 import numpy as np
