@@ -1464,19 +1464,20 @@ struct SimT {
   // hcbr words of the authors in `mask` (author = author0 + bit): node buffer -> snapshot, four loads in flight at a
   // time (a load-store-load-store chain would be one memory round trip per author)
   LBFT_HD void copy_hcbr(u32 node, u32 slot, u32 mask, u32 author0, u32 buf, u32 snap_word0) const {
+    constexpr u32 B = BIG ? 8 : 4;  // loads in flight per round trip (large networks copy dozens of words per notification)
     while (mask) {
-      u32 a[4], h[4], k = 0;
+      u32 a[B], h[B], k = 0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (u32 j = 0; j < 4; j++) {
+      for (u32 j = 0; j < B; j++) {
         a[j] = 0; h[j] = 0;
         if (mask) { a[j] = author0 + ctz32(mask); mask &= mask - 1; h[j] = hc_get(node, buf, a[j]); k = j + 1; }
       }
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (u32 j = 0; j < 4; j++)
+      for (u32 j = 0; j < B; j++)
         if (j < k) st(sfw(slot, snap_word0 + a[j]), h[j]);
     }
   }
