@@ -39,7 +39,7 @@ def parse():
 
 def algorithmic_bytes_per_event(layout, counters):
     """SURVEY.md 8(d) with this build's struct sizes (DESIGN.md "Roofline"), taken from the library itself
-    (lbft_batch_layout): 2*S_node + S_evt*(1 + p) + S_notif*(w + r)."""
+    (lbft_batch_layout): 2*S_node + S_evt*(1 + p) + S_notif*(w + r), charged to every reference-equivalent event."""
     ev = sum(counters["events"])
     s_node, s_evt, s_notif = layout["node_bytes"], layout["event_bytes"], layout["snapshot_bytes"]
     p = counters["events_scheduled"] / max(ev, 1)
@@ -47,17 +47,34 @@ def algorithmic_bytes_per_event(layout, counters):
     return 2 * s_node + s_evt * (1 + p) + s_notif * (r + r)
 
 
+def executed_bytes(layout, counters):
+    """The same formula charged only where the device moves the rows: duplicate timers folded at scheduling time never reach
+    the queue nor load a node row (they are counted in events[3] to keep the reference's totals); cancelled timers and
+    requests load a node's rows but do not write them back.  pops = events - timers_folded; node rows are read once per pop
+    and written once per update_node call; one queue entry written and read per pop; notification snapshots as in 8(d)."""
+    ev = sum(counters["events"])
+    pops = ev - counters.get("timers_folded", 0)
+    s_node, s_evt, s_notif = layout["node_bytes"], layout["event_bytes"], layout["snapshot_bytes"]
+    return pops * s_node + counters.get("node_updates", pops) * s_node + 2 * pops * s_evt + 2 * counters["events"][0] * s_notif, pops
+
+
 def measured_traffic_gb():
     """HBM bytes per launch of lbft_k_run from the PMC passes (FETCH_SIZE / WRITE_SIZE, collected in their own
     rocprofv3 runs of this same command by tools/gpu_profile.sh and committed under profiles/).  FETCH_SIZE is
     doubled as MI355X_MICROARCH.md prescribes for gfx950 (it tallies 128-byte requests as 64 bytes); the value is
-    therefore an upper bound for narrow accesses.  None when no profile of the current kernel is committed."""
+    therefore an upper bound for narrow accesses.  PMC counters cannot be collected from inside this process, so the
+    profile is stamped with the hash of the kernel sources it was taken from (librabft_simulator_amd.build.source_hash):
+    None when no profile of the CURRENT sources is committed -- a stale number is never replayed."""
     path = os.path.join(ROOT, "profiles", "current", "pmc_traffic.json")
     try:
+        from librabft_simulator_amd.build import source_hash
         with open(path) as f:
             t = json.load(f)
+        if t.get("source_hash") != source_hash():
+            return None
         return {"fetch_kb_raw": t["FETCH_SIZE"], "write_kb_raw": t["WRITE_SIZE"],
-                "gb_corrected": (2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024 / 1e9, "profile": t.get("profile")}
+                "gb_corrected": (2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024 / 1e9, "profile": t.get("profile"),
+                "source_hash": t.get("source_hash")}
     except Exception:
         return None
 
@@ -143,16 +160,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     c = res.counters
-    local = torch.tensor([c["rounds"], c["commits"], sum(c["events"]), c["faulted_instances"]], dtype=torch.float64,
-                         device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if dist is not None and args.backend != "nccl":  # rehearsal backends reduce host tensors
-        local, tmax = local.cpu(), tmax.cpu()
-    if dist is not None:
-        dist.all_reduce(local, op=dist.ReduceOp.SUM)  # the single collective of the run: throughput counters
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    rounds, commits, events, faulted = [float(v) for v in local.tolist()]
-    elapsed = float(tmax.item())
+    # the single collective of the run: one all-gather of every rank's row (throughput counters + its timed region);
+    # sums / the slowest rank are reduced locally
+    from librabft_simulator_amd.distributed import aggregate_counters
+    agg = aggregate_counters(c, device=("cuda" if (dist is None or args.backend == "nccl") else None), extra_max=[elapsed])
+    rounds, commits, events, faulted = float(agg["rounds"]), float(agg["commits"]), float(sum(agg["events"])), float(agg["faulted_instances"])
+    elapsed = float(agg["extra_max"][0])
     if rank == 0:
         per_step = elapsed / args.steps
         k_ms = float(np.mean(kernel_ms))
@@ -161,6 +174,8 @@ def main():
         traffic = measured_traffic_gb() if (args.instances, args.nodes, args.max_clock) == (65536, 4, 1000) else None
         local_events = sum(c["events"])
         achieved = local_events * bpe / (k_ms * 1e-3) / 1e9
+        ex_bytes, pops = executed_bytes(layout, c)
+        achieved_ex = ex_bytes / (k_ms * 1e-3) / 1e9
         out = {
             "metric": "simulated consensus rounds/sec (whole node), 65 536 x 4-node instances per GPU",
             "value": rounds / per_step, "unit": "rounds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -170,12 +185,20 @@ def main():
                                    "delta 20 gamma 2 lambda 0.5, seeds base+i; reference quirks Q1-Q6" % (m, args.nodes, args.max_clock),
                        "instances_per_gpu": m, "nodes": args.nodes, "max_clock": args.max_clock, "parallelism": "instances sharded, %d ranks" % world},
             "committed_blocks_per_s": commits / per_step, "events_per_s": events / per_step,
+            "events_note": "reference-equivalent events (incl. duplicate timers the device folds); device queue pops: roofline.executed",
             "faulted_instances": faulted,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["gb_corrected"] if traffic else None, "traffic_unit": "GB per launch",
                          "traffic_detail": traffic, "kernel": "lbft_k_run0" if layout.get("kernel_class", 0) == 0 else ("lbft_k_run2l" if (layout["kernel_class"] & 255) == 2 else "lbft_k_run1l") if layout["kernel_class"] & 1024 else "lbft_k_run<%d>" % (layout["kernel_class"] & 255), "kernel_ms": k_ms,
                          "algorithmic_bytes_per_event": bpe, "algorithmic_gb_per_launch": local_events * bpe / 1e9,
-                         "events_per_launch": local_events, "layout": layout},
+                         "events_per_launch": local_events,
+                         # the same roofline with traffic charged only where the device moves rows (folded duplicate timers never
+                         # reach the queue; cancelled timers and requests do not write node rows back): the stricter of the two
+                         "executed": {"achieved": achieved_ex, "frac": achieved_ex / HBM_PEAK_GBS, "gb_per_launch": ex_bytes / 1e9,
+                                      "queue_pops_per_launch": pops, "node_updates_per_launch": c.get("node_updates"),
+                                      "timers_folded_per_launch": c.get("timers_folded"),
+                                      "queue_pops_per_s": pops / (k_ms * 1e-3)},
+                         "layout": layout},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.nodes, args.max_clock)

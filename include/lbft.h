@@ -112,6 +112,12 @@ typedef struct lbft_counters {
   uint64_t max_snapshots;     /* max over instances of live notification snapshots */
   uint64_t max_blocks;        /* max over instances of proposed blocks */
   uint64_t launches;          /* run-kernel launches of the last run */
+  /* What the device executes, as opposed to the reference-equivalent counts above: duplicate UpdateTimerEvents of one (node, time) are
+   * folded at scheduling time and only counted in events[3] (simulator.rs:406-410 makes them no-ops), so the number of queue pops is
+   * events[0..3] summed minus timers_folded (round trace off); node_updates = ConsensusNode::update_node calls, i.e. the events that
+   * load AND write back a node's rows (cancelled timers and requests only load them). */
+  uint64_t timers_folded;
+  uint64_t node_updates;
 } lbft_counters;
 
 typedef struct lbft_batch lbft_batch;

@@ -63,6 +63,8 @@ class LbftCounters(C.Structure):
         ("max_snapshots", C.c_uint64),
         ("max_blocks", C.c_uint64),
         ("launches", C.c_uint64),
+        ("timers_folded", C.c_uint64),
+        ("node_updates", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -24,6 +24,17 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: cannot build the HIP library (there is no CPU fallback)")
 
 
+def source_hash():
+    """sha256 (16 hex digits) of the kernel sources: profiles/current/pmc_traffic.json is stamped with it, and bench.py only
+    reports that traffic while the stamp matches the sources the library was built from."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS[:4]:  # lbft_hip.hip, lbft_core.h, lbft_math.h, lbft_tables.h
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     if not os.path.exists(OUT):
         return True

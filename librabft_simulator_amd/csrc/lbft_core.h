@@ -153,7 +153,8 @@ extern unsigned long long lbft_host_stats[64];
 enum InstField : u32 {
   I_CLOCK = 0, I_STAMP, I_RNG0, I_RNG1, I_RNG2, I_RNG3, I_RNG4, I_RNG5, I_RNG6, I_RNG7,
   I_QLEN, I_SNAP_FREE, I_NBLOCKS, I_FAULT, I_EV0, I_EV1, I_EV2, I_EV3, I_DRAWS, I_DONE,
-  I_MAXQ, I_MAXSNAP, I_SNAP_MASK_LO, I_SNAP_MASK_HI, I_LAST_NODE, I_VD_TIME, I_VD_STAMP, I_CAL_CURSOR, I_CAL_FREE, I_CAL_BUMP, I_WORDS
+  I_MAXQ, I_MAXSNAP, I_SNAP_MASK_LO, I_SNAP_MASK_HI, I_LAST_NODE, I_VD_TIME, I_VD_STAMP, I_CAL_CURSOR, I_CAL_FREE, I_CAL_BUMP,
+  I_NFOLD /* duplicate timers folded at scheduling time (never queued) */, I_NUPD /* update_node calls */, I_WORDS
 };
 
 // Node-level rows (RecordStoreState record_store.rs:93-119, PacemakerState pacemaker.rs:60-77,
@@ -194,7 +195,8 @@ enum BlockField : u32 {
 // Snapshot (notification, data_sync.rs:16-39) rows; followed by tc_hcbr[n], to_hcbr[n].
 enum SnapField : u32 { S_EPOCH = 0, S_CERTS /* hcc | hqc << 16 */, S_PROP_VOTE /* proposed | vote << 16 */, S_TC_ROUND, S_TO_ROUND, S_TC_MASK, S_TO_MASK, S_FIXED_WORDS };
 
-#define LBFT_CAL_MAX_CLOCK 2047  // calendar queue: (max_clock + 1) * 4 buckets per instance
+#define LBFT_CAL_MAX_CLOCK 16383  // calendar queue: (max_clock + 1) * 4 buckets per instance (two rows + one bitmap bit each: 0.5 MiB
+                                  // per instance at the cap; the host side falls back to the heap when the batch would not fit the HBM)
 #define LBFT_NO_LEADER 0xffu
 #define LBFT_NEVER INT64_MAX
 
@@ -431,6 +433,8 @@ struct SimT {
   u32 vd_time, vd_stamp;
   u64 snap_mask;  // scap <= 64: free snapshot slots as a bit set held in registers (no free-stack round trip)
   u32 ev0, ev1, ev2, ev3;
+  u32 n_fold, n_upd;  // duplicate timers folded instead of queued / update_node calls: what the device executes, as opposed to the
+                      // reference-equivalent event counts ev0..ev3 (bench.py reports the roofline on both)
   Rng rng;
 
   // Front of the event queue: slots [0, ql) live in LDS on the device (lane-private column: element k of
@@ -688,6 +692,7 @@ struct SimT {
     snap_mask = ld(I_SNAP_MASK_LO) | ((u64)ld(I_SNAP_MASK_HI) << 32);
     last_node = ld(I_LAST_NODE); vd_time = ld(I_VD_TIME); vd_stamp = ld(I_VD_STAMP);
     cal_cursor = ld(I_CAL_CURSOR); cal_free = ld(I_CAL_FREE); cal_bump = ld(I_CAL_BUMP);
+    n_fold = ld(I_NFOLD); n_upd = ld(I_NUPD);
     blk_cache_reset();
   }
   LBFT_HD void store_scalars(bool done) {
@@ -701,6 +706,7 @@ struct SimT {
     st(I_SNAP_MASK_LO, (u32)snap_mask); st(I_SNAP_MASK_HI, (u32)(snap_mask >> 32));
     st(I_LAST_NODE, last_node); st(I_VD_TIME, vd_time); st(I_VD_STAMP, vd_stamp);
     st(I_CAL_CURSOR, cal_cursor); st(I_CAL_FREE, cal_free); st(I_CAL_BUMP, cal_bump);
+    st(I_NFOLD, n_fold); st(I_NUPD, n_upd);
     st(I_DONE, done ? 1u : 0u);
   }
 
@@ -1792,6 +1798,7 @@ struct SimT {
     // same time (it is still pending: that time is > clock), only count the duplicate.
     if (t_new <= (i64)P.max_clock && (u32)t_new == nf(node, NF_LAST_TIMER_T)) {
       LBFT_STAT(40);
+      n_fold++;
       nfs(node, NF_TIMER_DUPS, nf(node, NF_TIMER_DUPS) + 1);
       nfs(node, NF_DUP_STAMP, stamp);
       stamp++;
@@ -1858,7 +1865,8 @@ struct SimT {
         }
       }
       LBFT_MARK(16);
-      i64 t = (i64)clock + sample_delay();
+      i64 t = sample_delay();
+      t = t > INT64_MAX - (i64)clock ? INT64_MAX : (i64)clock + t;  // (a saturated sample must not wrap; it is past every horizon anyway)
       LBFT_MARK(18);
       // Each kind of message only decides WHAT is scheduled; the event itself is pushed at one site below (four inlined
       // copies of push_event, one per kind, would each run for the few lanes that need it).
@@ -1970,7 +1978,7 @@ struct SimT {
   LBFT_HD void init(u64 seed) {
     for (u32 w = 0; w < I_WORDS; w++) st(w, 0);
     clock = 0; stamp = 0; qlen = 0; nblocks = 0; fault = 0; maxq = 0; maxsnap = 0;
-    ev0 = ev1 = ev2 = ev3 = 0;
+    ev0 = ev1 = ev2 = ev3 = 0; n_fold = 0; n_upd = 0;
     blk_cache_reset();
     snap_free = P.scap;
     snap_mask = P.scap >= 64 ? ~0ULL : ((1ULL << P.scap) - 1);
@@ -1992,7 +2000,7 @@ struct SimT {
       // even propose: its NodeTime (clock - startup, negative) goes into its blocks, so the startup time must be exact
       // (clamping it to max_clock + 1 changed the committed commands' times under long-tailed delays).  Only the 32-bit
       // storage bounds it.
-      if (startup > 0x3fffffffLL) startup = 0x3fffffffLL;
+      if (startup > 0x3fffffffLL) { startup = 0x3fffffffLL; fault |= F_INTERNAL; }  // (not representable: say so instead of diverging silently)
       nfms(node, NF_STARTUP, (u32)(i32)startup);
       nfms(node, NF_IGNORE_UNTIL, (u32)(i32)(startup - 1));
       push_event(startup, 3, node, 0, 0);
@@ -2008,8 +2016,9 @@ struct SimT {
     u32 mw = P.off_trace + P.n * P.rcap + node;
     if (ar > ld(mw)) {
       st(mw, ar);
+      // (the reference writes rounds 0..max_round exclusive, data_writer.rs:74-75: a node AT round rcap loses nothing)
       if (ar < P.rcap) st(P.off_trace + node * P.rcap + ar, (u32)event_time);
-      else fault |= F_TRACE_OVERFLOW;
+      else if (ar > P.rcap) fault |= F_TRACE_OVERFLOW;
     }
   }
 
@@ -2100,6 +2109,7 @@ struct SimT {
       Actions a;
       a.next = LBFT_NEVER; a.send_to = -1; a.broadcast = false; a.query_all = false;
       if (do_update) {
+        n_upd++;
         a = node_update(node);
         if (sync) { sp.sync = 1; sp.sync_stamp = stamp++; }  // the request is scheduled before the timer (simulator.rs:424-440)
         LBFT_MARK(11);
@@ -2135,33 +2145,36 @@ inline bool sim_lean_features(const Params& p) { return !(p.quirks & 1u) && !p.r
 inline bool sim_lean(const Params& p) { return sim_class(p) == 2 && sim_lean_features(p); }
 inline bool sim_lean1(const Params& p) { return sim_class(p) == 1 && sim_lean_features(p); }
 
-// Row layout for a batch; fills the offset fields of `p` and returns words per instance.
-inline u32 compute_layout(Params& p) {
-  u32 w = I_WORDS;
+// Row layout for a batch; fills the offset fields of `p` and returns words per instance.  Accumulated in 64 bits: a tile is
+// addressed with 32-bit byte offsets (boff(): row << 8), so a layout is only usable while it stays below 2^24 rows; the
+// caller rejects larger ones (layout_fits) instead of letting row offsets wrap.
+inline u64 compute_layout(Params& p) {
+  u64 w = I_WORDS;
   p.mw = (p.n + 31) / 32;
-  p.off_node = w; p.node_words = NF_FIXED_WORDS + 2 * p.n + 4 * (p.mw - 1); w += p.n * p.node_words;
-  p.off_qhi = w; w += p.qcap;
-  p.off_qlo = w; w += p.qcal ? 0 : p.qcap;  // the calendar stores no keys
-  p.off_qmeta = w; w += p.qcap;
+  p.off_node = (u32)w; p.node_words = NF_FIXED_WORDS + 2 * p.n + 4 * (p.mw - 1); w += (u64)p.n * p.node_words;
+  p.off_qhi = (u32)w; w += p.qcap;
+  p.off_qlo = (u32)w; w += p.qcal ? 0 : p.qcap;  // the calendar stores no keys
+  p.off_qmeta = (u32)w; w += p.qcap;
   p.cal_buckets = p.qcal ? ((u32)p.max_clock + 1u) * 4u : 0;
-  p.off_cal_head = w; w += p.cal_buckets;
-  p.off_cal_tail = w; w += p.cal_buckets;
-  p.off_cal_bm = w; w += (p.cal_buckets + 31) / 32 + (p.qcal ? 1 : 0);
+  p.off_cal_head = (u32)w; w += p.cal_buckets;
+  p.off_cal_tail = (u32)w; w += p.cal_buckets;
+  p.off_cal_bm = (u32)w; w += (p.cal_buckets + 31) / 32 + (p.qcal ? 1 : 0);
   p.snap_words = S_FIXED_WORDS + 2 * p.n + 2 * (p.mw - 1) + ((p.quirks & 1u) ? 2 : 0);  // + the request's (epoch, certificates)
-  p.off_snap = w; w += p.scap * p.snap_words;
-  p.off_snap_ref = w; w += p.scap;
-  p.off_snap_free = w; w += p.scap;
+  p.off_snap = (u32)w; w += (u64)p.scap * p.snap_words;
+  p.off_snap_ref = (u32)w; w += p.scap;
+  p.off_snap_free = (u32)w; w += p.scap;
   p.blk_words = B_WORDS + 4 * (p.mw - 1);  // + extension words (nodes / authors >= 32) of KNOWN, QC, PEND and VOTERS
-  p.off_blk = w; w += p.bcap * p.blk_words;
-  p.off_log = w; w += p.n * p.lcap;
-  p.off_list = w; w += p.n > 16 ? p.n : 0;
-  p.off_trace = w; w += p.rcap ? p.n * p.rcap + p.n : 0;
-  p.off_arch = w; w += (p.quirks & 1u) ? p.n * p.ecap * p.snap_words : 0;
-  p.off_sync = w; w += (p.quirks & 1u) ? p.bcap : 0;
-  p.total_words = w;
+  p.off_blk = (u32)w; w += (u64)p.bcap * p.blk_words;
+  p.off_log = (u32)w; w += (u64)p.n * p.lcap;
+  p.off_list = (u32)w; w += p.n > 16 ? p.n : 0;
+  p.off_trace = (u32)w; w += p.rcap ? (u64)p.n * p.rcap + p.n : 0;
+  p.off_arch = (u32)w; w += (p.quirks & 1u) ? (u64)p.n * p.ecap * p.snap_words : 0;
+  p.off_sync = (u32)w; w += (p.quirks & 1u) ? p.bcap : 0;
+  p.total_words = w > 0xffffffffULL ? 0xffffffffu : (u32)w;
   p.qpack = sim_class(p) == 0 ? 1u : 0u;
   return w;
 }
+inline bool layout_fits(u64 total_words) { return total_words < (1ULL << 24); }
 
 }  // namespace lbft
 

@@ -174,7 +174,7 @@ __device__ __forceinline__ u64 wave_max(u64 v) {
   return v;
 }
 
-enum CounterSlot { C_EV0 = 0, C_EV1, C_EV2, C_EV3, C_DRAWS, C_ROUNDS, C_COMMITS, C_SCHED, C_FAULTED, C_MAXQ, C_MAXSNAP, C_MAXBLK, C_WORDS };
+enum CounterSlot { C_EV0 = 0, C_EV1, C_EV2, C_EV3, C_DRAWS, C_ROUNDS, C_COMMITS, C_SCHED, C_FAULTED, C_NFOLD, C_NUPD, C_MAXQ, C_MAXSNAP, C_MAXBLK, C_WORDS };
 
 // Per-node State hash (simulated_context.rs:51-55) and the batch counters (wavefront shuffle
 // reductions, one atomic per wavefront and counter).
@@ -218,6 +218,7 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_finalize(Params p, const u3
     c[C_EV0] = s.ld(I_EV0); c[C_EV1] = s.ld(I_EV1); c[C_EV2] = s.ld(I_EV2); c[C_EV3] = s.ld(I_EV3);
     c[C_DRAWS] = s.ld(I_DRAWS); c[C_ROUNDS] = min_round; c[C_COMMITS] = min_commits; c[C_SCHED] = s.ld(I_STAMP);
     c[C_FAULTED] = s.ld(I_FAULT) ? 1 : 0;
+    c[C_NFOLD] = s.ld(I_NFOLD); c[C_NUPD] = s.ld(I_NUPD);
     c[C_MAXQ] = s.ld(I_MAXQ); c[C_MAXSNAP] = s.ld(I_MAXSNAP); c[C_MAXBLK] = s.ld(I_NBLOCKS);
   }
   for (int k = 0; k < C_WORDS; k++) {
@@ -464,6 +465,9 @@ static int validate(const lbft_config* cfg) {
   if (cfg->delay_model == 0 && !(cfg->mean > 0.0 && cfg->variance >= 0.0)) return LBFT_ERR_INVALID;
   if (cfg->delay_model == 1 && !(cfg->uniform_lo >= 0 && cfg->uniform_hi >= cfg->uniform_lo)) return LBFT_ERR_INVALID;
   if (cfg->commands_per_epoch == 0) return LBFT_ERR_INVALID;
+  // NodeConfig (node.rs:76-81): durations and periods are f64 products truncated to i64; NaN / negative parameters have no meaning
+  if (!(cfg->gamma >= 0.0) || !(cfg->lambda >= 0.0) || cfg->delta < 0 || cfg->target_commit_interval < 0) return LBFT_ERR_INVALID;
+  if (!std::isfinite(cfg->gamma) || !std::isfinite(cfg->lambda) || !std::isfinite(cfg->mean) || !std::isfinite(cfg->variance)) return LBFT_ERR_INVALID;
   return LBFT_OK;
 }
 
@@ -798,6 +802,7 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   u32 bcap = c.block_capacity ? c.block_capacity : (u32)(bauto > 65534 ? 65534 : bauto);
   if (bcap > 65534 || scap > 65535 || n > 255) { g_err = "capacity out of range"; return LBFT_ERR_INVALID; }
   u32 lcap = c.log_capacity ? c.log_capacity : bcap;
+  if (lcap > bcap) lcap = bcap;  // a node commits each block at most once
   // Queue discipline: 4-node honest lossless networks scan an LDS-resident array (kernel class 0); everything else keeps
   // hundreds to tens of thousands of pending events and uses a calendar of (time, kind) FIFOs when max_clock allows it
   // (O(1) push and pop), otherwise a binary heap whose top levels are the LDS-resident slots.
@@ -815,7 +820,22 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   p.qcap = qcap; p.scap = scap; p.bcap = bcap; p.lcap = lcap; p.rcap = b->rcap; p.qcal = qcal; p.qheap = qheap; p.ecap = ecap;
   p.max_clock = (i32)max_clock;
   p.max_steps = b->max_steps;
-  compute_layout(p);
+  u64 words = compute_layout(p);
+  if (p.qcal) {  // the calendar's bucket rows grow with the horizon: keep it only while the batch fits comfortably in HBM
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    size_t avail = free_b + (b->d_state ? b->state_bytes : 0);
+    if (!layout_fits(words) || (double)words * p.stride * 4.0 > 0.85 * (double)avail) {
+      qcal = 0; p.qcal = 0;
+      relayout = true;
+      words = compute_layout(p);
+    }
+  }
+  if (!layout_fits(words)) {
+    p.qcap = 0;  // (forces a relayout next time)
+    g_err = "per-instance state exceeds 2^24 rows (64 MiB per instance): lower the capacities / the horizon";
+    return LBFT_ERR_INVALID;
+  }
   if (relayout) {
     if (b->d_state) { HIP_TRY(hipFree(b->d_state)); b->d_state = nullptr; }
     b->state_bytes = state_words(p) * sizeof(u32);
@@ -942,8 +962,12 @@ int lbft_batch_run_steps(lbft_batch* b, int64_t max_clock, uint32_t steps, uint6
 }
 
 struct CheckpointHeader {
-  char magic[8];  // "LBFTCKP1"
+  char magic[8];  // "LBFTCKP2"
   u32 n, qcap, scap, bcap, lcap, rcap, total_words, equiv;
+  // everything that changes the meaning of the state words without changing their number: the protocol mode, the fault model,
+  // the kernel class and the queue discipline / key encoding it implies, the archive capacity of retired record stores
+  u32 quirks, drop_ppm, part_size, rot, sim_class, qpack, qcal, qheap, ecap, pad_;
+  i64 part_start, part_end;
   u64 m, cpe;
   i64 max_clock, tci, delta, uni_lo, uni_hi;
   double mean, variance, gamma, lambda;
@@ -956,12 +980,14 @@ static u32 weights_hash(const std::vector<u32>& w) {
 }
 static void fill_header(const lbft_batch* b, CheckpointHeader& h) {
   memset(&h, 0, sizeof(h));
-  memcpy(h.magic, "LBFTCKP1", 8);
+  memcpy(h.magic, "LBFTCKP2", 8);
   const Params& p = b->p; const lbft_config& c = b->cfg;
   h.n = p.n; h.qcap = p.qcap; h.scap = p.scap; h.bcap = p.bcap; h.lcap = p.lcap; h.rcap = p.rcap; h.total_words = p.total_words;
   h.equiv = p.equiv; h.m = b->m; h.cpe = c.commands_per_epoch; h.max_clock = b->started_max_clock; h.tci = c.target_commit_interval;
   h.delta = c.delta; h.uni_lo = c.uniform_lo; h.uni_hi = c.uniform_hi; h.mean = c.mean; h.variance = c.variance; h.gamma = c.gamma;
   h.lambda = c.lambda; h.delay_model = c.delay_model; h.weights_hash = weights_hash(b->weights) ^ (p.rot * 0x9e3779b9u);
+  h.quirks = p.quirks; h.drop_ppm = p.drop_ppm; h.part_size = p.part_size; h.rot = p.rot; h.sim_class = (u32)sim_class(p) | ((sim_lean(p) || sim_lean1(p)) ? 256u : 0u);
+  h.qpack = p.qpack; h.qcal = p.qcal; h.qheap = p.qheap; h.ecap = p.ecap; h.part_start = c.partition_start; h.part_end = c.partition_end;
 }
 size_t lbft_batch_checkpoint_bytes(const lbft_batch* b) {
   if (!b || !b->started) return 0;
@@ -983,17 +1009,23 @@ int lbft_batch_checkpoint_load(lbft_batch* b, const void* buf, size_t len) {
   if (b->ran || b->manual || b->started) { g_err = "load a checkpoint into a fresh (or reset) batch"; return LBFT_ERR_STATE; }
   CheckpointHeader h;
   memcpy(&h, buf, sizeof(h));
-  if (memcmp(h.magic, "LBFTCKP1", 8) != 0) { g_err = "not a checkpoint"; return LBFT_ERR_INVALID; }
-  // the batch must have been created with the same configuration; capacities come from the checkpoint
+  if (memcmp(h.magic, "LBFTCKP2", 8) != 0) { g_err = "not a checkpoint (or one of an older format)"; return LBFT_ERR_INVALID; }
+  // the batch must have been created with the same configuration; capacities come from the checkpoint.  A failed load leaves
+  // the batch's own capacities as they were.
+  const lbft_config saved_cfg = b->cfg;
+  const u32 saved_rcap = b->rcap;
+  const int64_t saved_max_clock = b->started_max_clock;
   b->cfg.queue_capacity = h.qcap; b->cfg.snapshot_capacity = h.scap; b->cfg.block_capacity = h.bcap; b->cfg.log_capacity = h.lcap;
   b->rcap = h.rcap;
   int rc = prepare_run(b, h.max_clock);
-  if (rc != LBFT_OK) return rc;
-  b->started_max_clock = h.max_clock;
-  CheckpointHeader mine;
-  fill_header(b, mine);
-  if (memcmp(&mine, &h, sizeof(h)) != 0) { g_err = "checkpoint was taken from a batch with a different configuration"; return LBFT_ERR_INVALID; }
-  if (len != sizeof(h) + b->state_bytes) { g_err = "checkpoint size mismatch"; return LBFT_ERR_INVALID; }
+  if (rc == LBFT_OK) {
+    b->started_max_clock = h.max_clock;
+    CheckpointHeader mine;
+    fill_header(b, mine);
+    if (memcmp(&mine, &h, sizeof(h)) != 0) { g_err = "checkpoint was taken from a batch with a different configuration"; rc = LBFT_ERR_INVALID; }
+    else if (len != sizeof(h) + b->state_bytes) { g_err = "checkpoint size mismatch"; rc = LBFT_ERR_INVALID; }
+  }
+  if (rc != LBFT_OK) { b->cfg = saved_cfg; b->rcap = saved_rcap; b->started_max_clock = saved_max_clock; return rc; }
   HIP_TRY(hipMemcpy(b->d_state, (const char*)buf + sizeof(h), b->state_bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipEventRecord(b->ev0, b->stream));
   HIP_TRY(hipEventRecord(b->ev1, b->stream));
@@ -1017,6 +1049,7 @@ static int finalize_run(lbft_batch* b, u32 grid_full, u64 launches) {
   k.rng_draws = hc[C_DRAWS]; k.rounds = hc[C_ROUNDS]; k.commits = hc[C_COMMITS]; k.events_scheduled = hc[C_SCHED];
   k.faulted_instances = hc[C_FAULTED]; k.max_queue = hc[C_MAXQ]; k.max_snapshots = hc[C_MAXSNAP]; k.max_blocks = hc[C_MAXBLK];
   k.launches = launches;
+  k.timers_folded = hc[C_NFOLD]; k.node_updates = hc[C_NUPD];
   b->ran = true;
   if (k.faulted_instances) { g_err = "some instances raised a fault; see lbft_batch_faults"; return LBFT_ERR_FAULT; }
   return LBFT_OK;

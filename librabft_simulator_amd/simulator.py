@@ -267,7 +267,7 @@ class BatchSimulator:
         the device and ``round_switches.txt`` / ``number_of_messages.txt`` of instance 0 are written there in the
         reference's CSV format.  ``round_trace=N`` only records (N rounds per node) for ``BatchResult.round_switches``."""
         if csv_path is not None and round_trace is None:
-            round_trace = max(int(max_clock) // 5 + 64, 64)
+            round_trace = min(int(max_clock) + 64, 1 << 16)  # a round takes at least one time unit (n <= 2, zero delays)
         if round_trace:
             check(_lib.lib().lbft_batch_enable_round_trace(self._h, int(round_trace)))
         check(_lib.lib().lbft_batch_run_until(self._h, int(max_clock)), allow_fault=allow_faults)

@@ -1551,5 +1551,30 @@ void lbft_oracle_shuffle(uint64_t seed, uint32_t* out, size_t n) {
 }
 double lbft_oracle_exp_strict(double x) { return lbft_exp(x, EXP_TAB); }
 double lbft_oracle_log_strict(double x) { return lbft_log(x); }
+// Bulk form of the arithmetic bridge between the two math modes: how many of the n points x[i] give lbft_exp(x) != the host
+// libm's exp(x) (bit patterns) / an lbft_log(x) more than one ulp from the host's log (tests/test_math.py).
+size_t lbft_oracle_exp_mismatches(const double* x, size_t n) {
+  size_t bad = 0;
+  for (size_t i = 0; i < n; i++) {
+    double a = lbft_exp(x[i], EXP_TAB), b = std::exp(x[i]);
+    uint64_t ua, ub;
+    memcpy(&ua, &a, 8); memcpy(&ub, &b, 8);
+    bad += ua != ub;
+  }
+  return bad;
+}
+size_t lbft_oracle_log_mismatches(const double* x, size_t n, size_t* off_by_one_ulp) {
+  size_t bad = 0, ulp1 = 0;
+  for (size_t i = 0; i < n; i++) {
+    double a = lbft_log(x[i]), b = std::log(x[i]);
+    int64_t ia, ib;
+    memcpy(&ia, &a, 8); memcpy(&ib, &b, 8);
+    int64_t d = ia > ib ? ia - ib : ib - ia;
+    ulp1 += d == 1;
+    bad += d > 1;
+  }
+  if (off_by_one_ulp) *off_by_one_ulp = ulp1;
+  return bad;
+}
 
 }  // extern "C"

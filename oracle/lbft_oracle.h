@@ -166,6 +166,8 @@ void lbft_oracle_sample_delays(const lbft_oracle_config* cfg, uint64_t seed, int
 void lbft_oracle_shuffle(uint64_t seed, uint32_t* out, size_t n);
 double lbft_oracle_exp_strict(double x);
 double lbft_oracle_log_strict(double x);
+size_t lbft_oracle_exp_mismatches(const double* x, size_t n);
+size_t lbft_oracle_log_mismatches(const double* x, size_t n, size_t* off_by_one_ulp);
 
 #ifdef __cplusplus
 }

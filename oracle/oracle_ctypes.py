@@ -164,6 +164,10 @@ def lib():
         L.lbft_oracle_exp_strict.restype = C.c_double
         L.lbft_oracle_log_strict.argtypes = [C.c_double]
         L.lbft_oracle_log_strict.restype = C.c_double
+        L.lbft_oracle_exp_mismatches.argtypes = [vp, C.c_size_t]
+        L.lbft_oracle_exp_mismatches.restype = C.c_size_t
+        L.lbft_oracle_log_mismatches.argtypes = [vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.lbft_oracle_log_mismatches.restype = C.c_size_t
         _lib = L
     return _lib
 

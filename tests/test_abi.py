@@ -32,7 +32,7 @@ def test_header_symbols_are_exported(hiplib):
 def test_config_struct_matches_header_layout(hiplib):
     # lbft_config: 2*u32, 2*f64, 2*i64, u64, 2*i64, 2*f64, 2*u32, ptr, 4*u32
     assert ctypes.sizeof(hiplib.LbftConfig) == 8 + 16 + 16 + 8 + 16 + 16 + 8 + 8 + 16 + 8 + 16 + 8  # + lossy-network fields + rights_rotation (padded)
-    assert ctypes.sizeof(hiplib.LbftCounters) == 8 * 13
+    assert ctypes.sizeof(hiplib.LbftCounters) == 8 * 15
     assert hiplib.COMMIT_DTYPE.itemsize == 24
 
 

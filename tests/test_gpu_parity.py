@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+HOST_THREADS = __import__("os").cpu_count() or 8  # the oracle spot checks use every host core of the GPU box
 
 
 @pytest.fixture(scope="module")
@@ -329,8 +330,10 @@ def _prefix_consistent(cc, hist):
 
 
 def test_full_size_config4_16384x64_equivocators_properties(amd, oracle):
-    """BASELINE.json configs[3]: 16 384 x 64 nodes (f = 21), long-tail delays, every fifth node equivocating.
-    Size-independent properties at full size + bit-exact oracle spot check on a strided subset."""
+    """BASELINE.json configs[3] as SURVEY.md 8(d) wrote it: 16 384 x 64 nodes (f = 21), long-tail delays, every fifth node
+    equivocating, reference semantics, clock 300.  Degenerate -- nothing commits by then (and with reference quirk Q1 the
+    network stalls after ~4 commits however long it runs: stragglers cannot catch up) -- kept as the second line beside
+    test_full_size_config4_live_*.  Properties at full size + bit-exact oracle check on 256 instances."""
     m, n, max_clock = 16384, 64, 300
     kw = dict(num_nodes=n, mean=10.0, variance=400.0, equivocate_every=5)
     seeds = np.arange(1, m + 1, dtype=np.uint64)
@@ -343,15 +346,16 @@ def test_full_size_config4_16384x64_equivocators_properties(amd, oracle):
     assert (ar >= 1).all() and (ar.max(axis=1) - ar.min(axis=1) <= ar.max()).all()
     c = res.counters
     assert c["events"][1] == c["events"][2] or c["events"][1] >= c["events"][2]  # every processed response had a request
-    idx = np.arange(0, m, 4096)
-    ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds[idx], max_clock, threads=4, history_cap=hist.shape[2])
+    idx = np.arange(0, m, m // 256)  # 256 instances, bit-exact
+    ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds[idx], max_clock, threads=HOST_THREADS, history_cap=hist.shape[2])
     assert (cc[idx] == ref["commit_counts"]).all() and (ar[idx] == ref["active_rounds"]).all()
     assert (res.last_committed_states[idx] == ref["last_states"]).all() and (hist[idx] == ref["histories"]).all()
 
 
 def test_full_size_config5_8192x100_weighted_epochs_properties(amd, oracle):
-    """BASELINE.json configs[4]: 8 192 x 100 nodes, voting rights 1 + (i mod 4), an epoch every 50 commands
-    (reference semantics incl. quirks Q1/Q2).  Properties at full size + oracle spot check."""
+    """BASELINE.json configs[4] as SURVEY.md 8(d) wrote it: 8 192 x 100 nodes, voting rights 1 + (i mod 4), an epoch every
+    50 commands (reference semantics incl. quirks Q1/Q2), clock 300: never reaches an epoch change -- kept as the second
+    line beside test_full_size_config5_live_*.  Properties at full size + bit-exact oracle check on 256 instances."""
     m, n, max_clock = 8192, 100, 300
     rights = [1 + (i % 4) for i in range(n)]
     kw = dict(num_nodes=n, voting_rights=rights, commands_per_epoch=50)
@@ -364,10 +368,80 @@ def test_full_size_config5_8192x100_weighted_epochs_properties(amd, oracle):
     assert (hist["proposer"][np.arange(hist.shape[2])[None, None, :] < cc[:, :, None]] < n).all()
     assert (cc.min(axis=1) >= 1).mean() > 0.9               # the healthy weighted network commits
     assert (res.epochs == 0).all()                           # 50 commands are not reached by clock 300
-    idx = np.arange(0, m, 4096)
-    ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds[idx], max_clock, threads=2, history_cap=hist.shape[2])
+    idx = np.arange(0, m, m // 256)  # 256 instances, bit-exact
+    ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds[idx], max_clock, threads=HOST_THREADS, history_cap=hist.shape[2])
     assert (cc[idx] == ref["commit_counts"]).all() and (res.active_rounds[idx] == ref["active_rounds"]).all()
     assert (res.last_committed_states[idx] == ref["last_states"]).all() and (hist[idx] == ref["histories"]).all()
+
+
+def test_full_size_config4_live_16384x64_equivocators_commit(amd, oracle):
+    """Configuration 4 exercising what it is named for, at full size: 16 384 x 64 nodes, LogNormal(10, 400) delays, 13 of 64
+    nodes (index % 5 == 0) equivocating, the fixed protocol mode (quirks = 3: lagging nodes catch up through real
+    request / response payloads), clock 1000.  Every node of (almost) every instance commits >= 5 blocks, so the safety
+    assertion runs over non-empty logs; 256 instances are compared with the oracle bit for bit."""
+    m, n, max_clock = 16384, 64, 1000
+    kw = dict(num_nodes=n, mean=10.0, variance=400.0, equivocate_every=5, quirks=3)
+    seeds = np.arange(1, m + 1, dtype=np.uint64)
+    _, res = run_gpu(amd, kw, seeds, max_clock)
+    assert not res.faults.any()
+    cc = res.commit_counts
+    assert (cc.min(axis=1) >= 5).mean() >= 0.9, np.bincount(cc.min(axis=1))   # liveness despite f_byz = 13 < 64 / 3
+    assert cc.min() > 0
+    hist = res.committed_histories(int(cc.max()))
+    assert _prefix_consistent(cc, hist)                                          # safety over non-empty logs
+    valid = np.arange(hist.shape[2])[None, None, :] < cc[:, :, None]
+    assert (hist["proposer"][valid] < n).all()
+    # both blocks of an equivocating proposal can never be committed: a (proposer, index) pair appears once per log
+    key = hist["proposer"].astype(np.int64) * (1 << 32) + hist["index"].astype(np.int64)
+    first = np.sort(np.where(valid, key, -1 - np.arange(hist.shape[2])[None, None, :]), axis=2)
+    assert (np.diff(first, axis=2) != 0).all()
+    idx = np.arange(0, m, m // 256)
+    ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds[idx], max_clock, threads=HOST_THREADS, history_cap=hist.shape[2])
+    assert (cc[idx] == ref["commit_counts"]).all() and (res.active_rounds[idx] == ref["active_rounds"]).all()
+    assert (res.last_committed_states[idx] == ref["last_states"]).all() and (hist[idx] == ref["histories"]).all()
+    assert ref["counters"]["response_inserts"] > 0                               # stragglers did catch up through responses
+
+
+def test_full_size_config5_live_8192x100_rotating_rights_epochs(amd, oracle):
+    """Configuration 5 exercising what it is named for, at full size: 8 192 x 100 nodes, voting rights 1 + (i mod 4) rotating
+    by one node per epoch (rights_rotation = 1), an epoch every 3 commands, the fixed protocol mode (quirks = 3), clock
+    400: every instance goes through >= 2 epoch changes (node.rs:331-348).  256 instances bit-exact against the oracle."""
+    m, n, max_clock = 8192, 100, 400
+    rights = [1 + (i % 4) for i in range(n)]
+    kw = dict(num_nodes=n, voting_rights=rights, commands_per_epoch=3, quirks=3, rights_rotation=1)
+    seeds = np.arange(1, m + 1, dtype=np.uint64)
+    _, res = run_gpu(amd, kw, seeds, max_clock)
+    assert not res.faults.any()
+    cc, ep = res.commit_counts, res.epochs
+    assert (ep.max(axis=1) >= 2).all()                       # >= 2 reconfigurations in every instance ...
+    assert (ep.min(axis=1) >= 2).mean() >= 0.95              # ... at every one of its nodes in nearly all of them
+    assert (ep.min(axis=1) >= 1).all()
+    assert (ep == cc // 3).all()                             # read_epoch_id = commands / commands_per_epoch (simulated_context.rs:199-207)
+    hist = res.committed_histories(int(cc.max()))
+    assert _prefix_consistent(cc, hist)                      # logs agree across the epochs
+    idx = np.arange(0, m, m // 256)
+    ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds[idx], max_clock, threads=HOST_THREADS, history_cap=hist.shape[2])
+    assert (cc[idx] == ref["commit_counts"]).all() and (res.active_rounds[idx] == ref["active_rounds"]).all()
+    assert (res.last_committed_states[idx] == ref["last_states"]).all() and (hist[idx] == ref["histories"]).all()
+
+
+def test_full_batch_math_mode_0_all_262144_nodes(amd, oracle):
+    """The whole headline batch (65 536 x 4 nodes, clock 1000, ~1.3e8 events) on the HIP path against the oracle in
+    math_mode = 0 -- exp / log from the HOST libm, which is what the Rust reference calls -- on every host core: commit
+    counts, active rounds and State hashes of all 262 144 nodes and the aggregate counters.  (The other tests use the
+    oracle's math_mode = 1, i.e. the lbft_math.h the kernels share; tests/test_math.py bridges the two on 2e7 points.)"""
+    m = 65536
+    seeds = np.arange(1, m + 1, dtype=np.uint64)
+    _, res = run_gpu(amd, dict(num_nodes=4), seeds, 1000)
+    ref = oracle.run_batch(oracle.make_config(num_nodes=4, math_mode=0), seeds, 1000, threads=HOST_THREADS, history_cap=0)
+    assert not res.faults.any()
+    assert (res.commit_counts == ref["commit_counts"]).all()
+    assert (res.active_rounds == ref["active_rounds"]).all()
+    assert (res.last_committed_states == ref["last_states"]).all()   # SipHash of every node's whole committed history
+    c, rc = res.counters, ref["counters"]
+    for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
+        assert c[key] == rc[key], key
+    assert c["timers_folded"] < c["events"][3] and c["node_updates"] < sum(c["events"])
 
 
 # Byte-exact record hashing (SURVEY 8(f)4, first half): lbft_batch_committed_record_hashes against the oracle's own records

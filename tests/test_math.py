@@ -13,6 +13,31 @@ def test_exp_bit_identical_to_libm(oracle):
     assert bad == 0
 
 
+def test_exp_bit_identical_to_libm_on_2e7_points(oracle):
+    """The bridge between the oracle's two arithmetic modes (and hence between the HIP path, which shares lbft_math.h, and the
+    reference's glibc calls): lbft_exp == the host libm's exp, bit for bit, on 2*10^7 points -- the range the delay sampler
+    uses (mu + sigma * N for the log-normal, -x^2/2 for the ziggurat wedge test) and a sweep of the whole main path |x| < 512
+    (beyond it exp is deterministic on host and device but not correctly rounded; no delay model reaches it)."""
+    L = oracle.lib()
+    rng = np.random.default_rng(11)
+    total = 0
+    for lo, hi, n in ((-12.0, 12.0, 8_000_000), (-40.0, 0.0, 4_000_000), (0.0, 6.0, 6_000_000), (-511.0, 511.0, 2_000_000)):
+        x = rng.uniform(lo, hi, n)
+        assert L.lbft_oracle_exp_mismatches(x.ctypes.data, n) == 0, (lo, hi)
+        total += n
+    assert total == 20_000_000
+
+
+def test_log_within_one_ulp_on_1e7_points(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(12)
+    x = np.concatenate([rng.uniform(1e-300, 1.0, 5_000_000), np.exp(rng.uniform(-40, 0, 5_000_000))])
+    ulp1 = ctypes.c_size_t()
+    assert L.lbft_oracle_log_mismatches(x.ctypes.data, len(x), ctypes.byref(ulp1)) == 0
+    # (only the ziggurat's tail branch, ~1 sample in 3 700, takes a logarithm; a one-ulp difference there moves a delay by
+    # one time unit with probability ~1e-15 -- the end-to-end guard is tests/test_gpu_parity.py::test_full_batch_math_mode_0)
+
+
 def test_fixed_delay_truncation_quirk_q5(oracle):
     L = oracle.lib()
     # `--mean m --variance 0`: delay = trunc(exp(ln m)) -> 10, 19, 49 (SURVEY.md Q5)

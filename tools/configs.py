@@ -23,7 +23,45 @@ CONFIGS = {
     # commands, and the voting rights rotating by one node per epoch (rights_rotation, the epoch-reconfiguration extension)
     "c5b_1024x100_rotating_rights_epochs_fixed": dict(instances=1024, nodes=100, max_clock=600, weights=[1 + (i % 4) for i in range(100)],
                                                       commands_per_epoch=10, quirks=3, rights_rotation=1),
+    # Configurations 4 and 5 as SURVEY.md 8(d) wrote them are degenerate (round-1 verdict): with the reference's quirk Q1 a node that
+    # misses a certificate can never catch up, so under long-tailed delays stragglers accumulate until fewer than 2f+1 nodes are
+    # current and the network stops committing (C4: 0 commits by clock 300, 4 by clock 3000 at the best nodes); C5 never reaches
+    # its first epoch change.  The "live" variants exercise what the configurations are named for, at full size, in the fixed
+    # protocol mode (quirks = 3: requests answered by the peer, EpochId::previous() = id - 1):
+    #   c4live: 13 of 64 nodes equivocating under LogNormal(10, 400) delays -- every node of every instance commits >= 20 blocks by clock 1000;
+    #   c5live: weighted voting rights rotating by one node per epoch, an epoch every 3 commands -- >= 2 epoch changes per node by clock 400.
+    "c4live_16384x64_longtail_equivocators_fixed": dict(instances=16384, nodes=64, max_clock=1000, variance=400.0, equivocate_every=5, quirks=3),
+    "c5live_8192x100_rotating_rights_epochs_fixed": dict(instances=8192, nodes=100, max_clock=400, weights=[1 + (i % 4) for i in range(100)],
+                                                         commands_per_epoch=3, quirks=3, rights_rotation=1),
 }
+HBM_PEAK_GBS = 8000.0
+OPT_IN = ("c5b", "c4live", "c5live")
+
+
+def kernel_name(layout):
+    k = layout["kernel_class"]
+    cls, lean = k & 255, bool(k & 1024)
+    if cls == 0:
+        return "lbft_k_run0"
+    if lean:
+        return "lbft_k_run2l" if cls == 2 else "lbft_k_run1l"
+    return "lbft_k_run<%d>" % cls
+
+
+def roofline(layout, k, kernel_ms):
+    """SURVEY.md 8(d) per configuration, both ways (bench.py: all reference-equivalent events / rows the device moves)."""
+    ev = sum(k["events"])
+    s_node, s_evt, s_notif = layout["node_bytes"], layout["event_bytes"], layout["snapshot_bytes"]
+    p = k["events_scheduled"] / max(ev, 1)
+    r = k["events"][0] / max(ev, 1)
+    bpe = 2 * s_node + s_evt * (1 + p) + s_notif * 2 * r
+    pops = ev - k.get("timers_folded", 0)
+    ex = pops * s_node + k.get("node_updates", pops) * s_node + 2 * pops * s_evt + 2 * k["events"][0] * s_notif
+    sec = kernel_ms * 1e-3
+    return {"bound": "hbm", "kernel": kernel_name(layout), "kernel_ms": kernel_ms, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "algorithmic_bytes_per_event": bpe, "achieved": ev * bpe / sec / 1e9, "frac": ev * bpe / sec / 1e9 / HBM_PEAK_GBS,
+            "executed": {"gb_per_launch": ex / 1e9, "achieved": ex / sec / 1e9, "frac": ex / sec / 1e9 / HBM_PEAK_GBS, "queue_pops": pops,
+                         "node_updates": k.get("node_updates")}}
 
 
 def run(name, scale=1.0, reps=1, lpw=0):
@@ -43,18 +81,33 @@ def run(name, scale=1.0, reps=1, lpw=0):
         ms = sim.last_run_ms()[1]
         best = ms if best is None else min(best, ms)
     k = res.counters
-    out = {"config": name, "instances": m, "nodes": c["nodes"], "max_clock": c["max_clock"], "kernel_ms": best,
+    cc = res.commit_counts
+    worst = cc.min(axis=1)
+    liveness = {"min_node_commits": {"min": int(worst.min()), "median": float(np.median(worst)), "max": int(worst.max())},
+                "instances_with_5_commits_at_every_node": float((worst >= 5).mean()),
+                "epochs_min_max": [int(res.epochs.min()), int(res.epochs.max())]}
+    out = {"config": name, "liveness": liveness, "roofline": roofline(sim.layout(), k, best), "instances": m, "nodes": c["nodes"], "max_clock": c["max_clock"], "kernel_ms": best,
            "rounds_per_s": k["rounds"] / (best * 1e-3), "commits_per_s": k["commits"] / (best * 1e-3),
            "events_per_s": sum(k["events"]) / (best * 1e-3), "events": sum(k["events"]), "rounds": k["rounds"], "commits": k["commits"],
            "faulted_instances": k["faulted_instances"], "max_queue": k["max_queue"], "max_snapshots": k["max_snapshots"],
            "device_gb": sim.device_bytes() / 1e9, "layout": sim.layout()}
+    try:  # diagnostic builds (LBFT_HIP_LIB=.../liblbft_hip_prof.so): share of wavefront cycles per phase of the event loop
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from sweep import COUNTS, PHASES
+        pc = sim.phase_cycles()
+        tot = float(sum(int(pc[i]) for i in range(30) if i not in COUNTS)) or 1.0
+        out["phases"] = {PHASES.get(i, str(i)): round(int(pc[i]) / tot, 4) for i in range(30) if int(pc[i]) and i not in COUNTS}
+        out["cycles_per_wave_step"] = int(pc[31]) / max(int(pc[30]), 1)
+        out["wave_steps"] = int(pc[30])
+    except Exception:
+        pass
     print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    # c5b is opt-in: about a minute of GPU time per run
-    ap.add_argument("names", nargs="*", default=[n for n in CONFIGS if not n.startswith("c5b")])
+    # c5b / c4live / c5live are opt-in: seconds to a minute of GPU time per run and up to ~100 GB of device state
+    ap.add_argument("names", nargs="*", default=[n for n in CONFIGS if not n.startswith(OPT_IN)])
     ap.add_argument("--scale", type=float, default=1.0, help="fraction of the configuration's instance count")
     ap.add_argument("--reps", type=int, default=1)
     ap.add_argument("--lpw", type=int, default=0, help="lanes per wavefront carrying an instance (0 = auto)")

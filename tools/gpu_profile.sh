@@ -20,5 +20,16 @@ pass sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_
 pass sq3 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
 pass grbm GRBM_GUI_ACTIVE
 python tools/pmc_summary.py $OUT > $OUT/pmc_lbft_k_run.json 2> $OUT/pmc_summary.err
+# roofline.traffic for bench.py: FETCH/WRITE per launch, stamped with the hash of the kernel sources (copy to profiles/current/)
+python - "$OUT" "$TAG" <<'PY'
+import json, sys
+sys.path.insert(0, ".")
+from librabft_simulator_amd.build import source_hash
+out, tag = sys.argv[1], sys.argv[2]
+p = json.load(open(out + "/pmc_lbft_k_run.json"))
+json.dump({"FETCH_SIZE": p.get("FETCH_SIZE"), "WRITE_SIZE": p.get("WRITE_SIZE"), "unit": "KB per launch of the run kernel (rocprofv3 --pmc, separate passes)",
+           "profile": "profiles/%s/pmc_lbft_k_run.json" % tag, "workload": "bench.py default: 65536 x 4 nodes, max_clock 1000",
+           "source_hash": source_hash()}, open(out + "/pmc_traffic.json", "w"), indent=1)
+PY
 rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/tcc $OUT/sq1 $OUT/sq2 $OUT/sq3 $OUT/grbm
 cat $OUT/kernel_stats.csv | head -4; cat $OUT/pmc_lbft_k_run.json | head -40; tail -1 $OUT/bench_line.json | cut -c1-600

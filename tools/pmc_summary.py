@@ -8,8 +8,9 @@ import sys
 
 root = sys.argv[1]
 kernel = sys.argv[2] if len(sys.argv) > 2 else "lbft_k_run"
+prefix = sys.argv[3] if len(sys.argv) > 3 else ""  # only the pass directories whose name starts with this (one configuration)
 acc = collections.defaultdict(list)
-for path in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+for path in glob.glob(root + "/" + prefix + "*/**/*counter_collection.csv", recursive=True):
     per_dispatch = collections.defaultdict(float)
     with open(path) as f:
         for row in csv.DictReader(f):
