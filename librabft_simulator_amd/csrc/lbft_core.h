@@ -102,6 +102,8 @@ struct Params {
   u32 off_arch, ecap;   // quirks bit 0 (Q1 fixed): frozen record stores of past epochs, snapshot format, [n][ecap]
   u32 off_sync;         // quirks bit 0: scratch list of block ids (bcap words) for building a response's record order
   u32 off_trace, rcap;  // round-switch trace (DataWriter, data_writer.rs): first_time[n][rcap] then max_round[n]; rcap == 0: off
+  u32 off_ring, ring;   // cooperative large-network kernels: ring of pre-generated RNG draws (ring entries, a power of two; 2 rows each); 0 = none
+  u32 ring_topup;       // draws every network's generator runs ahead per event-loop step (0 = only on demand)
   u32 total_words;
   u32 max_steps;  // events per instance per launch (0 = unlimited)
   u32 lpw;        // lanes of each wavefront that carry an instance (1..64): occupancy vs lane-utilisation knob
@@ -154,7 +156,8 @@ enum InstField : u32 {
   I_CLOCK = 0, I_STAMP, I_RNG0, I_RNG1, I_RNG2, I_RNG3, I_RNG4, I_RNG5, I_RNG6, I_RNG7,
   I_QLEN, I_SNAP_FREE, I_NBLOCKS, I_FAULT, I_EV0, I_EV1, I_EV2, I_EV3, I_DRAWS, I_DONE,
   I_MAXQ, I_MAXSNAP, I_SNAP_MASK_LO, I_SNAP_MASK_HI, I_LAST_NODE, I_VD_TIME, I_VD_STAMP, I_CAL_CURSOR, I_CAL_FREE, I_CAL_BUMP,
-  I_NFOLD /* duplicate timers folded at scheduling time (never queued) */, I_NUPD /* update_node calls */, I_WORDS
+  I_NFOLD /* duplicate timers folded at scheduling time (never queued) */, I_NUPD /* update_node calls */,
+  I_RING_HEAD, I_RING_CNT /* ring of pre-generated draws: draws [head, head + cnt) */, I_WORDS
 };
 
 // Node-level rows (RecordStoreState record_store.rs:93-119, PacemakerState pacemaker.rs:60-77,
@@ -242,9 +245,20 @@ LBFT_HD i64 f64_to_i64_sat(double v) {
 }
 
 // ---- Xoshiro256** (rand_xoshiro 0.6) as a value type held in registers ---------------------------
-struct Rng {
+// RING: the kernels whose lanes cooperate on one network (SimT::COOP) keep a ring of pre-generated draws in the instance's
+// HBM rows in front of the live generator state: every draw is taken from the ring while it holds any (next_u64), so a
+// group of lanes can read the next 64 draws of one network with one load each, evaluate them in parallel, and the
+// sequential generator (22 instructions per draw, inherently serial) runs ahead of the consumers in every network of a
+// wavefront at once (ring_fill) instead of inside the one lane whose network happens to broadcast.
+template <bool RING>
+struct RngT {
   u64 s0, s1, s2, s3;
   u32 draws;
+  // ring state (RING only): entry e of the ring = rows (rrow + 2e, rrow + 2e + 1) of this instance's column
+  char* rtile;
+  u32 rbase;         // byte offset of the ring's first row in this lane's column (boff(off_ring))
+  u32 rhead, rcnt;   // draws [rhead, rhead + rcnt) are in the ring (indices taken modulo rmask + 1)
+  u32 rmask;         // entries - 1 (a power of two); 0xffffffff = no ring attached
   LBFT_HD void seed(u64 seed) {  // seed_from_u64: four SplitMix64 outputs
     u64 x = seed, z;
     x += 0x9e3779b97f4a7c15ULL; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; s0 = z ^ (z >> 31);
@@ -252,15 +266,38 @@ struct Rng {
     x += 0x9e3779b97f4a7c15ULL; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; s2 = z ^ (z >> 31);
     x += 0x9e3779b97f4a7c15ULL; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; s3 = z ^ (z >> 31);
     draws = 0;
+    if (RING) { rhead = 0; rcnt = 0; }
   }
-  LBFT_HD u64 next_u64() {
-    draws++;
+  LBFT_HD u64 step() {
     u64 r = rotl64(s1 * 5, 7) * 9;
     u64 t = s1 << 17;
     s2 ^= s0; s3 ^= s1; s1 ^= s2; s0 ^= s3;
     s2 ^= t;
     s3 = rotl64(s3, 45);
     return r;
+  }
+  LBFT_HD u32 ring_off(u32 e) const { return rbase + ((e & rmask) << 9); }  // two rows (512 bytes) per entry
+  LBFT_HD u64 ring_at(u32 e) const {
+    u32 o = ring_off(e);
+    return (u64)*reinterpret_cast<const u32*>(rtile + (size_t)o) | ((u64)*reinterpret_cast<const u32*>(rtile + (size_t)o + LBFT_ROW_BYTES) << 32);
+  }
+  // generator runs ahead: `g` more draws appended to the ring (the caller bounds g by the free room)
+  LBFT_HD void ring_fill(u32 g) {
+    for (u32 q = 0; q < g; q++) {
+      u64 v = step();
+      u32 o = ring_off(rhead + rcnt);
+      *reinterpret_cast<u32*>(rtile + (size_t)o) = (u32)v;
+      *reinterpret_cast<u32*>(rtile + (size_t)o + LBFT_ROW_BYTES) = (u32)(v >> 32);
+      rcnt++;
+    }
+  }
+  LBFT_HD u32 ring_room() const { return RING && rmask != 0xffffffffu ? rmask + 1 - rcnt : 0; }
+  LBFT_HD u64 next_u64() {
+    draws++;
+    if (RING) {
+      if (rcnt) { u64 v = ring_at(rhead); rhead++; rcnt--; return v; }
+    }
+    return step();
   }
   // rand 0.8 UniformInt<u64>::sample_single(0, n)  (configuration.rs:67)
   LBFT_HD u64 gen_range_u64(u64 n) {
@@ -281,6 +318,7 @@ struct Rng {
     }
   }
 };
+typedef RngT<false> Rng;
 
 // SipHash-1-3 (keys 0,0) of one little-endian u64 == Rust DefaultHasher over `Round(usize)`
 // (pacemaker.rs:101-108).
@@ -390,6 +428,41 @@ LBFT_HD size_t tile_offset_bytes(const Params& p, u32 i) { return (size_t)(i >> 
 LBFT_HD size_t state_words(const Params& p) { return (size_t)p.total_words * p.stride; }  // stride = m padded to 64
 LBFT_HD size_t word_offset(const Params& p, u32 i, u32 w) { return tile_offset_bytes(p, i) / 4 + (size_t)w * 64u + (i & 63u); }
 
+// ---- lanes of a wavefront cooperating on ONE network (SimT::coop_bulk) -------------------------------------------------
+// The cooperative code is written once over "per-lane values": on the device a PL<T> is a register of the executing lane
+// and LBFT_FOR_LANES runs its body once, for that lane; the host build (oracle/host_model.cpp, test infrastructure) holds
+// all 64 lanes' values in an array and runs each body for lane 0..63 in turn, so that the lane mapping, the ballots and the
+// shuffles of the device code are what the CPU-only differential tests execute.  Rules that keep the two equivalent: lanes
+// communicate only through the pl_* operations below or through memory written in an EARLIER body, never inside one body.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> struct PL {
+  T v;
+  LBFT_HD T& operator[](u32) { return v; }
+  LBFT_HD const T& operator[](u32) const { return v; }
+};
+LBFT_HD u32 lbft_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+#define LBFT_FOR_LANES(l) for (u32 l = lbft_lane_id(), lbft_once_ = 1; lbft_once_; lbft_once_ = 0)
+LBFT_HD u64 pl_ballot(const PL<u32>& p) { return __ballot(p.v != 0); }
+LBFT_HD void pl_shfl(PL<u32>& d, const PL<u32>& src, const PL<u32>& lane) { d.v = (u32)__shfl((int)src.v, (int)(lane.v & 63u), 64); }
+LBFT_HD u32 pl_read(const PL<u32>& src, u32 k) { return (u32)__builtin_amdgcn_readlane((int)src.v, (int)k); }  // k wavefront-uniform
+LBFT_HD void pl_write(PL<u32>& d, u32 k, u32 val) { d.v = lbft_lane_id() == k ? val : d.v; }  // (compare + select: this compiler has no writelane builtin)
+#define LBFT_UNI(x, k) ((u32)__builtin_amdgcn_readlane((int)(x), (int)(k)))  // lane k's value of x, in every lane
+#define LBFT_IS_LANE(k) (lbft_lane_id() == (k))
+#else
+template <class T> struct PL {
+  T v[64];
+  T& operator[](u32 l) { return v[l]; }
+  const T& operator[](u32 l) const { return v[l]; }
+};
+#define LBFT_FOR_LANES(l) for (u32 l = 0; l < 64; l++)
+inline u64 pl_ballot(const PL<u32>& p) { u64 m = 0; for (u32 l = 0; l < 64; l++) if (p.v[l]) m |= 1ULL << l; return m; }
+inline void pl_shfl(PL<u32>& d, const PL<u32>& src, const PL<u32>& lane) { PL<u32> t = src; for (u32 l = 0; l < 64; l++) d.v[l] = t.v[lane.v[l] & 63u]; }
+inline u32 pl_read(const PL<u32>& src, u32 k) { return src.v[k]; }
+inline void pl_write(PL<u32>& d, u32 k, u32 val) { d.v[k] = val; }
+#define LBFT_UNI(x, k) ((u32)(x))  // the host model runs one network per simulator object: it is its own lane k
+#define LBFT_IS_LANE(k) (true)
+#endif
+
 struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at most one element
   i64 next;
   i32 send_to;  // -1 = none
@@ -413,6 +486,12 @@ template <int CLS>
 struct SimT {
   static constexpr bool BIG = CLS == 2 || CLS == 5;   // multi-word node / author sets
   static constexpr bool LEAN = CLS == 5 || CLS == 6;  // 6 = class 1 without those three (13 spilled registers at 256)
+  // Large networks: the lanes of a wavefront cooperate on one network's broadcasts (coop_bulk); every class that may meet such a
+  // batch's state (the generic class 3 reads back / steps any batch) honours its ring of pre-generated draws.
+  static constexpr bool COOP = BIG;
+  static constexpr bool RING = BIG || CLS == 3;
+  bool coop_on;  // set by run_coop: the event loop is being run by a whole wavefront
+  LBFT_HD bool coop() const { return COOP && coop_on && P.qcal != 0 && P.ring != 0 && !lossy(); }
   LBFT_HD bool wide() const { return BIG ? true : (CLS == 3 ? P.n > 32 : false); }
   LBFT_HD bool heap() const { return CLS == 0 ? false : (BIG ? true : P.qheap != 0); }
   LBFT_HD bool tracing() const { return CLS != 0 && !LEAN && P.rcap != 0; }  // round-switch trace (DataWriter); class 0 never traces
@@ -427,7 +506,7 @@ struct SimT {
   i32 clock;
   u32 stamp, qlen, snap_free, nblocks, fault, maxq, maxsnap;
   u32 ev_stamp;   // creation stamp of the event being processed
-  u32 cal_cursor, cal_free, cal_bump;  // calendar queue: first possibly non-empty bucket, free-list head (slot + 1), bump allocator
+  u32 cal_cursor, cal_free, cal_bump;  // calendar queue: first possibly non-empty bucket, height of the stack of freed slots, bump allocator
   u32 last_node;  // node of the previous event (round-switch trace)
   // round-switch trace: folded duplicate timers of time vd_time still "pop" in the reference until stamp vd_stamp
   u32 vd_time, vd_stamp;
@@ -435,7 +514,7 @@ struct SimT {
   u32 ev0, ev1, ev2, ev3;
   u32 n_fold, n_upd;  // duplicate timers folded instead of queued / update_node calls: what the device executes, as opposed to the
                       // reference-equivalent event counts ev0..ev3 (bench.py reports the roofline on both)
-  Rng rng;
+  RngT<RING> rng;
 
   // Front of the event queue: slots [0, ql) live in LDS on the device (lane-private column: element k of
   // this instance is qk[k << qsh], so any per-lane slot index is bank-conflict free); slots >= ql spill to
@@ -454,7 +533,10 @@ struct SimT {
 
   LBFT_HD SimT(const Params& p, u32* state, u32 i) : SimT(p, reinterpret_cast<char*>(state) + tile_offset_bytes(p, i), (i & 63u) * 4u, 0) {}
   LBFT_HD SimT(const Params& p, char* tile_base, u32 lane_byte_offset, int) : P(p), tile(tile_base), lane4(lane_byte_offset), qk(nullptr), qm(nullptr), qstr(0), qsh(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab),
-        leader_lds(nullptr), dur_lds(nullptr), leader_lds_len(0), dur_lds_len(0), hc(nullptr), plist_lds(nullptr) {}
+        leader_lds(nullptr), dur_lds(nullptr), leader_lds_len(0), dur_lds_len(0), hc(nullptr), plist_lds(nullptr) {
+    coop_on = false;
+    if (RING) { rng.rtile = tile; rng.rbase = boff(P.off_ring); rng.rmask = P.ring ? P.ring - 1u : 0xffffffffu; rng.rhead = 0; rng.rcnt = 0; }
+  }
   LBFT_HD void attach_queue(u64* keys, u32* metas, u32 stride, u32 slots) {
     qk = keys; qm = metas; qstr = stride; ql = qpacked() ? (slots & ~7u) : slots;  // packed entries are scanned in batches of 8
     qsh = 0;
@@ -693,6 +775,7 @@ struct SimT {
     last_node = ld(I_LAST_NODE); vd_time = ld(I_VD_TIME); vd_stamp = ld(I_VD_STAMP);
     cal_cursor = ld(I_CAL_CURSOR); cal_free = ld(I_CAL_FREE); cal_bump = ld(I_CAL_BUMP);
     n_fold = ld(I_NFOLD); n_upd = ld(I_NUPD);
+    if (RING) { rng.rhead = ld(I_RING_HEAD); rng.rcnt = ld(I_RING_CNT); }
     blk_cache_reset();
   }
   LBFT_HD void store_scalars(bool done) {
@@ -707,6 +790,7 @@ struct SimT {
     st(I_LAST_NODE, last_node); st(I_VD_TIME, vd_time); st(I_VD_STAMP, vd_stamp);
     st(I_CAL_CURSOR, cal_cursor); st(I_CAL_FREE, cal_free); st(I_CAL_BUMP, cal_bump);
     st(I_NFOLD, n_fold); st(I_NUPD, n_upd);
+    if (RING) { st(I_RING_HEAD, rng.rhead); st(I_RING_CNT, rng.rcnt); }
     st(I_DONE, done ? 1u : 0u);
   }
 
@@ -804,9 +888,11 @@ struct SimT {
       // Calendar queue: bucket = (time, kind) in pop order; creation stamps grow with every push, so appending
       // keeps each bucket sorted by stamp and the key never has to be stored or compared.  O(1), ~1 round trip.
       u32 idx = (u32)time * 4u + (3u - kind);
-      u32 s1 = cal_free;                      // slot + 1
       u32 tl = ld(P.off_cal_tail + idx);
-      if (s1) cal_free = ld(P.off_qhi + s1 - 1);
+      // slot + 1: from the stack of freed slots (rows off_qlo, which the calendar does not need for keys; a stack rather than a
+      // linked free list so that a cooperative bulk send can take a whole group of slots with independent loads), else a fresh one
+      u32 s1;
+      if (cal_free) s1 = ld(P.off_qlo + --cal_free);
       else s1 = ++cal_bump;                   // bounded by the qlen < qcap check above
       st(P.off_qmeta + s1 - 1, meta);
       st(P.off_qhi + s1 - 1, 0);              // next
@@ -852,8 +938,7 @@ struct SimT {
       u32 nx = ld(P.off_qhi + s1 - 1);
       st(P.off_cal_head + idx, nx);
       if (!nx) { st(P.off_cal_tail + idx, 0); st(P.off_cal_bm + w, raw & ~(1u << (idx & 31u))); }
-      st(P.off_qhi + s1 - 1, cal_free);       // free-list link
-      cal_free = s1;
+      st(P.off_qlo + cal_free++, s1);         // stack of freed slots
       time = (i32)(idx >> 2);
       kind = 3u - (idx & 3u);
       ev_stamp = 0;                           // (only the round trace needs stamps; it runs on the heap queue)
@@ -1510,42 +1595,60 @@ struct SimT {
     }
   }
   LBFT_HD u32 arch_base(u32 node, u32 epoch) const { return P.off_arch + (node * P.ecap + epoch) * P.snap_words; }
-  // is `round` in known_quorum_certificate_rounds (record_store.rs:766-799) of a store whose chains start at hqc / hcc?
-  LBFT_HD bool known_round(u32 hqc, u32 hcc, u32 round) const {
-    for (u32 c = 0; c < 2; c++) {
-      u32 i = 0;
-      for (u32 x = c ? hcc : hqc; x; i++) {
-        Blk rx = blk_get(x);
-        if (rx.round() < round) break;
-        if (((i & (i + 1)) == 0) && rx.round() == round) return true;
-        x = rx.prev();
-      }
+  // known_quorum_certificate_rounds (record_store.rs:766-799) of the requester: the rounds at positions 0, 1, 3, 7, 15, ... of
+  // the chains below its highest quorum certificate and its highest commit certificate.  unknown_records asks "is round R
+  // known?" for the rounds of the peer's chains, which only ever DEScend along a chain -- so each (peer chain, requester
+  // chain) pair keeps a cursor that moves down the requester's chain monotonically (one light two-word fetch per block,
+  // not through the block cache: nothing else looks at these old records) instead of restarting from the top for every
+  // query: O(gap) block fetches per response instead of O(gap^2).
+  struct KnownCursor { u32 x, i, xr; };  // requester-chain block x at position i with round xr (x == 0: end of the chain)
+  LBFT_HD void chain_fetch(u32 x, u32& round, u32& prev) const {
+    u32 bb = boff(bfw(x, 0));
+    round = ldf(bb, B_ROUND); prev = ldf(bb, B_LINK) & 0xffffu;
+  }
+  LBFT_HD KnownCursor known_start(u32 x) const {
+    KnownCursor c; c.x = x; c.i = 0; c.xr = 0;
+    if (x) { u32 pv; chain_fetch(x, c.xr, pv); }
+    return c;
+  }
+  LBFT_HD bool known_at(KnownCursor& c, u32 round) const {
+    while (c.x && c.xr > round) {
+      u32 r, pv;
+      chain_fetch(c.x, r, pv);
+      c.x = pv; c.i++;
+      c.xr = 0;
+      if (pv) { u32 pv2; chain_fetch(pv, c.xr, pv2); }
     }
-    return false;
+    return c.x != 0 && c.xr == round && ((c.i & (c.i + 1)) == 0);
   }
   // unknown_records (record_store.rs:801-831) of the store described at `base`, inserted into node's current store in
   // the order the reference sends them: (block, QC) pairs by ascending round, the timeouts, the proposed block.
   LBFT_HD void insert_unknown_records(u32 node, u32 base, bool filter, u32 k_hqc, u32 k_hcc) {
     u32 certs = ld(base + S_CERTS);
     u32 x1 = certs >> 16, x2 = certs & 0xffffu, cnt = 0;
+    // cursors [peer chain][requester chain]
+    KnownCursor q1q = known_start(filter ? k_hqc : 0), q1c = known_start(filter ? k_hcc : 0), q2q = q1q, q2c = q1c;
+    Blk r1, r2;
+    for (u32 f = 0; f < BC_WORDS; f++) { r1.w[f] = 0; r2.w[f] = 0; }
+    bool fresh1 = true, fresh2 = true;  // x1 / x2 moved to a block that has not been looked at yet
     for (;;) {  // util.rs merge_sort of the two chains by descending round, identical certificates once
-      Blk r1, r2;
-      for (u32 f = 0; f < BC_WORDS; f++) { r1.w[f] = 0; r2.w[f] = 0; }
-      if (x1) { r1 = blk_get(x1); if (filter && known_round(k_hqc, k_hcc, r1.round())) x1 = 0; }
-      if (x2) { r2 = blk_get(x2); if (filter && known_round(k_hqc, k_hcc, r2.round())) x2 = 0; }
+      if (x1 && fresh1) { r1 = blk_get(x1); fresh1 = false; if (filter && (known_at(q1q, r1.round()) || known_at(q1c, r1.round()))) x1 = 0; }
+      if (x2 && fresh2) { r2 = blk_get(x2); fresh2 = false; if (filter && (known_at(q2q, r2.round()) || known_at(q2c, r2.round()))) x2 = 0; }
       if (!x1 && !x2) break;
       u32 e1 = 0, e2 = 0;
       if (x1 && x2) {
         if (r2.round() < r1.round()) e1 = x1;
         else if (r2.round() == r1.round()) { e1 = x1; if (x2 != x1) e2 = x2; }
         else e2 = x2;
-        if (r2.round() <= r1.round()) x1 = r1.prev();
-        if (r2.round() >= r1.round()) x2 = r2.prev();
-      } else if (x1) { e1 = x1; x1 = r1.prev(); }
-      else { e2 = x2; x2 = r2.prev(); }
+        bool adv1 = r2.round() <= r1.round(), adv2 = r2.round() >= r1.round();
+        if (adv1) { x1 = r1.prev(); fresh1 = true; }
+        if (adv2) { x2 = r2.prev(); fresh2 = true; }
+      } else if (x1) { e1 = x1; x1 = r1.prev(); fresh1 = true; }
+      else { e2 = x2; x2 = r2.prev(); fresh2 = true; }
       if (e1) { if (cnt < P.bcap) st(P.off_sync + cnt, e1); else fault |= F_EPOCH_OVERFLOW; cnt++; }
       if (e2) { if (cnt < P.bcap) st(P.off_sync + cnt, e2); else fault |= F_EPOCH_OVERFLOW; cnt++; }
     }
+    LBFT_MARK(21);
     if (cnt > P.bcap) cnt = P.bcap;
     u32 epoch = nf(node, NF_EPOCH);
     for (u32 j = cnt; j-- > 0;) {
@@ -1846,6 +1949,16 @@ struct SimT {
       if (act.query_all) n_b = P.n - 1;
     }
     u32 first_a = sp.response + sp.sync, first_b = first_a + n_a, total = first_b + n_b;
+    // Cooperative kernels: a list of n - 1 messages (broadcast / query-all) is left to coop_bulk, which run_coop executes with
+    // all lanes of the wavefront right after this loop -- same order, same draws; what precedes the lists (response, sync
+    // request, a single notification) is sent here.  (n > 32: n_a is 0, 1 or n - 1 and n_b is 0 or n - 1.)
+    bulk = 0;
+    if (coop()) {
+      if (n_a > 1) bulk |= 1u;
+      if (n_b > 0) bulk |= 2u;
+      total = first_a + (n_a == 1 ? 1u : 0u);
+      bulk_node = node;
+    }
     LBFT_STAT(16 + (total > 7 ? 7 : total)); LBFT_STATN(24, total);
     if (sp.have_actions) { if (act.broadcast) LBFT_STAT(25); else if (n_a) LBFT_STAT(26); if (act.query_all) LBFT_STAT(27); if (sp.sync) LBFT_STAT(28); }
     i32 slot = -1, slot_twin = -1, rs = 0;
@@ -1918,8 +2031,277 @@ struct SimT {
     }
     if (slot >= 0) { if (refs) st(P.off_snap_ref + (u32)slot, refs); else snap_free_slot((u32)slot); }
     if (slot_twin >= 0) { if (refs_twin) st(P.off_snap_ref + (u32)slot_twin, refs_twin); else snap_free_slot((u32)slot_twin); }
-    if (q1() && n_b && rs >= 0) { if (rrefs) st(P.off_snap_ref + (u32)rs, rrefs); else snap_free_slot((u32)rs); }
+    if (q1() && n_b && rs >= 0 && !(bulk & 2u)) { if (rrefs) st(P.off_snap_ref + (u32)rs, rrefs); else snap_free_slot((u32)rs); }
     LBFT_MARK(13);
+  }
+
+  // ---- cooperative bulk send: the n - 1 messages of one broadcast (which = 0: DataSyncNotify to the shuffled receivers,
+  // simulator.rs:326-354) or one query-all (which = 1: DataSyncRequest to the shuffled senders, :356-377) of the network in
+  // lane `k`, executed by ALL lanes of the wavefront: lanes = messages.  The reference's order is kept exactly -- shuffle
+  // draws, then one delay sample per receiver in shuffled order, creation stamps in that order, FIFO order inside every
+  // (time, kind) bucket of the calendar queue -- but only what is inherently serial runs serially:
+  //   * the Fisher-Yates shuffle: a wavefront-uniform loop over draws that all lanes fetched from the ring with one load;
+  //   * the delay samples: every lane evaluates one ring draw as if a sample started there (ziggurat first try +
+  //     exp, or the uniform model's first try); a ballot of "first try accepted" tells how many consecutive samples those
+  //     lanes settle at once, and only a draw that needs the rejection path (~1.2 %) is sampled serially by the leader;
+  //   * the pushes: slots come from the stack of freed slots / the bump allocator by rank (independent loads), lanes whose
+  //     messages fall into the same bucket find each other with bit-sliced ballots over the time, link themselves in lane
+  //     (= stamp) order, and one lane per bucket appends the chain to the bucket's tail -- one dependent load per distinct
+  //     bucket instead of one memory round trip per message.
+  u32 bulk;       // leader lane: bit 0 = a broadcast is pending, bit 1 = a query-all is pending (set by send_loop)
+  u32 bulk_node;  // leader lane: the node whose actions are being processed
+  LBFT_HD u32 ldc(u32 l4, u32 w) const { return *reinterpret_cast<const u32*>(tile + (size_t)((w << 8) + l4)); }
+  LBFT_HD void stc(u32 l4, u32 w, u32 v) const { *reinterpret_cast<u32*>(tile + (size_t)((w << 8) + l4)) = v; }
+  // the first try of sample_delay() on the draw `bits`: true = accepted (then d is the delay sample_delay() returns)
+  LBFT_HD bool fast_delay(u64 bits, i64& d) const {
+    if (P.delay_model == 1) {
+      u64 zone = (P.uni_span << clz64(P.uni_span)) - 1;
+      d = P.uni_lo + (i64)mulhi64(bits, P.uni_span);
+      return bits * P.uni_span <= zone;
+    }
+    u32 i = (u32)(bits & 0xff);
+    double u = lbft_asdouble((1024ULL << 52) | (bits >> 12)) - 3.0;
+    double x = u * lbft_asdouble(zig_x[i]);
+    double ax = x < 0.0 ? -x : x;
+    d = f64_to_i64_sat(lbft_exp(P.mu + P.sigma * x, exp_tab));
+    return ax < lbft_asdouble(zig_x[i + 1]);
+  }
+  LBFT_HD u32 horizon_time(i32 clk, i64 d) const {  // clock + delay, 0xffffffff = past max_clock (never queued)
+    i64 t = d > INT64_MAX - (i64)clk ? INT64_MAX : (i64)clk + d;
+    return t <= (i64)P.max_clock ? (u32)t : 0xffffffffu;
+  }
+  LBFT_HD void coop_bulk(u32 k, u32 which) {
+    const bool is_k = LBFT_IS_LANE(k);
+    const u32 l4 = LBFT_UNI(lane4, k);
+    const u32 node = LBFT_UNI(bulk_node, k);
+    const i32 clk = (i32)LBFT_UNI((u32)clock, k);
+    const u32 cnt = P.n - 1;
+    const u32 kc = which ? 2u : 3u;  // 3 - Event kind (DataSyncNotify = 0, DataSyncRequest = 1): the bucket within a time
+    const u32 ring_row = P.off_ring, ring_mask = P.ring - 1u;
+    // leader: what the scalar loop decides at the start of a list
+    u32 eq_k = 0, rs_k = 0;
+    if (is_k) {
+      if (which == 0) {
+        if (is_equivocator(node)) {  // (E2): does this notification carry one of the node's own (double) proposals?
+          u32 pb = proposed_block(node);
+          eq_k = (pb != 0 && blk_get(pb).author() == node) ? 1u : 0u;
+        }
+      } else {
+        rs_k = q1() ? (u32)make_request_slot(nf(node, NF_EPOCH), nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16)) : 0u;
+      }
+    }
+    const u32 equivocal = LBFT_UNI(eq_k, k);
+    const i32 rs = (i32)LBFT_UNI(rs_k, k);
+    // ---- receivers in index order, then SliceRandom::shuffle: for i = cnt - 1 .. 1: swap(i, gen_range_u32(i + 1)) ----
+    PL<u32> perm0, perm1;  // entry i of the list: lane i of perm0 (i < 64) / lane i - 64 of perm1
+    LBFT_FOR_LANES(l) { perm0[l] = l < node ? l : l + 1u; perm1[l] = 64u + l < node ? 64u + l : 65u + l; }
+    for (u32 i = cnt - 1; i >= 1;) {
+      u32 avail = LBFT_UNI(rng.rcnt, k);
+      if (avail == 0) {
+        if (is_k) rng.ring_fill(rng.ring_room() < 64u ? rng.ring_room() : 64u);
+        avail = LBFT_UNI(rng.rcnt, k);
+      }
+      const u32 take = avail < 64u ? avail : 64u;
+      const u32 head = LBFT_UNI(rng.rhead, k);
+      PL<u32> dhi;  // next_u32() = next_u64() >> 32 of the next `take` draws
+      LBFT_FOR_LANES(l) dhi[l] = l < take ? ldc(l4, ring_row + 2u * ((head + l) & ring_mask) + 1u) : 0u;
+      u32 used = 0;
+      while (used < take && i >= 1) {
+        u32 v = pl_read(dhi, used);
+        used++;
+        u32 range = i + 1u, zone = (range << clz32(range)) - 1u;
+        u64 mm = (u64)v * range;
+        if ((u32)mm <= zone) {
+          u32 j = (u32)(mm >> 32);
+          u32 a = i < 64u ? pl_read(perm0, i) : pl_read(perm1, i - 64u);
+          u32 b = j < 64u ? pl_read(perm0, j) : pl_read(perm1, j - 64u);
+          if (i < 64u) pl_write(perm0, i, b); else pl_write(perm1, i - 64u, b);
+          if (j < 64u) pl_write(perm0, j, a); else pl_write(perm1, j - 64u, a);
+          i--;
+        }
+      }
+      if (is_k) { rng.rhead += used; rng.rcnt -= used; rng.draws += used; }
+    }
+    LBFT_MARK(16);
+    // ---- one delay sample per receiver, in list order ----
+    PL<u32> tm0, tm1;  // scheduled time of message j (lane j of tm0 / lane j - 64 of tm1); 0xffffffff = past the horizon
+    LBFT_FOR_LANES(l) { tm0[l] = 0xffffffffu; tm1[l] = 0xffffffffu; }
+    for (u32 j = 0; j < cnt;) {
+      u32 avail = LBFT_UNI(rng.rcnt, k);
+      if (avail == 0) {
+        if (is_k) rng.ring_fill(rng.ring_room() < 64u ? rng.ring_room() : 64u);
+        avail = LBFT_UNI(rng.rcnt, k);
+      }
+      const u32 take = avail < 64u ? avail : 64u;
+      const u32 head = LBFT_UNI(rng.rhead, k);
+      PL<u32> fast, tv;
+      LBFT_FOR_LANES(l) {
+        fast[l] = 0; tv[l] = 0xffffffffu;
+        if (l < take) {
+          u32 e = ring_row + 2u * ((head + l) & ring_mask);
+          u64 bits = (u64)ldc(l4, e) | ((u64)ldc(l4, e + 1u) << 32);
+          i64 d;
+          fast[l] = fast_delay(bits, d) ? 1u : 0u;
+          tv[l] = horizon_time(clk, d);
+        }
+      }
+      const u64 F = pl_ballot(fast);
+      u32 run = ~F ? ctz64(~F) : 64u;  // consecutive first-try samples from the head of the ring
+      if (run > take) run = take;
+      if (run > cnt - j) run = cnt - j;
+      {  // message j + q takes lane q's value (q < run)
+        PL<u32> src, got;
+        LBFT_FOR_LANES(l) src[l] = (l - j) & 63u;
+        pl_shfl(got, tv, src);
+        LBFT_FOR_LANES(l) if (l >= j && l < j + run) tm0[l] = got[l];
+        if (cnt > 64u) {
+          LBFT_FOR_LANES(l) src[l] = (64u + l - j) & 63u;
+          pl_shfl(got, tv, src);
+          LBFT_FOR_LANES(l) if (64u + l >= j && 64u + l < j + run) tm1[l] = got[l];
+        }
+      }
+      if (is_k) { rng.rhead += run; rng.rcnt -= run; rng.draws += run; }
+      j += run;
+      if (j < cnt && run < take) {  // the draw at the head needs the rejection path: the leader samples it serially
+        u32 tvk = 0;
+        if (is_k) tvk = horizon_time(clk, sample_delay());
+        u32 tvu = LBFT_UNI(tvk, k);
+        if (j < 64u) pl_write(tm0, j, tvu); else pl_write(tm1, j - 64u, tvu);
+        j++;
+      }
+    }
+    LBFT_MARK(18);
+    // ---- schedule: lanes = messages, 64 at a time ----
+    i32 sr = -1, st_ = -1;  // snapshot slot of the notification / of its twin (-1 not needed yet, -2 none available)
+    u32 refs = 0, refs_twin = 0, rrefs = 0;
+    for (u32 jb = 0; jb < cnt; jb += 64u) {
+      PL<u32> r, t, live, twin;
+      LBFT_FOR_LANES(l) {
+        r[l] = jb ? perm1[l] : perm0[l];
+        t[l] = jb + l < cnt ? (jb ? tm1[l] : tm0[l]) : 0xffffffffu;
+        live[l] = t[l] != 0xffffffffu ? 1u : 0u;
+        twin[l] = (which == 0 && equivocal && (r[l] & 1u) == 0) ? 1u : 0u;
+      }
+      const u64 T = pl_ballot(twin);
+      if (which == 0) {  // the notification snapshot(s), created at the first message that is actually scheduled
+        const u64 L0 = pl_ballot(live);
+        const u64 Lr = L0 & ~T, Lt = L0 & T;
+        const bool need_r = Lr != 0 && sr == -1, need_t = Lt != 0 && st_ == -1;
+        const bool twin_first = need_r && need_t && ctz64(Lt) < ctz64(Lr);
+        if (is_k) {
+          for (u32 q = 0; q < 2; q++) {
+            bool do_twin = (q == 0) == twin_first;
+            if (do_twin && need_t) { st_ = snap_alloc(); if (st_ < 0) st_ = -2; else write_snapshot(node, (u32)st_, true); }
+            if (!do_twin && need_r) { sr = snap_alloc(); if (sr < 0) sr = -2; else write_snapshot(node, (u32)sr); }
+          }
+        }
+        sr = (i32)LBFT_UNI((u32)sr, k); st_ = (i32)LBFT_UNI((u32)st_, k);
+        LBFT_FOR_LANES(l) if (live[l] && (twin[l] ? st_ < 0 : sr < 0)) live[l] = 0;  // no slot: not scheduled, the stamp is consumed
+      } else if (rs < 0) {
+        LBFT_FOR_LANES(l) live[l] = 0;
+      }
+      u64 L = pl_ballot(live);
+      u32 nl = popc64(L);
+      const u32 qlen_u = LBFT_UNI(qlen, k);
+      const u32 room = P.qcap > qlen_u ? P.qcap - qlen_u : 0u;
+      if (nl > room) {  // queue overflow: the surplus is not scheduled
+        LBFT_FOR_LANES(l) if (live[l] && popc64(L & ((1ULL << l) - 1ULL)) >= room) live[l] = 0;
+        if (is_k) fault |= F_QUEUE_OVERFLOW;
+        L = pl_ballot(live);
+        nl = popc64(L);
+      }
+      if (nl) {
+        const u32 fc = LBFT_UNI(cal_free, k), bump = LBFT_UNI(cal_bump, k);
+        const u32 slot_word = which == 0 ? 0u : (u32)rs;
+        PL<u32> s1;  // queue slot + 1 of the lane's message
+        LBFT_FOR_LANES(l) {
+          s1[l] = 0;
+          if (live[l]) {
+            u32 rank = popc64(L & ((1ULL << l) - 1ULL));
+            s1[l] = rank < fc ? ldc(l4, P.off_qlo + fc - 1u - rank) : bump + (rank - fc) + 1u;
+            u32 snap = which == 0 ? (u32)(twin[l] ? st_ : sr) : slot_word;
+            u32 meta = which == 0 ? (r[l] | (node << 8) | (snap << 16)) : (node | (r[l] << 8) | (snap << 16));
+            stc(l4, P.off_qmeta + s1[l] - 1u, meta);
+          }
+        }
+        // lanes whose messages share a bucket (same time; the kind is common): M; sharing a bitmap word (same time >> 3): M3
+        PL<u64> M, M3;
+        LBFT_FOR_LANES(l) { M[l] = live[l] ? L : 0; M3[l] = M[l]; }
+        for (u32 b = 0; (1u << b) <= (u32)P.max_clock; b++) {
+          PL<u32> bit;
+          LBFT_FOR_LANES(l) bit[l] = (live[l] && ((t[l] >> b) & 1u)) ? 1u : 0u;
+          const u64 B = pl_ballot(bit);
+          if (B == 0 || B == L) continue;
+          LBFT_FOR_LANES(l) { u64 m = bit[l] ? B : ~B; M[l] &= m; if (b >= 3u) M3[l] &= m; }
+        }
+        PL<u32> succ_lane, has_succ, has_pred, succ_slot;
+        LBFT_FOR_LANES(l) {
+          u64 lower = M[l] & ((1ULL << l) - 1ULL);
+          u64 upper = l == 63u ? 0ULL : (M[l] >> (l + 1u)) << (l + 1u);
+          has_pred[l] = lower != 0; has_succ[l] = upper != 0;
+          succ_lane[l] = upper ? ctz64(upper) : l;
+        }
+        pl_shfl(succ_slot, s1, succ_lane);
+        PL<u32> tl;
+        LBFT_FOR_LANES(l) {
+          tl[l] = 0;
+          if (live[l]) {
+            stc(l4, P.off_qhi + s1[l] - 1u, has_succ[l] ? succ_slot[l] : 0u);  // next
+            if (!has_pred[l]) tl[l] = ldc(l4, P.off_cal_tail + t[l] * 4u + kc);
+          }
+        }
+        PL<u32> needbit;
+        LBFT_FOR_LANES(l) {
+          needbit[l] = 0;
+          if (live[l]) {
+            u32 idx = t[l] * 4u + kc;
+            if (!has_pred[l]) {
+              if (tl[l]) stc(l4, P.off_qhi + tl[l] - 1u, s1[l]);
+              else { stc(l4, P.off_cal_head + idx, s1[l]); needbit[l] = 1; }
+            }
+            if (!has_succ[l]) stc(l4, P.off_cal_tail + idx, s1[l]);
+          }
+        }
+        const u64 NB = pl_ballot(needbit);
+        if (NB) {  // occupancy bits of buckets that were empty: one read-modify-write per bitmap word
+          PL<u32> bits;
+          LBFT_FOR_LANES(l) bits[l] = 0;
+          for (u32 v = 0; v < 8u; v++) {
+            PL<u32> is_v;
+            LBFT_FOR_LANES(l) is_v[l] = (needbit[l] && (t[l] & 7u) == v) ? 1u : 0u;
+            const u64 Bv = pl_ballot(is_v);
+            if (!Bv) continue;
+            LBFT_FOR_LANES(l) if (needbit[l] && (M3[l] & Bv)) bits[l] |= 1u << (v * 4u + kc);
+          }
+          LBFT_FOR_LANES(l) {
+            if (needbit[l] && (M3[l] & NB & ((1ULL << l) - 1ULL)) == 0) {
+              u32 w = P.off_cal_bm + (t[l] >> 3);
+              stc(l4, w, ldc(l4, w) | bits[l]);
+            }
+          }
+        }
+        if (which == 0) { refs += popc64(L & ~T); refs_twin += popc64(L & T); } else rrefs += nl;
+        if (is_k) {
+          qlen += nl;
+          if (qlen > maxq) maxq = qlen;
+          cal_free = fc - (nl < fc ? nl : fc);
+          cal_bump = bump + (nl > fc ? nl - fc : 0u);
+          u32 lo = (u32)clk * 4u + kc;  // every message lies at or after the current time: a lower bound for the cursor
+          if (lo < cal_cursor) cal_cursor = lo;
+        }
+      }
+    }
+    if (is_k) {
+      stamp += cnt;
+      if (stamp >= (1u << 30)) fault |= F_STAMP_OVERFLOW;
+      if (which == 0) {
+        if (sr >= 0) { if (refs) st(P.off_snap_ref + (u32)sr, refs); else snap_free_slot((u32)sr); }
+        if (st_ >= 0) { if (refs_twin) st(P.off_snap_ref + (u32)st_, refs_twin); else snap_free_slot((u32)st_); }
+      } else if (q1() && rs >= 0) {
+        if (rrefs) st(P.off_snap_ref + (u32)rs, rrefs); else snap_free_slot((u32)rs);
+      }
+    }
+    LBFT_MARK(19);
   }
 
   // ---- record hashes of a node's committed chain (first half: byte-exact record hashing) ----
@@ -2023,17 +2405,15 @@ struct SimT {
   }
 
   // ---- Simulator::loop_until (simulator.rs:380-475); returns true when the queue drained ----
-  LBFT_HD bool run() {
-    u32 steps = 0;
-    u32 max_steps = P.max_steps ? P.max_steps : 0xffffffffu;
-    LBFT_PIN_VGPR(max_steps);
-    for (;;) {
-      if (steps >= max_steps) return false;
+  // One event = step_begin (pop, the node's rows, the event's handler, update_node, process_node_actions, the messages the
+  // scalar send loop handles) + step_end (write-back); the cooperative kernels run coop_bulk between the two.
+  struct StepCtx { u32 node, sender, kind; i32 t_event; bool do_update; };
+  LBFT_HD bool step_begin(StepCtx& c) {  // false: the queue is empty
+    {
       i32 t; u32 kind, meta;
-      if (!pop_event(t, kind, meta)) return true;
+      if (!pop_event(t, kind, meta)) return false;
       LBFT_MARK(0);
       LBFT_COUNT(30);
-      steps++;
       if (tracing()) trace_round_switch(last_node, t);
       i32 t_event = t;
       if (t > clock) clock = t;
@@ -2117,17 +2497,76 @@ struct SimT {
         sp.have_actions = 1;
       }
       send_loop(node, sender, sp, a);
-      if (do_update) {
-        LBFT_DRAIN_VMEM();
-        LBFT_MARK(14);
-        end_node(node);
-        LBFT_MARK(15);
-        LBFT_DRAIN_VMEM();
-        LBFT_MARK(17);
-      }
-      // folded duplicate timers of this scheduled time still pop after this timer in the reference
-      if (tracing() && kind == 3 && (u32)t_event == vd_time && ev_stamp < vd_stamp) trace_round_switch(node, t_event);
+      c.node = node; c.sender = sender; c.kind = kind; c.t_event = t_event; c.do_update = do_update;
     }
+    return true;
+  }
+  LBFT_HD void step_end(const StepCtx& c) {
+    if (c.do_update) {
+      LBFT_DRAIN_VMEM();
+      LBFT_MARK(14);
+      end_node(c.node);
+      LBFT_MARK(15);
+      LBFT_DRAIN_VMEM();
+      LBFT_MARK(17);
+    }
+    // folded duplicate timers of this scheduled time still pop after this timer in the reference
+    if (tracing() && c.kind == 3 && (u32)c.t_event == vd_time && ev_stamp < vd_stamp) trace_round_switch(c.node, c.t_event);
+  }
+  LBFT_HD bool run() {
+    u32 steps = 0;
+    u32 max_steps = P.max_steps ? P.max_steps : 0xffffffffu;
+    LBFT_PIN_VGPR(max_steps);
+    bulk = 0;
+    for (;;) {
+      if (steps >= max_steps) return false;
+      StepCtx c;
+      if (!step_begin(c)) return true;
+      steps++;
+      // (a kernel class with cooperative bulk sends that is run lane-per-network -- the generic read-back class, the host
+      // model's scalar mode -- never defers a list: coop() is false outside run_coop's classes)
+      step_end(c);
+    }
+  }
+  // The same loop for the kernels whose lanes cooperate (COOP): EVERY lane of the wavefront runs it; `leader` lanes carry a
+  // network and execute the events, the other lanes only take part in the bulk sends of the leaders' networks.
+  LBFT_HD bool run_coop(bool leader) {
+    u32 steps = 0;
+    u32 max_steps = P.max_steps ? P.max_steps : 0xffffffffu;
+    bool go = leader, drained = true;
+    bulk = 0; bulk_node = 0;
+    coop_on = true;
+    for (;;) {
+      if (go && steps >= max_steps) { go = false; drained = false; }
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (__ballot(go) == 0) break;
+#else
+      if (!go) break;
+#endif
+      StepCtx c;
+      c.node = 0; c.sender = 0; c.kind = 0; c.t_event = 0; c.do_update = false;
+      bulk = 0;
+      bool act = go;
+      if (act) {
+        // the generator runs ahead of the consumers in every network of the wavefront at once (see RngT)
+        if (P.ring_topup) { u32 room = rng.ring_room(); rng.ring_fill(room < P.ring_topup ? room : P.ring_topup); }
+        if (!step_begin(c)) { go = false; act = false; } else steps++;
+      }
+#if defined(__HIP_DEVICE_COMPILE__)
+      unsigned long long need = __ballot(act && bulk != 0);
+#else
+      unsigned long long need = (act && bulk != 0) ? 1ULL : 0ULL;
+#endif
+      while (need) {
+        u32 k = ctz64(need);
+        need &= need - 1;
+        u32 bk = LBFT_UNI(bulk, k);
+        if (bk & 1u) coop_bulk(k, 0);
+        if (bk & 2u) coop_bulk(k, 1);
+      }
+      if (act) step_end(c);
+    }
+    return drained;
   }
 };
 
@@ -2153,7 +2592,7 @@ inline u64 compute_layout(Params& p) {
   p.mw = (p.n + 31) / 32;
   p.off_node = (u32)w; p.node_words = NF_FIXED_WORDS + 2 * p.n + 4 * (p.mw - 1); w += (u64)p.n * p.node_words;
   p.off_qhi = (u32)w; w += p.qcap;
-  p.off_qlo = (u32)w; w += p.qcal ? 0 : p.qcap;  // the calendar stores no keys
+  p.off_qlo = (u32)w; w += p.qcap;  // (the calendar stores no keys: these rows hold its stack of freed slots)
   p.off_qmeta = (u32)w; w += p.qcap;
   p.cal_buckets = p.qcal ? ((u32)p.max_clock + 1u) * 4u : 0;
   p.off_cal_head = (u32)w; w += p.cal_buckets;
@@ -2170,6 +2609,7 @@ inline u64 compute_layout(Params& p) {
   p.off_trace = (u32)w; w += p.rcap ? (u64)p.n * p.rcap + p.n : 0;
   p.off_arch = (u32)w; w += (p.quirks & 1u) ? (u64)p.n * p.ecap * p.snap_words : 0;
   p.off_sync = (u32)w; w += (p.quirks & 1u) ? p.bcap : 0;
+  p.off_ring = (u32)w; w += 2ULL * p.ring;
   p.total_words = w > 0xffffffffULL ? 0xffffffffu : (u32)w;
   p.qpack = sim_class(p) == 0 ? 1u : 0u;
   return w;

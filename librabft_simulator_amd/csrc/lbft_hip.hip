@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -101,6 +102,41 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
   // every row access is saddr + 32-bit voffset
   u32 tile_idx = __builtin_amdgcn_readfirstlane(((blockIdx.x * LBFT_RUN_WAVES + wave) * p.lpw) >> 6);
   char* tile = reinterpret_cast<char*>(state) + (size_t)tile_idx * p.total_words * LBFT_ROW_BYTES;
+  if constexpr (SimT<CLS>::COOP) {
+    // Large networks: EVERY lane of the wavefront runs the event loop; the first lpw lanes carry a network each, all 64
+    // cooperate on the bulk sends of those networks (SimT::run_coop / coop_bulk).
+    SimT<CLS> s(p, tile, ((active ? i : lane) & 63u) * 4u, 0);
+    bool lead = false;
+    if (active) lead = s.ld(I_DONE) == 0;
+    s.attach_queue(keys, metas, p.lpw, p.ql);
+    s.attach_tables(t_zx, t_zf, t_et);
+    s.attach_round_tables(t_leader, n_leader, t_dur, n_dur);
+    if (lead) {
+      u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 12u);
+      s.attach_peer_list(lists + ((size_t)wave * p.lpw + lane) * LBFT_MAX_NODES);
+      s.load_scalars();
+      s.queue_to_lds();
+    }
+#if defined(LBFT_PHASE_TIMERS)
+    u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)LBFT_RUN_WAVES * p.ql * p.lpw) +
+                                        (size_t)meta_words + (meta_words & 1u)) + wave * LBFT_NPHASES;
+    if (lane == 0) { for (int k = 0; k < LBFT_NPHASES; k++) wprof[k] = 0; wprof[31] = __builtin_readcyclecounter(); }
+    s.wprof = wprof;
+    u64 t_begin = __builtin_readcyclecounter();
+#endif
+    bool drained = s.run_coop(lead);
+    if (lead) {
+      done = drained;
+      s.queue_from_lds();
+      s.store_scalars(done);
+    }
+#if defined(LBFT_PHASE_TIMERS)
+    if (p.prof && lane == 0) {
+      for (int k = 0; k < 31; k++) atomicAdd(&p.prof[k], (unsigned long long)s.wprof[k]);
+      atomicAdd(&p.prof[31], (unsigned long long)(__builtin_readcyclecounter() - t_begin));
+    }
+#endif
+  } else
   if (active) {
     SimT<CLS> s(p, tile, (i & 63u) * 4u, 0);
     if (s.ld(I_DONE) == 0) {
@@ -820,6 +856,21 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   p.qcap = qcap; p.scap = scap; p.bcap = bcap; p.lcap = lcap; p.rcap = b->rcap; p.qcal = qcal; p.qheap = qheap; p.ecap = ecap;
   p.max_clock = (i32)max_clock;
   p.max_steps = b->max_steps;
+  // Cooperative large-network kernels (class 2 on the calendar queue): ring of pre-generated RNG draws per instance and how far
+  // every network's generator runs ahead per step (tuning knobs: LBFT_RING = entries, a power of two, 0 = lane-per-network
+  // execution as for the small classes; LBFT_RING_TOPUP = draws per step)
+  {
+    u32 ring = 0, topup = 0;
+    if (n > 32 && qcal) {
+      ring = 512; topup = 4;
+      if (const char* e = getenv("LBFT_RING")) ring = (u32)atoi(e);
+      if (const char* e = getenv("LBFT_RING_TOPUP")) topup = (u32)atoi(e);
+      if (ring & (ring - 1)) ring = 512;
+      if (ring && ring < 128) ring = 128;
+    }
+    if (p.ring != ring) relayout = true;
+    p.ring = ring; p.ring_topup = ring ? topup : 0;
+  }
   u64 words = compute_layout(p);
   if (p.qcal) {  // the calendar's bucket rows grow with the horizon: keep it only while the batch fits comfortably in HBM
     size_t free_b = 0, total_b = 0;

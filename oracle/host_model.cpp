@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../librabft_simulator_amd/csrc/lbft_core.h"
@@ -26,6 +27,8 @@ typedef struct lbft_hostmodel_caps {
   uint32_t force_generic;  // 1 = run the step as the run-time-generic class SimT<3> instead of the specialised one
   uint32_t rcap;           // > 0: round-switch trace (DataWriter) with this many rounds per node
   uint32_t qcal;           // 1 = calendar event queue (needs max_clock <= LBFT_CAL_MAX_CLOCK and a class >= 1 kernel)
+  uint32_t ring;           // > 0 (class 2 + calendar): the cooperative event loop (run_coop / coop_bulk, 64 emulated lanes) with a ring of this many pre-generated draws
+  uint32_t ring_topup;     // draws the generator runs ahead per step
 } lbft_hostmodel_caps;
 
 // Same outputs as lbft_oracle_run_batch, plus per-instance fault words and max queue/snapshot use.
@@ -53,6 +56,8 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
     if (p.ecap < 64) p.ecap = 64;
   }
   p.qcal = caps->qcal;
+  p.ring = (caps->qcal && p.n > 32) ? caps->ring : 0; p.ring_topup = p.ring ? caps->ring_topup : 0;
+  if (p.ring & (p.ring - 1)) return -12;
   if (p.qcal) { if (max_clock > LBFT_CAL_MAX_CLOCK || p.rcap) return -11; p.qheap = 1; p.ql = 0; }
   p.delay_model = cfg->delay_model;
   p.mu = std::log(cfg->mean / std::sqrt(1.0 + cfg->variance / (cfg->mean * cfg->mean)));
@@ -101,7 +106,9 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
     s.load_scalars();
     s.queue_to_lds();
     s.hcbr_to_lds();
-    bool done = s.run();
+    bool done;
+    if constexpr (std::remove_reference<decltype(s)>::type::COOP) done = p.ring ? s.run_coop(true) : s.run();
+    else done = s.run();
     s.queue_from_lds();
     s.hcbr_from_lds();
     s.store_scalars(done);

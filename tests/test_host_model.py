@@ -60,6 +60,57 @@ LARGE = {
 }
 
 
+# Cooperative event loop of the large-network kernels (SimT::run_coop / coop_bulk): the host build emulates the 64 lanes of a
+# wavefront (PL<T> arrays, LBFT_FOR_LANES), so the lane mapping, ballots and shuffles of the device code run here.  ring = ring of
+# pre-generated RNG draws (entries), topup = draws the generator runs ahead per step.
+COOP = {
+    "n33_two_mask_words": (dict(num_nodes=33), 2, 300),
+    "n33_uniform_delays": (dict(num_nodes=33, delay_model=1, uniform_lo=5, uniform_hi=15), 2, 300),
+    "n40": (dict(num_nodes=40), 2, 250),
+    "n64_long_tail": (dict(num_nodes=64, mean=10.0, variance=400.0), 2, 300),
+    "n64_long_tail_equivocators": (dict(num_nodes=64, mean=10.0, variance=400.0, equivocate_every=5), 2, 300),
+    "n65_first_two_pass_list": (dict(num_nodes=65, mean=10.0, variance=100.0), 1, 250),
+    "n66": (dict(num_nodes=66), 1, 200),
+    "n100_weighted": (dict(num_nodes=100, voting_rights=[1 + (i % 4) for i in range(100)]), 1, 200),
+    "n128_max": (dict(num_nodes=128), 1, 120),
+    "n36_timeouts": (dict(num_nodes=36, mean=10.0, variance=900.0, delta=5), 2, 400),
+    "n64_q3_equivocators_live": (dict(num_nodes=64, mean=10.0, variance=400.0, equivocate_every=5, quirks=3), 2, 500),
+    "n100_q3_rotating_rights_epochs": (dict(num_nodes=100, voting_rights=[1 + (i % 4) for i in range(100)], quirks=3, rights_rotation=1,
+                                            commands_per_epoch=3), 1, 300),
+    "n36_q2_cpe3": (dict(num_nodes=36, commands_per_epoch=3, quirks=2), 2, 300),
+}
+
+
+@pytest.mark.parametrize("ring,topup", [(512, 0), (128, 0), (512, 4), (256, 16)])
+@pytest.mark.parametrize("name", sorted(COOP))
+def test_cooperative_event_loop_equals_oracle(oracle, name, ring, topup):
+    kw, m, max_clock = COOP[name]
+    cfg = oracle.make_config(math_mode=1, **kw)
+    n = kw["num_nodes"]
+    seeds = np.arange(7, 7 + m, dtype=np.uint64) * 31337
+    a = oracle.run_batch(cfg, seeds, max_clock, threads=8, history_cap=128)
+    b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=8, history_cap=128, qcap=max(4096, 8 * n * n),
+                                   scap=(n * n + 8 * n) if kw.get("quirks", 0) & 1 else 16 * n, bcap=512, lcap=512, ql=0, qheap=1, qcal=1,
+                                   ring=ring, ring_topup=topup)
+    assert not b["faults"].any()
+    for key in ("commit_counts", "active_rounds", "last_states", "histories"):
+        assert (a[key] == b[key]).all(), key
+    ca, cb = a["counters"], b["counters"]
+    for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
+        assert ca[key] == cb[key], key
+
+
+def test_cooperative_event_loop_small_capacities_fault_cleanly(oracle):
+    """Queue / snapshot overflow inside a bulk send raises the fault bit (no out-of-bounds slot, no hang)."""
+    kw = dict(num_nodes=40)
+    cfg = oracle.make_config(math_mode=1, **kw)
+    seeds = np.arange(1, 3, dtype=np.uint64)
+    b = oracle.hostmodel_run_batch(cfg, seeds, 200, threads=2, history_cap=8, qcap=300, scap=640, bcap=128, lcap=128, ql=0, qheap=1, qcal=1, ring=128)
+    assert (b["faults"] & 1).all()   # F_QUEUE_OVERFLOW
+    b = oracle.hostmodel_run_batch(cfg, seeds, 200, threads=2, history_cap=8, qcap=16 * 1600, scap=3, bcap=128, lcap=128, ql=0, qheap=1, qcal=1, ring=128)
+    assert (b["faults"] & 2).all()   # F_SNAP_OVERFLOW
+
+
 # qcal = 1: calendar event queue (one FIFO per (time, kind) bucket) instead of the binary heap
 @pytest.mark.parametrize("qcal", [0, 1])
 @pytest.mark.parametrize("name", sorted(LARGE))
