@@ -163,6 +163,8 @@ int lbft_batch_committed_histories(const lbft_batch* b, lbft_commit* out, size_t
 /* StateFinalizer::last_committed_state() (simulated_context.rs:194-196; State = SipHash-1-3 of the
  * history, :51-55), computed on the device: out[inst * num_nodes + node]. */
 int lbft_batch_last_committed_states(const lbft_batch* b, uint64_t* out);
+/* ... and of one node: contexts[node].last_committed_state() as librabft-v2/tests/simulated_run.rs:57-65 reads it. */
+int lbft_batch_last_committed_state(const lbft_batch* b, size_t inst, uint32_t node, uint64_t* out);
 /* SimulatedNode::startup_time (simulator.rs:55,217): out[inst * num_nodes + node]. */
 int lbft_batch_startup_times(const lbft_batch* b, int64_t* out);
 /* Current epoch of each node (librabft-v2/src/node.rs:34): out[inst * num_nodes + node]. */
@@ -249,9 +251,13 @@ int lbft_node_create_notification(lbft_batch* b, size_t inst, uint32_t node, uin
  * reference would return Some(Request). */
 int lbft_node_handle_notification(lbft_batch* b, size_t inst, uint32_t receiver, uint32_t sender, uint32_t handle, uint32_t* should_sync);
 int lbft_node_release_notification(lbft_batch* b, size_t inst, uint32_t handle);
-/* The other half of the DataSyncNode trait (interfaces.rs:54-86), for batches created with quirks bit 0 (the record-exchange
- * layout; LBFT_ERR_UNSUPPORTED otherwise).  Handles are snapshot slots like notification handles and are released with
- * lbft_node_release_notification.
+/* The other half of the DataSyncNode trait (interfaces.rs:54-86).  In batches created with quirks bit 0 (the record-exchange
+ * layout) requests and responses carry real payloads; handles are snapshot slots like notification handles and are released
+ * with lbft_node_release_notification.  In reference mode (quirks bit 0 clear) the calls follow the reference simulator, where
+ * a request is answered by the node that issued it (simulator.rs:446, quirk Q1): handles are payload-free tokens,
+ * lbft_node_handle_request must be called on the requester itself (LBFT_ERR_UNSUPPORTED on any other node: a peer's answer
+ * needs the payloads of quirks bit 0) and lbft_node_handle_response inserts nothing, exactly like data_sync.rs:209-240 over
+ * records the node already holds.
  *   create_request  (data_sync.rs:66-71,179-181): the requester's epoch and known_quorum_certificate_rounds (record_store.rs:766-799)
  *   handle_request  (data_sync.rs:183-207) on the node it was sent to: the records the requester lacks (unknown_records,
  *                   record_store.rs:801-831), for every epoch from the requester's to the node's own -> a response handle

@@ -507,6 +507,7 @@ struct SimT {
   u32 stamp, qlen, snap_free, nblocks, fault, maxq, maxsnap;
   u32 ev_stamp;   // creation stamp of the event being processed
   u32 cal_cursor, cal_free, cal_bump;  // calendar queue: first possibly non-empty bucket, height of the stack of freed slots, bump allocator
+  u32 sp_idx, sp_s1, sp_meta, sp_nx;   // calendar queue: the entry behind the last popped one, fetched ahead (sp_s1 = slot + 1, 0 = none); never stored
   u32 last_node;  // node of the previous event (round-switch trace)
   // round-switch trace: folded duplicate timers of time vd_time still "pop" in the reference until stamp vd_stamp
   u32 vd_time, vd_stamp;
@@ -534,7 +535,7 @@ struct SimT {
   LBFT_HD SimT(const Params& p, u32* state, u32 i) : SimT(p, reinterpret_cast<char*>(state) + tile_offset_bytes(p, i), (i & 63u) * 4u, 0) {}
   LBFT_HD SimT(const Params& p, char* tile_base, u32 lane_byte_offset, int) : P(p), tile(tile_base), lane4(lane_byte_offset), qk(nullptr), qm(nullptr), qstr(0), qsh(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab),
         leader_lds(nullptr), dur_lds(nullptr), leader_lds_len(0), dur_lds_len(0), hc(nullptr), plist_lds(nullptr) {
-    coop_on = false;
+    coop_on = false; cur_xk = 0; wtab = p.weights;
     if (RING) { rng.rtile = tile; rng.rbase = boff(P.off_ring); rng.rmask = P.ring ? P.ring - 1u : 0xffffffffu; rng.rhead = 0; rng.rcnt = 0; }
   }
   LBFT_HD void attach_queue(u64* keys, u32* metas, u32 stride, u32 slots) {
@@ -571,6 +572,8 @@ struct SimT {
   }
   LBFT_HD void attach_tables(const u64* zx, const u64* zf, const u64* et) { zig_x = zx; zig_f = zf; exp_tab = et; }
   LBFT_HD void attach_peer_list(u8* list) { plist_lds = list; }
+  const u32* wtab;  // voting rights (the device attaches an LDS copy: weight() sits inside the vote / timeout insertion loops)
+  LBFT_HD void attach_weights(const u32* w) { wtab = w; }
   LBFT_HD void attach_round_tables(const u8* leaders, u32 nl, const i64* durs, u32 nd) { leader_lds = leaders; leader_lds_len = nl; dur_lds = durs; dur_lds_len = nd; }
 
   LBFT_HD u32 boff(u32 w) const { return (w << 8) + lane4; }  // tile-relative byte offset of row w (a tile is < 4 GiB)
@@ -604,8 +607,11 @@ struct SimT {
 #endif
     for (u32 f = 0; f < NF_FIXED_WORDS; f++) cw[f] = ldf(nb, f);
     cdirty = 0;
+    ax_load(node);
+    cur_xk = wide() ? node >> 5 : 0u;
   }
   LBFT_HD void end_node(u32 node) const {
+    ax_store(node);
     u32 nb = boff(P.off_node + node * P.node_words);
 #if !defined(LBFT_END_NODE_PER_ROW)
     // rows are written back by groups of fields that change together: 6 tests instead of 41 (A/B on the 65536 x 4 batch in
@@ -651,6 +657,10 @@ struct SimT {
   // unrolling, so the records live in VGPRs.
   struct Blk {
     u32 w[BC_WORDS];
+    // n > 32: word xk (1..3) of the block's KNOWN / QC / PEND node sets, fetched together with the record for the node of the
+    // current event (begin_node: cur_xk = node >> 5) -- the mask tests and updates of insert_block / insert_qc /
+    // compute_state for nodes >= 32 then cost no memory round trip each.  xk = 0: not fetched (bm_* then go to memory).
+    u32 x[3], xk;
     LBFT_HD u32 round() const { return w[B_ROUND]; }
     LBFT_HD u32 prev() const { return w[B_LINK] & 0xffffu; }
     LBFT_HD u32 author() const { return w[B_LINK] >> 16; }
@@ -694,9 +704,15 @@ struct SimT {
     }
     bc_next = bc_next + 1 == LBFT_BLK_CACHE ? 0 : bc_next + 1;
   }
+  mutable u32 cur_xk;  // extension word of the node sets that the current event's node lives in (0: node < 32 or n <= 32)
   LBFT_HD Blk blk_get(u32 b) const {  // b != 0
     Blk r;
     bool hit = false;
+    r.xk = wide() ? cur_xk : 0u;
+    r.x[0] = r.x[1] = r.x[2] = 0;
+    if (r.xk) {  // (issued before the cache lookup: overlaps with the record's own burst on a miss)
+      r.x[0] = ld(bxw(b, B_KNOWN, r.xk)); r.x[1] = ld(bxw(b, B_QC, r.xk)); r.x[2] = ld(bxw(b, B_PEND, r.xk));
+    }
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -736,14 +752,17 @@ struct SimT {
   LBFT_HD u32 bxw(u32 b, u32 f, u32 k) const { return bfw(b, B_WORDS + (f - B_KNOWN) * (P.mw - 1) + k - 1); }
   LBFT_HD bool bm_test(u32 b, const Blk& rb, u32 f, u32 node) const {
     if (!wide() || node < 32) return (rb.w[f] >> node) & 1u;
+    if (rb.xk == (node >> 5)) return (rb.x[f - B_KNOWN] >> (node & 31u)) & 1u;
     return (ld(bxw(b, f, node >> 5)) >> (node & 31u)) & 1u;
   }
   LBFT_HD void bm_set(u32 b, Blk& rb, u32 f, u32 node) const {
     if (!wide() || node < 32) { rb.w[f] |= 1u << node; blk_put(b, f, rb.w[f]); }
+    else if (rb.xk == (node >> 5)) { rb.x[f - B_KNOWN] |= 1u << (node & 31u); st(bxw(b, f, node >> 5), rb.x[f - B_KNOWN]); }
     else { u32 w = bxw(b, f, node >> 5); st(w, ld(w) | (1u << (node & 31u))); }
   }
   LBFT_HD void bm_clr(u32 b, Blk& rb, u32 f, u32 node) const {
     if (!wide() || node < 32) { rb.w[f] &= ~(1u << node); blk_put(b, f, rb.w[f]); }
+    else if (rb.xk == (node >> 5)) { rb.x[f - B_KNOWN] &= ~(1u << (node & 31u)); st(bxw(b, f, node >> 5), rb.x[f - B_KNOWN]); }
     else { u32 w = bxw(b, f, node >> 5); st(w, ld(w) & ~(1u << (node & 31u))); }
   }
   // Write-through update of one mask word of block b (f is B_KNOWN, B_QC or B_PEND).
@@ -775,6 +794,7 @@ struct SimT {
     last_node = ld(I_LAST_NODE); vd_time = ld(I_VD_TIME); vd_stamp = ld(I_VD_STAMP);
     cal_cursor = ld(I_CAL_CURSOR); cal_free = ld(I_CAL_FREE); cal_bump = ld(I_CAL_BUMP);
     n_fold = ld(I_NFOLD); n_upd = ld(I_NUPD);
+    sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0;
     if (RING) { rng.rhead = ld(I_RING_HEAD); rng.rcnt = ld(I_RING_CNT); }
     blk_cache_reset();
   }
@@ -896,7 +916,7 @@ struct SimT {
       else s1 = ++cal_bump;                   // bounded by the qlen < qcap check above
       st(P.off_qmeta + s1 - 1, meta);
       st(P.off_qhi + s1 - 1, 0);              // next
-      if (tl) st(P.off_qhi + tl - 1, s1);
+      if (tl) { st(P.off_qhi + tl - 1, s1); if (tl == sp_s1) sp_nx = s1; }  // (the entry pop_event fetched ahead got a successor)
       else {
         st(P.off_cal_head + idx, s1);
         u32 bw = P.off_cal_bm + (idx >> 5);
@@ -927,17 +947,35 @@ struct SimT {
     if (qlen == 0) return false;
     LBFT_STAT(48 + (qlen > 56 ? 7 : qlen / 8));
     if (cal()) {  // first non-empty bucket at or after the cursor, head of its FIFO
-      u32 w = cal_cursor >> 5;
-      u32 raw = ld(P.off_cal_bm + w);
-      u32 bits = raw & (~0u << (cal_cursor & 31u));
-      while (!bits) { w++; raw = ld(P.off_cal_bm + w); bits = raw; }
-      u32 idx = w * 32u + ctz32(bits);
-      cal_cursor = idx;
-      u32 s1 = ld(P.off_cal_head + idx);
-      meta = ld(P.off_qmeta + s1 - 1);
-      u32 nx = ld(P.off_qhi + s1 - 1);
+      // A bucket usually holds many events (all notifications of one time unit), so the previous pop already fetched the
+      // (meta, next) words of this bucket's next entry (sp_*): unless a push lowered the cursor since, that entry is the one
+      // to pop -- no bitmap word, no head row, no entry fetch: the three dependent round trips of a pop are gone.
+      u32 idx, s1, nx, w = 0, raw = 0;
+      bool have_raw = false;
+      if (sp_s1 != 0 && cal_cursor == sp_idx) {
+        idx = sp_idx; s1 = sp_s1; meta = sp_meta; nx = sp_nx;
+      } else {
+        w = cal_cursor >> 5;
+        raw = ld(P.off_cal_bm + w);
+        u32 bits = raw & (~0u << (cal_cursor & 31u));
+        while (!bits) { w++; raw = ld(P.off_cal_bm + w); bits = raw; }
+        have_raw = true;
+        idx = w * 32u + ctz32(bits);
+        cal_cursor = idx;
+        s1 = ld(P.off_cal_head + idx);
+        meta = ld(P.off_qmeta + s1 - 1);
+        nx = ld(P.off_qhi + s1 - 1);
+      }
       st(P.off_cal_head + idx, nx);
-      if (!nx) { st(P.off_cal_tail + idx, 0); st(P.off_cal_bm + w, raw & ~(1u << (idx & 31u))); }
+      if (!nx) {
+        if (!have_raw) { w = idx >> 5; raw = ld(P.off_cal_bm + w); }
+        st(P.off_cal_tail + idx, 0); st(P.off_cal_bm + w, raw & ~(1u << (idx & 31u)));
+        sp_s1 = 0;
+      } else {  // fetch the entry behind this one now; a later append to it is patched in by push_event / coop_bulk
+        sp_idx = idx; sp_s1 = nx;
+        sp_meta = ld(P.off_qmeta + nx - 1);
+        sp_nx = ld(P.off_qhi + nx - 1);
+      }
       st(P.off_qlo + cal_free++, s1);         // stack of freed slots
       time = (i32)(idx >> 2);
       kind = 3u - (idx & 3u);
@@ -1087,7 +1125,7 @@ struct SimT {
   LBFT_HD u32 weight(u32 node, u32 author) const {  // vector load from a small table
     if (P.unit_weights) return 1u;
     u32 i = author + rights_shift(node);
-    return P.weights[i >= P.n ? i - P.n : i];
+    return wtab[i >= P.n ? i - P.n : i];
   }
 
   // ---- leader / duration ----
@@ -1137,23 +1175,79 @@ struct SimT {
   // the cached fixed rows, authors >= 32 (n > 32 only) in extension rows behind the hcbr buffers ----
   LBFT_HD u32 am_idx(u32 f) const { return f == NF_TC_MASK ? 0u : f == NF_TO_MASK ? 1u : f == NF_BAL0_AUTHORS ? 2u : 3u; }
   LBFT_HD u32 amxw(u32 node, u32 f, u32 k) const { return nfw(node, NF_FIXED_WORDS + 2 * P.n + am_idx(f) * (P.mw - 1) + k - 1); }
-  LBFT_HD u32 am_word(u32 node, u32 f, u32 k) const { return k == 0 ? nf(node, f) : ld(amxw(node, f, k)); }
-  LBFT_HD void am_set_word(u32 node, u32 f, u32 k, u32 v) const { if (k == 0) nfs(node, f, v); else st(amxw(node, f, k), v); }
+  // Words 1..3 of the four sets are staged in registers with the fixed rows (begin_node / end_node): a read-modify-write of
+  // an extension row would otherwise be one dependent memory round trip per author >= 32 in every vote / timeout insertion
+  // (64-node networks: half of all authors).  Indices are kept compile-time after unrolling (value selects, not dynamically
+  // indexed stores) so that ax[][] lives in registers.
+  mutable u32 ax[4][3];
+  mutable u32 axdirty;  // bit (set * 3 + word - 1)
+  LBFT_HD void ax_load(u32 node) const {
+    axdirty = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 i = 0; i < 4; i++) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 k = 0; k < 3; k++) ax[i][k] = (wide() && k + 1 < P.mw) ? ld(nfw(node, NF_FIXED_WORDS + 2 * P.n + i * (P.mw - 1) + k)) : 0u;
+    }
+  }
+  LBFT_HD void ax_store(u32 node) const {
+    if (!wide() || !axdirty) return;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 i = 0; i < 4; i++) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 k = 0; k < 3; k++)
+        if ((axdirty >> (i * 3 + k)) & 1u) st(nfw(node, NF_FIXED_WORDS + 2 * P.n + i * (P.mw - 1) + k), ax[i][k]);
+    }
+  }
+  LBFT_HD u32 ax_get(u32 i, u32 k) const {  // k = 1..3
+    u32 v = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 ii = 0; ii < 4; ii++) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 kk = 0; kk < 3; kk++) v = (ii == i && kk + 1 == k) ? ax[ii][kk] : v;
+    }
+    return v;
+  }
+  LBFT_HD void ax_put(u32 i, u32 k, u32 v) const {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 ii = 0; ii < 4; ii++) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 kk = 0; kk < 3; kk++) ax[ii][kk] = (ii == i && kk + 1 == k) ? v : ax[ii][kk];
+    }
+    axdirty |= 1u << (i * 3 + k - 1);
+  }
+  LBFT_HD u32 am_word(u32 node, u32 f, u32 k) const { return k == 0 ? nf(node, f) : ax_get(am_idx(f), k); }
+  LBFT_HD void am_set_word(u32 node, u32 f, u32 k, u32 v) const { if (k == 0) nfs(node, f, v); else ax_put(am_idx(f), k, v); }
   LBFT_HD bool am_test(u32 node, u32 f, u32 a) const {
     if (!wide() || a < 32) return (nf(node, f) >> a) & 1u;
-    return (ld(amxw(node, f, a >> 5)) >> (a & 31u)) & 1u;
+    return (ax_get(am_idx(f), a >> 5) >> (a & 31u)) & 1u;
   }
   LBFT_HD void am_set(u32 node, u32 f, u32 a) const {
     if (!wide() || a < 32) nfs(node, f, nf(node, f) | (1u << a));
-    else { u32 w = amxw(node, f, a >> 5); st(w, ld(w) | (1u << (a & 31u))); }
+    else ax_put(am_idx(f), a >> 5, ax_get(am_idx(f), a >> 5) | (1u << (a & 31u)));
   }
   LBFT_HD void am_clear(u32 node, u32 f) const {
     nfs(node, f, 0);
-    for (u32 k = 1; wide() && k < P.mw; k++) st(amxw(node, f, k), 0);
+    for (u32 k = 1; wide() && k < P.mw; k++) ax_put(am_idx(f), k, 0);
   }
   LBFT_HD void am_copy(u32 node, u32 dst, u32 src) const {
     nfs(node, dst, nf(node, src));
-    for (u32 k = 1; wide() && k < P.mw; k++) st(amxw(node, dst, k), ld(amxw(node, src, k)));
+    for (u32 k = 1; wide() && k < P.mw; k++) ax_put(am_idx(dst), k, ax_get(am_idx(src), k));
   }
 
   // ---- RecordStoreState ----
@@ -1262,19 +1356,23 @@ struct SimT {
   // The timeouts of a notification (data_sync.rs:150-163), in author order; the hcbr words of up to four
   // authors are fetched in one burst before they are inserted.
   LBFT_HD void insert_timeouts(u32 node, u32 slot, u32 first_word, u32 mask, u32 round, u32 author0 = 0) const {
+    // an author whose timeout the node already holds is rejected without side effects (record_store.rs:390-415) and inserting
+    // one author never changes that for another: only the new ones are fetched
+    mask &= ~am_word(node, NF_TO_MASK, author0 >> 5);
+    constexpr u32 TB = BIG ? 8 : 4;  // hcbr words in flight per round trip
     while (mask) {
-      u32 a[4], h[4], k = 0;
+      u32 a[TB], h[TB], k = 0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (u32 j = 0; j < 4; j++) {
+      for (u32 j = 0; j < TB; j++) {
         a[j] = 0; h[j] = 0;
         if (mask) { a[j] = author0 + ctz32(mask); mask &= mask - 1; h[j] = ld(sfw(slot, first_word + a[j])); k = j + 1; }
       }
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (u32 j = 0; j < 4; j++)
+      for (u32 j = 0; j < TB; j++)
         if (j < k) insert_timeout(node, a[j], round, h[j]);
     }
   }
@@ -1292,6 +1390,7 @@ struct SimT {
     u32 b = ++nblocks;
     u32 base = prev_blk ? prev_blk : nf(node, NF_INIT_STATE_BLK);
     Blk rb;
+    rb.xk = wide() ? cur_xk : 0u; rb.x[0] = rb.x[1] = rb.x[2] = 0;  // a new block: nobody knows it yet
     rb.w[B_ROUND] = nf(node, NF_CUR_ROUND);
     rb.w[B_LINK] = prev_blk | (node << 16);
     rb.w[B_PREV_ROUND] = 0; rb.w[B_PP] = 0; rb.w[B_PP_ROUND] = 0; rb.w[B_DEPTH] = 1;
@@ -1440,6 +1539,7 @@ struct SimT {
 #pragma unroll
 #endif
     for (u32 f = 0; f < BC_WORDS; f++) r0.w[f] = 0;
+    r0.xk = 0; r0.x[0] = r0.x[1] = r0.x[2] = 0;
     {  // an old block that nothing else will look at again: straight from its row, not through the cache
       u32 sb = boff(bfw(start, 0));
       r0.w[B_LINK] = ldf(sb, B_LINK); r0.w[B_PREV_ROUND] = ldf(sb, B_PREV_ROUND);
@@ -1630,6 +1730,7 @@ struct SimT {
     KnownCursor q1q = known_start(filter ? k_hqc : 0), q1c = known_start(filter ? k_hcc : 0), q2q = q1q, q2c = q1c;
     Blk r1, r2;
     for (u32 f = 0; f < BC_WORDS; f++) { r1.w[f] = 0; r2.w[f] = 0; }
+    r1.xk = r2.xk = 0; r1.x[0] = r1.x[1] = r1.x[2] = 0; r2.x[0] = r2.x[1] = r2.x[2] = 0;
     bool fresh1 = true, fresh2 = true;  // x1 / x2 moved to a block that has not been looked at yet
     for (;;) {  // util.rs merge_sort of the two chains by descending round, identical certificates once
       if (x1 && fresh1) { r1 = blk_get(x1); fresh1 = false; if (filter && (known_at(q1q, r1.round()) || known_at(q1c, r1.round()))) x1 = 0; }
@@ -2292,6 +2393,7 @@ struct SimT {
       }
     }
     if (is_k) {
+      if (sp_s1) sp_nx = ld(P.off_qhi + sp_s1 - 1);  // the entry pop_event fetched ahead may have got a successor from another lane
       stamp += cnt;
       if (stamp >= (1u << 30)) fault |= F_STAMP_OVERFLOW;
       if (which == 0) {
@@ -2361,6 +2463,7 @@ struct SimT {
     for (u32 w = 0; w < I_WORDS; w++) st(w, 0);
     clock = 0; stamp = 0; qlen = 0; nblocks = 0; fault = 0; maxq = 0; maxsnap = 0;
     ev0 = ev1 = ev2 = ev3 = 0; n_fold = 0; n_upd = 0;
+    sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0;
     blk_cache_reset();
     snap_free = P.scap;
     snap_mask = P.scap >= 64 ? ~0ULL : ((1ULL << P.scap) - 1);

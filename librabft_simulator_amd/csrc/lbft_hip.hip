@@ -58,7 +58,8 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restr
 #endif
 #define LBFT_LDS_LEADERS 1024  // rounds of the leader table kept in LDS (bytes)
 #define LBFT_LDS_DURS 128      // entries of the duration table kept in LDS (i64)
-#define LBFT_TABLE_U64 (257 + 257 + 256 + LBFT_LDS_DURS + LBFT_LDS_LEADERS / 8)
+#define LBFT_LDS_WEIGHTS LBFT_MAX_NODES  // voting rights (u32)
+#define LBFT_TABLE_U64 (257 + 257 + 256 + LBFT_LDS_DURS + LBFT_LDS_LEADERS / 8 + LBFT_LDS_WEIGHTS / 2)
 
 // [tables][queue keys][queue metas][diagnostics: LBFT_NPHASES u64 per wavefront][n > 16: one 128-byte receiver list per instance]
 // `slot_bytes`: 12 (key + meta) or 8 (packed one-word entries, kernel class 0)
@@ -89,6 +90,8 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
   u32 n_leader = p.leader_len < LBFT_LDS_LEADERS ? p.leader_len : LBFT_LDS_LEADERS;
   for (u32 t = threadIdx.x; t < n_dur; t += LBFT_RUN_BLOCK) t_dur[t] = p.dur_tab[t];
   for (u32 t = threadIdx.x; t < n_leader; t += LBFT_RUN_BLOCK) t_leader[t] = p.leader_tab[t];
+  u32* t_weights = reinterpret_cast<u32*>(lds + 770 + LBFT_LDS_DURS + LBFT_LDS_LEADERS / 8);
+  for (u32 t = threadIdx.x; t < p.n; t += LBFT_RUN_BLOCK) t_weights[t] = p.weights[t];
   __syncthreads();
   u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   u64* keys = lds + LBFT_TABLE_U64 + (size_t)wave * p.ql * p.lpw + lane;
@@ -111,6 +114,7 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
     s.attach_queue(keys, metas, p.lpw, p.ql);
     s.attach_tables(t_zx, t_zf, t_et);
     s.attach_round_tables(t_leader, n_leader, t_dur, n_dur);
+    s.attach_weights(t_weights);
     if (lead) {
       u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 12u);
       s.attach_peer_list(lists + ((size_t)wave * p.lpw + lane) * LBFT_MAX_NODES);
@@ -143,6 +147,7 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
       s.attach_queue(keys, metas, p.lpw, p.ql);
       s.attach_tables(t_zx, t_zf, t_et);
       s.attach_round_tables(t_leader, n_leader, t_dur, n_dur);
+      s.attach_weights(t_weights);
       if (p.n > 16) {  // receiver / sender lists of process_node_actions: LDS instead of HBM rows
         u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, CLS == 0 ? 8u : 12u);
         s.attach_peer_list(lists + ((size_t)wave * p.lpw + lane) * LBFT_MAX_NODES);
@@ -394,6 +399,7 @@ __global__ void lbft_k_exp_log(const u64* __restrict__ exp_tab, const double* __
 // Host side of the C ABI
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
+static bool lean_allowed() { const char* e = getenv("LBFT_NO_LEAN"); return !(e && atoi(e)); }  // tuning knob: 1 = always the full-register kernels
 
 static int hip_fail(hipError_t e, const char* what) {
   g_err = std::string(what) + ": " + hipGetErrorString(e);
@@ -671,41 +677,61 @@ int lbft_node_handle_notification(lbft_batch* b, size_t inst, uint32_t receiver,
   if (should_sync) *should_sync = (uint32_t)h[0];
   return LBFT_OK;
 }
-// The request / response half of DataSyncNode needs the record-exchange layout of quirks bit 0 (request words in the
-// snapshot slots, archive of retired record stores).
-static int need_exchange_layout(const lbft_batch* b) {
-  if (b && !(b->p.quirks & 1u)) { g_err = "node-level requests / responses need a batch created with quirks bit 0"; return LBFT_ERR_UNSUPPORTED; }
-  return LBFT_OK;
-}
+// The request / response half of DataSyncNode.  Batches created with quirks bit 0 hold real payloads (request words in the
+// snapshot slots, archive of retired record stores).  Without it the batch follows the reference simulator, where a request
+// is answered by the node that issued it (simulator.rs:446, quirk Q1): such a response can only name records the node
+// already holds, so it inserts nothing (the oracle asserts response_inserts == 0 in every quirks-0 run) and the calls
+// exchange payload-free TOKENS: 0xffff0000 | requester for a request, 0xfffe0000 | requester for its response.
+#define LBFT_TOKEN_REQUEST 0xffff0000u
+#define LBFT_TOKEN_RESPONSE 0xfffe0000u
+static bool exchange_layout(const lbft_batch* b) { return b && (b->p.quirks & 1u); }
 int lbft_node_create_request(lbft_batch* b, size_t inst, uint32_t node, uint32_t* handle) {
   if (!handle) return LBFT_ERR_INVALID;
-  int rc = need_exchange_layout(b);
-  if (rc != LBFT_OK) return rc;
+  if (!exchange_layout(b)) {
+    if (!b || inst >= b->m || node >= b->p.n) return LBFT_ERR_INVALID;
+    if (!b->manual) { g_err = "lbft_batch_manual_begin first"; return LBFT_ERR_STATE; }
+    *handle = LBFT_TOKEN_REQUEST | node;
+    return LBFT_OK;
+  }
   unsigned long long h[1];
-  rc = node_op(b, OP_CREATE_REQUEST, inst, node, 0, 0, 0, h, 1);
+  int rc = node_op(b, OP_CREATE_REQUEST, inst, node, 0, 0, 0, h, 1);
   if (rc != LBFT_OK) return rc;
   if ((long long)h[0] < 0) { g_err = "no free snapshot slot (snapshot_capacity)"; return LBFT_ERR_FAULT; }
   *handle = (uint32_t)h[0];
   return LBFT_OK;
 }
 int lbft_node_handle_request(lbft_batch* b, size_t inst, uint32_t node, uint32_t request, uint32_t* response) {
-  if (!response || (b && request >= b->p.scap)) return LBFT_ERR_INVALID;
-  int rc = need_exchange_layout(b);
-  if (rc != LBFT_OK) return rc;
+  if (!response) return LBFT_ERR_INVALID;
+  if (!exchange_layout(b)) {
+    if (!b || inst >= b->m || node >= b->p.n || (request & 0xffff0000u) != LBFT_TOKEN_REQUEST) return LBFT_ERR_INVALID;
+    if (!b->manual) { g_err = "lbft_batch_manual_begin first"; return LBFT_ERR_STATE; }
+    if ((request & 0xffffu) != node) {
+      g_err = "reference mode (quirks bit 0 clear): a request is answered by its own requester (simulator.rs:446); create the batch with quirks bit 0 for peer-answered requests";
+      return LBFT_ERR_UNSUPPORTED;
+    }
+    *response = LBFT_TOKEN_RESPONSE | node;
+    return LBFT_OK;
+  }
+  if (request >= b->p.scap) return LBFT_ERR_INVALID;
   unsigned long long h[1];
-  rc = node_op(b, OP_HANDLE_REQUEST, inst, node, 0, request, 0, h, 1);
+  int rc = node_op(b, OP_HANDLE_REQUEST, inst, node, 0, request, 0, h, 1);
   if (rc != LBFT_OK) return rc;
   if ((long long)h[0] < 0) { g_err = "no free snapshot slot (snapshot_capacity)"; return LBFT_ERR_FAULT; }
   *response = (uint32_t)h[0];
   return LBFT_OK;
 }
 int lbft_node_handle_response(lbft_batch* b, size_t inst, uint32_t node, uint32_t peer, uint32_t response, int64_t node_time) {
-  if (b && (peer >= b->p.n || response >= b->p.scap)) return LBFT_ERR_INVALID;
-  int rc = need_exchange_layout(b);
-  if (rc != LBFT_OK) return rc;
+  if (!exchange_layout(b)) {
+    if (!b || inst >= b->m || node >= b->p.n || peer >= b->p.n || (response & 0xffff0000u) != LBFT_TOKEN_RESPONSE) return LBFT_ERR_INVALID;
+    if (!b->manual) { g_err = "lbft_batch_manual_begin first"; return LBFT_ERR_STATE; }
+    if ((response & 0xffffu) != node) { g_err = "reference mode: the response to a self-answered request goes back to its requester"; return LBFT_ERR_INVALID; }
+    return LBFT_OK;  // data_sync.rs:209-240 over records the node already holds: every insertion is rejected as a duplicate
+  }
+  if (peer >= b->p.n || response >= b->p.scap) return LBFT_ERR_INVALID;
   return node_op(b, OP_HANDLE_RESPONSE, inst, node, peer, response, node_time, nullptr, 0);
 }
 int lbft_node_release_notification(lbft_batch* b, size_t inst, uint32_t handle) {
+  if (b && !exchange_layout(b) && (handle & 0xfffe0000u) == 0xfffe0000u) return LBFT_OK;  // payload-free request / response token
   if (b && handle >= b->p.scap) return LBFT_ERR_INVALID;
   return node_op(b, OP_RELEASE_NOTIFICATION, inst, 0, 0, handle, 0, nullptr, 0);
 }
@@ -793,7 +819,7 @@ int lbft_batch_layout(const lbft_batch* b, uint32_t* out) {
   out[4] = p.total_words * 4; // HBM bytes per instance
   out[5] = p.ql;              // event-queue slots per instance resident in LDS
   out[6] = p.lpw;             // lanes per wavefront carrying an instance
-  out[7] = (uint32_t)sim_class(p) | (p.qheap << 8) | (p.qcal << 9) | (((sim_lean(p) || sim_lean1(p)) ? 1u : 0u) << 10);
+  out[7] = (uint32_t)sim_class(p) | (p.qheap << 8) | (p.qcal << 9) | ((((sim_lean(p) || sim_lean1(p)) && lean_allowed()) ? 1u : 0u) << 10) | ((p.ring ? 1u : 0u) << 11);
   return LBFT_OK;
 }
 
@@ -902,7 +928,7 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
     // wavefront-step costs the union of its lanes' paths (65536 x 4 nodes, r01_s3 build: 27.0 ms at 64 lanes = one wavefront
     // per SIMD, 24.4 ms at 32 = two per SIMD, 40.1 ms at 16 = two rounds; 1024 x 4 nodes: 22.9 ms at 8 lanes, 17.6 at 4,
     // 13.2 at 2, 9.4 ms at ONE network per wavefront; 8192 x 100 nodes: 9.0 s at 16 lanes, 5.9 s at 8, 7.8 s at 4 = two rounds).
-    u64 resident = (sim_class(p) == 0 || sim_lean(p) || sim_lean1(p)) ? 2048 : 1024 * LBFT_BIG_WAVES_PER_SIMD;
+    u64 resident = (sim_class(p) == 0 || ((sim_lean(p) || sim_lean1(p)) && lean_allowed())) ? 2048 : 1024 * LBFT_BIG_WAVES_PER_SIMD;
     u64 want = (b->m + resident - 1) / resident;
     lpw = 1;
     while (lpw < want && lpw < 32) lpw <<= 1;
@@ -961,7 +987,7 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
 static int launch_run(lbft_batch* b) {
   Params& p = b->p;
   int cls = sim_class(p);
-  bool lean = sim_lean(p), lean1 = sim_lean1(p);
+  bool lean = sim_lean(p) && lean_allowed(), lean1 = sim_lean1(p) && lean_allowed();
   const void* run_fn = lean ? reinterpret_cast<const void*>(lbft_k_run2l) : lean1 ? reinterpret_cast<const void*>(lbft_k_run1l) : cls == 0 ? reinterpret_cast<const void*>(lbft_k_run0)
                      : cls == 1 ? reinterpret_cast<const void*>(lbft_k_run<1>) : reinterpret_cast<const void*>(lbft_k_run<2>);
   HIP_TRY(hipFuncSetAttribute(run_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
@@ -1137,6 +1163,15 @@ int lbft_batch_last_committed_states(const lbft_batch* b, uint64_t* out) {
   if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
   HIP_TRY(hipSetDevice(b->device));
   HIP_TRY(hipMemcpy(out, b->d_states_out, b->m * b->p.n * sizeof(u64), hipMemcpyDeviceToHost));
+  return LBFT_OK;
+}
+
+// StateFinalizer::last_committed_state() of one node (simulated_context.rs:51-55,194-196)
+int lbft_batch_last_committed_state(const lbft_batch* b, size_t inst, uint32_t node, uint64_t* out) {
+  if (!b || !out || inst >= b->m || node >= b->p.n) return LBFT_ERR_INVALID;
+  if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
+  HIP_TRY(hipSetDevice(b->device));
+  HIP_TRY(hipMemcpy(out, b->d_states_out + inst * b->p.n + node, sizeof(u64), hipMemcpyDeviceToHost));
   return LBFT_OK;
 }
 

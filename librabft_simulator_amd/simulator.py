@@ -227,7 +227,9 @@ class SimulatedContextView:
         return [(Command(int(e["proposer"]), int(e["index"])), int(e["time"])) for e in h]
 
     def last_committed_state(self):
-        return State(int(self._r.last_committed_states[self._i, self._n]))
+        out = C.c_uint64()
+        check(_lib.lib().lbft_batch_last_committed_state(self._r._sim._h, self._i, self._n, C.byref(out)))
+        return State(int(out.value))
 
 
 class BatchSimulator:

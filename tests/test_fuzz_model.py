@@ -72,6 +72,40 @@ def test_random_configurations_match_the_oracle(oracle, chunk):
                 assert (got[:, 2] == ref["qc_hash"]).all() and ((got[:, 3] >> 32) == 0).all() and ref["has_qc"].all(), kw
 
 
+@pytest.mark.parametrize("chunk", range(8))
+def test_random_large_configurations_on_the_cooperative_loop(oracle, chunk):
+    """The same generator for networks of 33..128 nodes, run through the cooperative event loop of the large-network kernels
+    (run_coop / coop_bulk on 64 emulated lanes): ring sizes, top-up rates, two-pass receiver lists (n > 65), equivocators,
+    partitions, all quirk modes.  (Random message loss keeps the lane-per-network loop: coop() excludes it.)"""
+    rng = np.random.default_rng(90210 + chunk)
+    for _ in range(5):
+        kw = draw_config(rng)
+        n = int(rng.choice([33, 36, 40, 48, 64, 65, 66, 80, 100, 128]))
+        kw["num_nodes"] = n
+        for k in ("voting_rights", "equivocate_every", "partition_size", "partition_start", "partition_end", "rights_rotation"):
+            kw.pop(k, None)
+        if rng.random() < 0.4:
+            kw["voting_rights"] = [int(v) for v in rng.integers(1, 6, n)]
+            if "commands_per_epoch" in kw and rng.random() < 0.6:
+                kw["rights_rotation"] = int(rng.integers(1, n))
+        if rng.random() < 0.4:
+            kw["equivocate_every"] = int(rng.integers(2, 9))
+        if rng.random() < 0.5:
+            kw.pop("drop_per_million", None)
+        max_clock = int(rng.choice([120, 200, 260])) if n <= 66 else 130
+        seeds = rng.integers(1, 2 ** 62, 1, dtype=np.uint64)
+        cfg = oracle.make_config(math_mode=1, **kw)
+        a = oracle.run_batch(cfg, seeds, max_clock, threads=4, history_cap=64)
+        b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=4, history_cap=64, qcap=max(8192, 32 * n * n),
+                                       scap=min(65535, 6 * n * n + 16 * n) if kw.get("quirks", 0) & 1 else 128 * n, bcap=512, lcap=512, ql=0, qheap=1, qcal=1,
+                                       ring=int(rng.choice([128, 256, 512])), ring_topup=int(rng.choice([0, 4, 16])))
+        assert not b["faults"].any(), (kw, b["faults"])
+        for key in ("commit_counts", "active_rounds", "last_states", "histories"):
+            assert (a[key] == b[key]).all(), (key, kw)
+        for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
+            assert a["counters"][key] == b["counters"][key], (key, kw)
+
+
 # LBFT_FUZZ_GPU_CHUNKS=n widens the device run (10 configurations per chunk; the default keeps `pytest -m gpu` short)
 @pytest.mark.gpu
 @pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_CHUNKS", "5"))))

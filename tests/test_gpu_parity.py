@@ -405,17 +405,15 @@ def test_full_size_config4_live_16384x64_equivocators_commit(amd, oracle):
 def test_full_size_config5_live_8192x100_rotating_rights_epochs(amd, oracle):
     """Configuration 5 exercising what it is named for, at full size: 8 192 x 100 nodes, voting rights 1 + (i mod 4) rotating
     by one node per epoch (rights_rotation = 1), an epoch every 3 commands, the fixed protocol mode (quirks = 3), clock
-    400: every instance goes through >= 2 epoch changes (node.rs:331-348).  256 instances bit-exact against the oracle."""
-    m, n, max_clock = 8192, 100, 400
+    450: every node of every instance goes through >= 2 epoch changes (node.rs:331-348).  256 instances bit-exact against the oracle."""
+    m, n, max_clock = 8192, 100, 450
     rights = [1 + (i % 4) for i in range(n)]
     kw = dict(num_nodes=n, voting_rights=rights, commands_per_epoch=3, quirks=3, rights_rotation=1)
     seeds = np.arange(1, m + 1, dtype=np.uint64)
     _, res = run_gpu(amd, kw, seeds, max_clock)
     assert not res.faults.any()
     cc, ep = res.commit_counts, res.epochs
-    assert (ep.max(axis=1) >= 2).all()                       # >= 2 reconfigurations in every instance ...
-    assert (ep.min(axis=1) >= 2).mean() >= 0.95              # ... at every one of its nodes in nearly all of them
-    assert (ep.min(axis=1) >= 1).all()
+    assert (ep >= 2).all()                                   # >= 2 reconfigurations at every node of every instance
     assert (ep == cc // 3).all()                             # read_epoch_id = commands / commands_per_epoch (simulated_context.rs:199-207)
     hist = res.committed_histories(int(cc.max()))
     assert _prefix_consistent(cc, hist)                      # logs agree across the epochs

@@ -273,3 +273,30 @@ def test_device_node_level_equals_oracle(oracle, name):
     res = dev.sim.manual_finalize()
     assert res.commit_counts[0].sum() == 0
     assert [int(c) for c in res.commit_counts[1]] == [dev.view(i)["commit_count"] for i in range(n)]
+
+
+@pytest.mark.gpu
+def test_device_request_response_in_reference_mode_are_self_answered_and_insert_nothing(oracle):
+    """quirks bit 0 clear = the reference simulator's routing (simulator.rs:441-466, quirk Q1): the whole DataSyncNode trait is
+    callable; a request is answered by its own requester and the response changes nothing -- on the device and in the oracle."""
+    import librabft_simulator_amd as amd
+    n = 4
+    dev, ora = DeviceDriver(amd, n), OracleDriver(oracle, n)
+    for d in (dev, ora):
+        trace = []
+        for clock in range(0, 120):
+            full_exchange(d, clock, trace, members=[0, 1, 2])
+    before = [dev.view(i) for i in range(n)]
+    assert before == [ora.view(i) for i in range(n)] and before[0]["highest_quorum_certificate_round"] >= 2
+    for node in (0, 3):  # an up-to-date node and the one that heard nothing
+        req = dev.request(node)
+        resp = dev.respond(node, req)          # self-answered
+        dev.absorb(node, resp, 120)
+        oreq = ora.request(node)
+        ora.absorb(node, ora.respond(node, oreq), 120)
+        assert dev.view(node) == before[node] == ora.view(node)
+        dev.release(req); dev.release(resp)
+    req = dev.request(3)
+    with pytest.raises(amd.LbftError) as e:    # a peer's answer needs the payloads of quirks bit 0
+        dev.respond(0, req)
+    assert e.value.code == -3

@@ -29,9 +29,9 @@ CONFIGS = {
     # its first epoch change.  The "live" variants exercise what the configurations are named for, at full size, in the fixed
     # protocol mode (quirks = 3: requests answered by the peer, EpochId::previous() = id - 1):
     #   c4live: 13 of 64 nodes equivocating under LogNormal(10, 400) delays -- every node of every instance commits >= 20 blocks by clock 1000;
-    #   c5live: weighted voting rights rotating by one node per epoch, an epoch every 3 commands -- >= 2 epoch changes per node by clock 400.
+    #   c5live: weighted voting rights rotating by one node per epoch, an epoch every 3 commands -- >= 2 epoch changes per node by clock 450.
     "c4live_16384x64_longtail_equivocators_fixed": dict(instances=16384, nodes=64, max_clock=1000, variance=400.0, equivocate_every=5, quirks=3),
-    "c5live_8192x100_rotating_rights_epochs_fixed": dict(instances=8192, nodes=100, max_clock=400, weights=[1 + (i % 4) for i in range(100)],
+    "c5live_8192x100_rotating_rights_epochs_fixed": dict(instances=8192, nodes=100, max_clock=450, weights=[1 + (i % 4) for i in range(100)],
                                                          commands_per_epoch=3, quirks=3, rights_rotation=1),
 }
 HBM_PEAK_GBS = 8000.0
