@@ -39,6 +39,16 @@ typedef int32_t i32;
 typedef uint64_t u64;
 typedef int64_t i64;
 
+// Tuning switches of the large-network classes (each measured on the MI355X):
+#ifndef LBFT_AX
+#define LBFT_AX 1    // author-set extension words staged in registers with the node's fixed rows
+#endif
+#ifndef LBFT_BX
+#define LBFT_BX 1    // a block's node-set extension words fetched once per record copy (lazily, three words in one round trip)
+#endif
+#ifndef LBFT_SPEC
+#define LBFT_SPEC 1  // calendar queue: the entry behind the popped one is fetched ahead
+#endif
 #define LBFT_MAX_NODES 128  // node / author sets are 1..4 32-bit words (word 0 in the hot rows, the rest in extension rows)
 
 // Sticky per-instance fault bits (readable after the run; never abort the process).
@@ -62,7 +72,9 @@ enum Fault : u32 {
 struct Params {
   u32 n;       // nodes per instance
   u32 m;       // instances in this batch (on this GPU)
-  u32 stride;  // row stride in words (m padded to a multiple of 64)
+  u32 stride;  // instances the state array holds (m padded to a multiple of 64)
+  u32 tw;      // tile width: instances whose rows are word-interleaved (64 for kernel class 0; the lanes per wavefront otherwise)
+  u32 rsh;     // log2 of a row's bytes = log2(4 * tw)
   u32 qcap, scap, bcap, lcap;
   i32 max_clock;
   u32 delay_model;  // 0 LogNormal, 1 uniform integer
@@ -143,13 +155,17 @@ extern unsigned long long lbft_host_stats[64];
 #define LBFT_STATN(k, n) do { } while (0)
 #endif
 
-// HBM layout: instances are grouped in tiles of 64 (one wavefront's worth); a tile is contiguous and holds
-// its rows word-interleaved: word w of instance i lives at byte (i / 64) * total_words * 256 + w * 256 +
-// (i % 64) * 4.  A wavefront's 64 lanes read row w as one 256-byte segment, and everything a wavefront ever
-// touches sits in one contiguous ~1 MB window (TLB- and DRAM-page-friendly).  Inside the run kernel the
-// tile base is wavefront-uniform (an SGPR pair) and a row access is `tile + u32 byte offset`, i.e. the
-// saddr + 32-bit voffset form of global_load/global_store: no 64-bit vector address arithmetic.
-#define LBFT_ROW_BYTES 256u
+// HBM layout: instances are grouped in tiles of `tw` (the instances one wavefront advances); a tile is contiguous and holds
+// its rows word-interleaved: word w of instance i lives at byte (i / tw) * total_words * 4 tw + w * 4 tw + (i % tw) * 4.
+// The lanes of a wavefront read row w as one contiguous segment, consecutive rows are adjacent, and everything a wavefront
+// ever touches sits in one contiguous window (TLB- and DRAM-page-friendly).  Kernel class 0 (the headline small-network
+// path) uses tw = 64 at compile time (two 32-lane wavefronts of a workgroup share a tile: 256-byte rows).  The other
+// classes run few networks per wavefront (8 or 16 lanes of 64-node networks, down to one), and there a 64-wide tile
+// would make every word access fetch a 128-byte line of which 16-64 bytes are used and spread a 41-word node burst over 41
+// lines: with tw = lanes per wavefront the same burst is 41 * 4 tw contiguous bytes, fully used.
+// Inside the run kernel the tile base is wavefront-uniform (an SGPR pair) and a row access is `tile + u32 byte offset`,
+// i.e. the saddr + 32-bit voffset form of global_load/global_store: no 64-bit vector address arithmetic.
+#define LBFT_ROW_BYTES 256u  // kernel class 0 (tw = 64)
 
 // Instance-level rows.
 enum InstField : u32 {
@@ -259,6 +275,7 @@ struct RngT {
   u32 rbase;         // byte offset of the ring's first row in this lane's column (boff(off_ring))
   u32 rhead, rcnt;   // draws [rhead, rhead + rcnt) are in the ring (indices taken modulo rmask + 1)
   u32 rmask;         // entries - 1 (a power of two); 0xffffffff = no ring attached
+  u32 rrsh;          // log2 of a row's bytes in this batch's layout
   LBFT_HD void seed(u64 seed) {  // seed_from_u64: four SplitMix64 outputs
     u64 x = seed, z;
     x += 0x9e3779b97f4a7c15ULL; z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; s0 = z ^ (z >> 31);
@@ -276,10 +293,10 @@ struct RngT {
     s3 = rotl64(s3, 45);
     return r;
   }
-  LBFT_HD u32 ring_off(u32 e) const { return rbase + ((e & rmask) << 9); }  // two rows (512 bytes) per entry
+  LBFT_HD u32 ring_off(u32 e) const { return rbase + ((e & rmask) << (rrsh + 1)); }  // two rows per entry
   LBFT_HD u64 ring_at(u32 e) const {
     u32 o = ring_off(e);
-    return (u64)*reinterpret_cast<const u32*>(rtile + (size_t)o) | ((u64)*reinterpret_cast<const u32*>(rtile + (size_t)o + LBFT_ROW_BYTES) << 32);
+    return (u64)*reinterpret_cast<const u32*>(rtile + (size_t)o) | ((u64)*reinterpret_cast<const u32*>(rtile + (size_t)o + (1u << rrsh)) << 32);
   }
   // generator runs ahead: `g` more draws appended to the ring (the caller bounds g by the free room)
   LBFT_HD void ring_fill(u32 g) {
@@ -287,7 +304,7 @@ struct RngT {
       u64 v = step();
       u32 o = ring_off(rhead + rcnt);
       *reinterpret_cast<u32*>(rtile + (size_t)o) = (u32)v;
-      *reinterpret_cast<u32*>(rtile + (size_t)o + LBFT_ROW_BYTES) = (u32)(v >> 32);
+      *reinterpret_cast<u32*>(rtile + (size_t)o + (1u << rrsh)) = (u32)(v >> 32);
       rcnt++;
     }
   }
@@ -424,9 +441,9 @@ LBFT_HD u32 compute_leader(const u32* weights, u32 n, u32 total_votes, u64 round
 }
 
 // Byte offset of instance i's tile / word offset of a word of instance i in the state array.
-LBFT_HD size_t tile_offset_bytes(const Params& p, u32 i) { return (size_t)(i >> 6) * p.total_words * LBFT_ROW_BYTES; }
+LBFT_HD size_t tile_offset_bytes(const Params& p, u32 i) { return (size_t)(i / p.tw) * p.total_words * ((size_t)4 * p.tw); }
 LBFT_HD size_t state_words(const Params& p) { return (size_t)p.total_words * p.stride; }  // stride = m padded to 64
-LBFT_HD size_t word_offset(const Params& p, u32 i, u32 w) { return tile_offset_bytes(p, i) / 4 + (size_t)w * 64u + (i & 63u); }
+LBFT_HD size_t word_offset(const Params& p, u32 i, u32 w) { return tile_offset_bytes(p, i) / 4 + (size_t)w * p.tw + (i & (p.tw - 1u)); }
 
 // ---- lanes of a wavefront cooperating on ONE network (SimT::coop_bulk) -------------------------------------------------
 // The cooperative code is written once over "per-lane values": on the device a PL<T> is a register of the executing lane
@@ -488,6 +505,9 @@ struct SimT {
   static constexpr bool LEAN = CLS == 5 || CLS == 6;  // 6 = class 1 without those three (13 spilled registers at 256)
   // Large networks: the lanes of a wavefront cooperate on one network's broadcasts (coop_bulk); every class that may meet such a
   // batch's state (the generic class 3 reads back / steps any batch) honours its ring of pre-generated draws.
+  // 64-wide tiles addressed at compile time for the small-network classes (many lanes per wavefront); the large-network
+  // classes address tiles of P.tw = lanes per wavefront (lbft_core.h "HBM layout")
+  static constexpr bool TILE64 = CLS == 0 || CLS == 1 || CLS == 6;
   static constexpr bool COOP = BIG;
   static constexpr bool RING = BIG || CLS == 3;
   bool coop_on;  // set by run_coop: the event loop is being run by a whole wavefront
@@ -532,11 +552,11 @@ struct SimT {
   u64* wprof;  // this wavefront's LDS accumulators
 #endif
 
-  LBFT_HD SimT(const Params& p, u32* state, u32 i) : SimT(p, reinterpret_cast<char*>(state) + tile_offset_bytes(p, i), (i & 63u) * 4u, 0) {}
+  LBFT_HD SimT(const Params& p, u32* state, u32 i) : SimT(p, reinterpret_cast<char*>(state) + tile_offset_bytes(p, i), (i & (p.tw - 1u)) * 4u, 0) {}
   LBFT_HD SimT(const Params& p, char* tile_base, u32 lane_byte_offset, int) : P(p), tile(tile_base), lane4(lane_byte_offset), qk(nullptr), qm(nullptr), qstr(0), qsh(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab),
         leader_lds(nullptr), dur_lds(nullptr), leader_lds_len(0), dur_lds_len(0), hc(nullptr), plist_lds(nullptr) {
     coop_on = false; cur_xk = 0; wtab = p.weights;
-    if (RING) { rng.rtile = tile; rng.rbase = boff(P.off_ring); rng.rmask = P.ring ? P.ring - 1u : 0xffffffffu; rng.rhead = 0; rng.rcnt = 0; }
+    if (RING) { rng.rtile = tile; rng.rrsh = rsh(); rng.rbase = boff(P.off_ring); rng.rmask = P.ring ? P.ring - 1u : 0xffffffffu; rng.rhead = 0; rng.rcnt = 0; }
   }
   LBFT_HD void attach_queue(u64* keys, u32* metas, u32 stride, u32 slots) {
     qk = keys; qm = metas; qstr = stride; ql = qpacked() ? (slots & ~7u) : slots;  // packed entries are scanned in batches of 8
@@ -576,12 +596,23 @@ struct SimT {
   LBFT_HD void attach_weights(const u32* w) { wtab = w; }
   LBFT_HD void attach_round_tables(const u8* leaders, u32 nl, const i64* durs, u32 nd) { leader_lds = leaders; leader_lds_len = nl; dur_lds = durs; dur_lds_len = nd; }
 
-  LBFT_HD u32 boff(u32 w) const { return (w << 8) + lane4; }  // tile-relative byte offset of row w (a tile is < 4 GiB)
+  LBFT_HD u32 rsh() const { return TILE64 ? 8u : P.rsh; }  // log2(row bytes)
+  // (a multiplication, not `w << P.rsh`: hipcc 7.2 dies on the variable shift in this address pattern -- "Illegal instruction
+  // detected: V_CMP_NE_U32 0, $src_shared_base" --; rows and row bytes are below 2^24, a plain 32-bit multiply is what compiles)
+  LBFT_HD static u32 mul24(u32 a, u32 b) { return a * b; }  // (__umul24 trips the same compiler bug)
+  LBFT_HD u32 rowb() const { return TILE64 ? 256u : 4u * P.tw; }  // bytes of a row
+  LBFT_HD u32 boff(u32 w) const { return TILE64 ? (w << 8) + lane4 : mul24(w, rowb()) + lane4; }  // tile-relative byte offset of row w (a tile is < 4 GiB)
   LBFT_HD u32 ld(u32 w) const { return *reinterpret_cast<const u32*>(tile + (size_t)boff(w)); }
   LBFT_HD void st(u32 w, u32 v) const { *reinterpret_cast<u32*>(tile + (size_t)boff(w)) = v; }
   // row (w0 + f) given boff(w0): groups of 16 rows share one 32-bit base, the rest is the instruction's immediate
-  LBFT_HD u32 ldf(u32 base, u32 f) const { return *reinterpret_cast<const u32*>(tile + (size_t)(base + (f & ~15u) * LBFT_ROW_BYTES) + (f & 15u) * LBFT_ROW_BYTES); }
-  LBFT_HD void stf(u32 base, u32 f, u32 v) const { *reinterpret_cast<u32*>(tile + (size_t)(base + (f & ~15u) * LBFT_ROW_BYTES) + (f & 15u) * LBFT_ROW_BYTES) = v; }
+  LBFT_HD u32 ldf(u32 base, u32 f) const {
+    if (TILE64) return *reinterpret_cast<const u32*>(tile + (size_t)(base + (f & ~15u) * LBFT_ROW_BYTES) + (f & 15u) * LBFT_ROW_BYTES);
+    return *reinterpret_cast<const u32*>(tile + (size_t)(base + mul24(f, rowb())));
+  }
+  LBFT_HD void stf(u32 base, u32 f, u32 v) const {
+    if (TILE64) *reinterpret_cast<u32*>(tile + (size_t)(base + (f & ~15u) * LBFT_ROW_BYTES) + (f & 15u) * LBFT_ROW_BYTES) = v;
+    else *reinterpret_cast<u32*>(tile + (size_t)(base + mul24(f, rowb()))) = v;
+  }
 
   // ---- field accessors ----
   LBFT_HD u32 nfw(u32 node, u32 f) const { return P.off_node + node * P.node_words + f; }
@@ -608,7 +639,6 @@ struct SimT {
     for (u32 f = 0; f < NF_FIXED_WORDS; f++) cw[f] = ldf(nb, f);
     cdirty = 0;
     ax_load(node);
-    cur_xk = wide() ? node >> 5 : 0u;
   }
   LBFT_HD void end_node(u32 node) const {
     ax_store(node);
@@ -660,7 +690,7 @@ struct SimT {
     // n > 32: word xk (1..3) of the block's KNOWN / QC / PEND node sets, fetched together with the record for the node of the
     // current event (begin_node: cur_xk = node >> 5) -- the mask tests and updates of insert_block / insert_qc /
     // compute_state for nodes >= 32 then cost no memory round trip each.  xk = 0: not fetched (bm_* then go to memory).
-    u32 x[3], xk;
+    mutable u32 x[3], xk;
     LBFT_HD u32 round() const { return w[B_ROUND]; }
     LBFT_HD u32 prev() const { return w[B_LINK] & 0xffffu; }
     LBFT_HD u32 author() const { return w[B_LINK] >> 16; }
@@ -708,11 +738,7 @@ struct SimT {
   LBFT_HD Blk blk_get(u32 b) const {  // b != 0
     Blk r;
     bool hit = false;
-    r.xk = wide() ? cur_xk : 0u;
-    r.x[0] = r.x[1] = r.x[2] = 0;
-    if (r.xk) {  // (issued before the cache lookup: overlaps with the record's own burst on a miss)
-      r.x[0] = ld(bxw(b, B_KNOWN, r.xk)); r.x[1] = ld(bxw(b, B_QC, r.xk)); r.x[2] = ld(bxw(b, B_PEND, r.xk));
-    }
+    r.xk = 0; r.x[0] = r.x[1] = r.x[2] = 0;  // (node-set extension words: fetched by the first bm_* operation that needs them)
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -750,20 +776,40 @@ struct SimT {
   // Node sets of a block (B_KNOWN / B_QC / B_PEND): nodes 0..31 live in the hot record, nodes >= 32 (n > 32
   // only) in extension rows behind the cold fields.
   LBFT_HD u32 bxw(u32 b, u32 f, u32 k) const { return bfw(b, B_WORDS + (f - B_KNOWN) * (P.mw - 1) + k - 1); }
+  // (one round trip for the three words of this record copy instead of one per test / update)
+  LBFT_HD void bx_fetch(u32 b, const Blk& rb, u32 k) const {
+    if (rb.xk == k) return;
+    rb.x[0] = ld(bxw(b, B_KNOWN, k)); rb.x[1] = ld(bxw(b, B_QC, k)); rb.x[2] = ld(bxw(b, B_PEND, k));
+    rb.xk = k;
+  }
   LBFT_HD bool bm_test(u32 b, const Blk& rb, u32 f, u32 node) const {
     if (!wide() || node < 32) return (rb.w[f] >> node) & 1u;
-    if (rb.xk == (node >> 5)) return (rb.x[f - B_KNOWN] >> (node & 31u)) & 1u;
+#if LBFT_BX
+    bx_fetch(b, rb, node >> 5);
+    return (rb.x[f - B_KNOWN] >> (node & 31u)) & 1u;
+#else
     return (ld(bxw(b, f, node >> 5)) >> (node & 31u)) & 1u;
+#endif
   }
   LBFT_HD void bm_set(u32 b, Blk& rb, u32 f, u32 node) const {
-    if (!wide() || node < 32) { rb.w[f] |= 1u << node; blk_put(b, f, rb.w[f]); }
-    else if (rb.xk == (node >> 5)) { rb.x[f - B_KNOWN] |= 1u << (node & 31u); st(bxw(b, f, node >> 5), rb.x[f - B_KNOWN]); }
-    else { u32 w = bxw(b, f, node >> 5); st(w, ld(w) | (1u << (node & 31u))); }
+    if (!wide() || node < 32) { rb.w[f] |= 1u << node; blk_put(b, f, rb.w[f]); return; }
+#if LBFT_BX
+    bx_fetch(b, rb, node >> 5);
+    rb.x[f - B_KNOWN] |= 1u << (node & 31u);
+    st(bxw(b, f, node >> 5), rb.x[f - B_KNOWN]);
+#else
+    { u32 w = bxw(b, f, node >> 5); st(w, ld(w) | (1u << (node & 31u))); }
+#endif
   }
   LBFT_HD void bm_clr(u32 b, Blk& rb, u32 f, u32 node) const {
-    if (!wide() || node < 32) { rb.w[f] &= ~(1u << node); blk_put(b, f, rb.w[f]); }
-    else if (rb.xk == (node >> 5)) { rb.x[f - B_KNOWN] &= ~(1u << (node & 31u)); st(bxw(b, f, node >> 5), rb.x[f - B_KNOWN]); }
-    else { u32 w = bxw(b, f, node >> 5); st(w, ld(w) & ~(1u << (node & 31u))); }
+    if (!wide() || node < 32) { rb.w[f] &= ~(1u << node); blk_put(b, f, rb.w[f]); return; }
+#if LBFT_BX
+    bx_fetch(b, rb, node >> 5);
+    rb.x[f - B_KNOWN] &= ~(1u << (node & 31u));
+    st(bxw(b, f, node >> 5), rb.x[f - B_KNOWN]);
+#else
+    { u32 w = bxw(b, f, node >> 5); st(w, ld(w) & ~(1u << (node & 31u))); }
+#endif
   }
   // Write-through update of one mask word of block b (f is B_KNOWN, B_QC or B_PEND).
   LBFT_HD void blk_put(u32 b, u32 f, u32 v) const {
@@ -916,7 +962,7 @@ struct SimT {
       else s1 = ++cal_bump;                   // bounded by the qlen < qcap check above
       st(P.off_qmeta + s1 - 1, meta);
       st(P.off_qhi + s1 - 1, 0);              // next
-      if (tl) { st(P.off_qhi + tl - 1, s1); if (tl == sp_s1) sp_nx = s1; }  // (the entry pop_event fetched ahead got a successor)
+      if (tl) { st(P.off_qhi + tl - 1, s1); if (LBFT_SPEC && tl == sp_s1) sp_nx = s1; }  // (the entry pop_event fetched ahead got a successor)
       else {
         st(P.off_cal_head + idx, s1);
         u32 bw = P.off_cal_bm + (idx >> 5);
@@ -952,7 +998,7 @@ struct SimT {
       // to pop -- no bitmap word, no head row, no entry fetch: the three dependent round trips of a pop are gone.
       u32 idx, s1, nx, w = 0, raw = 0;
       bool have_raw = false;
-      if (sp_s1 != 0 && cal_cursor == sp_idx) {
+      if (LBFT_SPEC && sp_s1 != 0 && cal_cursor == sp_idx) {
         idx = sp_idx; s1 = sp_s1; meta = sp_meta; nx = sp_nx;
       } else {
         w = cal_cursor >> 5;
@@ -971,7 +1017,7 @@ struct SimT {
         if (!have_raw) { w = idx >> 5; raw = ld(P.off_cal_bm + w); }
         st(P.off_cal_tail + idx, 0); st(P.off_cal_bm + w, raw & ~(1u << (idx & 31u)));
         sp_s1 = 0;
-      } else {  // fetch the entry behind this one now; a later append to it is patched in by push_event / coop_bulk
+      } else if (LBFT_SPEC) {  // fetch the entry behind this one now; a later append to it is patched in by push_event / coop_bulk
         sp_idx = idx; sp_s1 = nx;
         sp_meta = ld(P.off_qmeta + nx - 1);
         sp_nx = ld(P.off_qhi + nx - 1);
@@ -1183,6 +1229,9 @@ struct SimT {
   mutable u32 axdirty;  // bit (set * 3 + word - 1)
   LBFT_HD void ax_load(u32 node) const {
     axdirty = 0;
+#if LBFT_AX
+    if (!wide()) return;
+    u32 base = nfw(node, NF_FIXED_WORDS + 2 * P.n);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -1190,11 +1239,16 @@ struct SimT {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (u32 k = 0; k < 3; k++) ax[i][k] = (wide() && k + 1 < P.mw) ? ld(nfw(node, NF_FIXED_WORDS + 2 * P.n + i * (P.mw - 1) + k)) : 0u;
+      for (u32 k = 0; k < 3; k++) {  // (unconditional loads of a clamped row, then a select: one burst with the fixed rows)
+        u32 kk = k + 1 < P.mw ? k : 0;
+        u32 v = ld(base + i * (P.mw - 1) + kk);
+        ax[i][k] = k + 1 < P.mw ? v : 0u;
+      }
     }
+#endif
   }
   LBFT_HD void ax_store(u32 node) const {
-    if (!wide() || !axdirty) return;
+    if (!LBFT_AX || !wide() || !axdirty) return;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -1231,6 +1285,7 @@ struct SimT {
     }
     axdirty |= 1u << (i * 3 + k - 1);
   }
+#if LBFT_AX
   LBFT_HD u32 am_word(u32 node, u32 f, u32 k) const { return k == 0 ? nf(node, f) : ax_get(am_idx(f), k); }
   LBFT_HD void am_set_word(u32 node, u32 f, u32 k, u32 v) const { if (k == 0) nfs(node, f, v); else ax_put(am_idx(f), k, v); }
   LBFT_HD bool am_test(u32 node, u32 f, u32 a) const {
@@ -1249,6 +1304,26 @@ struct SimT {
     nfs(node, dst, nf(node, src));
     for (u32 k = 1; wide() && k < P.mw; k++) ax_put(am_idx(dst), k, ax_get(am_idx(src), k));
   }
+#else
+  LBFT_HD u32 am_word(u32 node, u32 f, u32 k) const { return k == 0 ? nf(node, f) : ld(amxw(node, f, k)); }
+  LBFT_HD void am_set_word(u32 node, u32 f, u32 k, u32 v) const { if (k == 0) nfs(node, f, v); else st(amxw(node, f, k), v); }
+  LBFT_HD bool am_test(u32 node, u32 f, u32 a) const {
+    if (!wide() || a < 32) return (nf(node, f) >> a) & 1u;
+    return (ld(amxw(node, f, a >> 5)) >> (a & 31u)) & 1u;
+  }
+  LBFT_HD void am_set(u32 node, u32 f, u32 a) const {
+    if (!wide() || a < 32) nfs(node, f, nf(node, f) | (1u << a));
+    else { u32 w = amxw(node, f, a >> 5); st(w, ld(w) | (1u << (a & 31u))); }
+  }
+  LBFT_HD void am_clear(u32 node, u32 f) const {
+    nfs(node, f, 0);
+    for (u32 k = 1; wide() && k < P.mw; k++) st(amxw(node, f, k), 0);
+  }
+  LBFT_HD void am_copy(u32 node, u32 dst, u32 src) const {
+    nfs(node, dst, nf(node, src));
+    for (u32 k = 1; wide() && k < P.mw; k++) st(amxw(node, dst, k), ld(amxw(node, src, k)));
+  }
+#endif
 
   // ---- RecordStoreState ----
   LBFT_HD void clear_ballot(u32 node) const {
@@ -1390,7 +1465,7 @@ struct SimT {
     u32 b = ++nblocks;
     u32 base = prev_blk ? prev_blk : nf(node, NF_INIT_STATE_BLK);
     Blk rb;
-    rb.xk = wide() ? cur_xk : 0u; rb.x[0] = rb.x[1] = rb.x[2] = 0;  // a new block: nobody knows it yet
+    rb.xk = 0; rb.x[0] = rb.x[1] = rb.x[2] = 0;
     rb.w[B_ROUND] = nf(node, NF_CUR_ROUND);
     rb.w[B_LINK] = prev_blk | (node << 16);
     rb.w[B_PREV_ROUND] = 0; rb.w[B_PP] = 0; rb.w[B_PP_ROUND] = 0; rb.w[B_DEPTH] = 1;
@@ -2151,8 +2226,8 @@ struct SimT {
   //     bucket instead of one memory round trip per message.
   u32 bulk;       // leader lane: bit 0 = a broadcast is pending, bit 1 = a query-all is pending (set by send_loop)
   u32 bulk_node;  // leader lane: the node whose actions are being processed
-  LBFT_HD u32 ldc(u32 l4, u32 w) const { return *reinterpret_cast<const u32*>(tile + (size_t)((w << 8) + l4)); }
-  LBFT_HD void stc(u32 l4, u32 w, u32 v) const { *reinterpret_cast<u32*>(tile + (size_t)((w << 8) + l4)) = v; }
+  LBFT_HD u32 ldc(u32 l4, u32 w) const { return *reinterpret_cast<const u32*>(tile + (size_t)(mul24(w, rowb()) + l4)); }
+  LBFT_HD void stc(u32 l4, u32 w, u32 v) const { *reinterpret_cast<u32*>(tile + (size_t)(mul24(w, rowb()) + l4)) = v; }
   // the first try of sample_delay() on the draw `bits`: true = accepted (then d is the delay sample_delay() returns)
   LBFT_HD bool fast_delay(u64 bits, i64& d) const {
     if (P.delay_model == 1) {
@@ -2393,7 +2468,7 @@ struct SimT {
       }
     }
     if (is_k) {
-      if (sp_s1) sp_nx = ld(P.off_qhi + sp_s1 - 1);  // the entry pop_event fetched ahead may have got a successor from another lane
+      if (LBFT_SPEC && sp_s1) sp_nx = ld(P.off_qhi + sp_s1 - 1);  // the entry pop_event fetched ahead may have got a successor from another lane
       stamp += cnt;
       if (stamp >= (1u << 30)) fault |= F_STAMP_OVERFLOW;
       if (which == 0) {
@@ -2688,7 +2763,7 @@ inline bool sim_lean(const Params& p) { return sim_class(p) == 2 && sim_lean_fea
 inline bool sim_lean1(const Params& p) { return sim_class(p) == 1 && sim_lean_features(p); }
 
 // Row layout for a batch; fills the offset fields of `p` and returns words per instance.  Accumulated in 64 bits: a tile is
-// addressed with 32-bit byte offsets (boff(): row << 8), so a layout is only usable while it stays below 2^24 rows; the
+// addressed with 32-bit byte offsets (boff(): row << rsh, at most 8), so a layout is only usable while it stays below 2^24 rows; the
 // caller rejects larger ones (layout_fits) instead of letting row offsets wrap.
 inline u64 compute_layout(Params& p) {
   u64 w = I_WORDS;

@@ -103,12 +103,14 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
   bool done = true;
   // lpw divides 64, so a wavefront's instances share one tile: its base is wavefront-uniform (SGPRs) and
   // every row access is saddr + 32-bit voffset
-  u32 tile_idx = __builtin_amdgcn_readfirstlane(((blockIdx.x * LBFT_RUN_WAVES + wave) * p.lpw) >> 6);
-  char* tile = reinterpret_cast<char*>(state) + (size_t)tile_idx * p.total_words * LBFT_ROW_BYTES;
+  // (tile width tw: 64 for the small-network classes -- two 32-lane wavefronts share a tile --, otherwise tw == lpw: one tile per wavefront)
+  const u32 tw = SimT<CLS>::TILE64 ? 64u : p.tw;
+  u32 tile_idx = __builtin_amdgcn_readfirstlane(((blockIdx.x * LBFT_RUN_WAVES + wave) * p.lpw) / tw);
+  char* tile = reinterpret_cast<char*>(state) + (size_t)tile_idx * p.total_words * ((size_t)4 * tw);
   if constexpr (SimT<CLS>::COOP) {
     // Large networks: EVERY lane of the wavefront runs the event loop; the first lpw lanes carry a network each, all 64
     // cooperate on the bulk sends of those networks (SimT::run_coop / coop_bulk).
-    SimT<CLS> s(p, tile, ((active ? i : lane) & 63u) * 4u, 0);
+    SimT<CLS> s(p, tile, ((active ? i : lane) & (tw - 1u)) * 4u, 0);
     bool lead = false;
     if (active) lead = s.ld(I_DONE) == 0;
     s.attach_queue(keys, metas, p.lpw, p.ql);
@@ -142,7 +144,7 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
 #endif
   } else
   if (active) {
-    SimT<CLS> s(p, tile, (i & 63u) * 4u, 0);
+    SimT<CLS> s(p, tile, (i & (tw - 1u)) * 4u, 0);
     if (s.ld(I_DONE) == 0) {
       s.attach_queue(keys, metas, p.lpw, p.ql);
       s.attach_tables(t_zx, t_zf, t_et);
@@ -399,7 +401,11 @@ __global__ void lbft_k_exp_log(const u64* __restrict__ exp_tab, const double* __
 // Host side of the C ABI
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
-static bool lean_allowed() { const char* e = getenv("LBFT_NO_LEAN"); return !(e && atoi(e)); }  // tuning knob: 1 = always the full-register kernels
+// Tuning knobs: LBFT_NO_LEAN=1 = always the full-register kernels; LBFT_LEAN2=1 = the two-wavefronts-per-SIMD kernel for
+// large networks as well (round 1's choice; since the register-staged node sets and the narrow tiles of round 2 the
+// full-register kernel with twice the lanes is as fast or faster: 16384 x 64 nodes 584 vs 633 ms, 8192 x 100 nodes 3.09 vs 3.42 s)
+static bool lean_allowed() { const char* e = getenv("LBFT_NO_LEAN"); return !(e && atoi(e)); }
+static bool lean2_allowed() { const char* e = getenv("LBFT_LEAN2"); return lean_allowed() && e && atoi(e); }
 
 static int hip_fail(hipError_t e, const char* what) {
   g_err = std::string(what) + ": " + hipGetErrorString(e);
@@ -465,6 +471,7 @@ static int fill_params(const lbft_config* cfg, size_t m, Params& p, std::vector<
   p.n = cfg->num_nodes;
   p.m = (u32)m;
   p.stride = (u32)((m + 63) / 64 * 64);
+  p.tw = 64; p.rsh = 8;
   p.delay_model = cfg->delay_model;
   // RandomDelay::new (simulator.rs:99-106), computed once on the host with the host libm like the reference
   p.mu = std::log(cfg->mean / std::sqrt(1.0 + cfg->variance / (cfg->mean * cfg->mean)));
@@ -767,9 +774,9 @@ int lbft_batch_round_switches(const lbft_batch* b, size_t inst, int64_t* out, si
   u32 words = p.n * p.rcap + p.n;
   std::vector<u32> h(words + 3);
   // strided rows of one instance: word w lives at word_offset(p, inst, w); copy as a 2-D memcpy (4 bytes x words, pitch 256)
-  HIP_TRY(hipMemcpy2D(h.data(), sizeof(u32), b->d_state + word_offset(p, (u32)inst, p.off_trace), LBFT_ROW_BYTES, sizeof(u32), words,
+  HIP_TRY(hipMemcpy2D(h.data(), sizeof(u32), b->d_state + word_offset(p, (u32)inst, p.off_trace), (size_t)4 * p.tw, sizeof(u32), words,
                       hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy2D(h.data() + words, sizeof(u32), b->d_state + word_offset(p, (u32)inst, I_EV0), LBFT_ROW_BYTES, sizeof(u32), 3,
+  HIP_TRY(hipMemcpy2D(h.data() + words, sizeof(u32), b->d_state + word_offset(p, (u32)inst, I_EV0), (size_t)4 * p.tw, sizeof(u32), 3,
                       hipMemcpyDeviceToHost));
   u32 mr = 0;
   for (u32 k = 0; k < p.n; k++) mr = h[p.n * p.rcap + k] > mr ? h[p.n * p.rcap + k] : mr;
@@ -819,7 +826,7 @@ int lbft_batch_layout(const lbft_batch* b, uint32_t* out) {
   out[4] = p.total_words * 4; // HBM bytes per instance
   out[5] = p.ql;              // event-queue slots per instance resident in LDS
   out[6] = p.lpw;             // lanes per wavefront carrying an instance
-  out[7] = (uint32_t)sim_class(p) | (p.qheap << 8) | (p.qcal << 9) | ((((sim_lean(p) || sim_lean1(p)) && lean_allowed()) ? 1u : 0u) << 10) | ((p.ring ? 1u : 0u) << 11);
+  out[7] = (uint32_t)sim_class(p) | (p.qheap << 8) | (p.qcal << 9) | ((((sim_lean(p) && lean2_allowed()) || (sim_lean1(p) && lean_allowed())) ? 1u : 0u) << 10) | ((p.ring ? 1u : 0u) << 11);
   return LBFT_OK;
 }
 
@@ -838,9 +845,9 @@ static int zero_calendar(lbft_batch* b) {
   const Params& p = b->p;
   if (!p.qcal) return LBFT_OK;
   size_t rows = (size_t)p.off_snap - p.off_cal_head;  // head, tail, bitmap
-  size_t tiles = p.stride / 64;
-  HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(b->d_state) + (size_t)p.off_cal_head * LBFT_ROW_BYTES, (size_t)p.total_words * LBFT_ROW_BYTES, 0,
-                           rows * LBFT_ROW_BYTES, tiles, b->stream));
+  size_t tiles = p.stride / p.tw, row_bytes = (size_t)4 * p.tw;
+  HIP_TRY(hipMemset2DAsync(reinterpret_cast<char*>(b->d_state) + (size_t)p.off_cal_head * row_bytes, (size_t)p.total_words * row_bytes, 0,
+                           rows * row_bytes, tiles, b->stream));
   return LBFT_OK;
 }
 
@@ -928,12 +935,21 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
     // wavefront-step costs the union of its lanes' paths (65536 x 4 nodes, r01_s3 build: 27.0 ms at 64 lanes = one wavefront
     // per SIMD, 24.4 ms at 32 = two per SIMD, 40.1 ms at 16 = two rounds; 1024 x 4 nodes: 22.9 ms at 8 lanes, 17.6 at 4,
     // 13.2 at 2, 9.4 ms at ONE network per wavefront; 8192 x 100 nodes: 9.0 s at 16 lanes, 5.9 s at 8, 7.8 s at 4 = two rounds).
-    u64 resident = (sim_class(p) == 0 || ((sim_lean(p) || sim_lean1(p)) && lean_allowed())) ? 2048 : 1024 * LBFT_BIG_WAVES_PER_SIMD;
+    u64 resident = (sim_class(p) == 0 || (sim_lean(p) && lean2_allowed()) || (sim_lean1(p) && lean_allowed())) ? 2048 : 1024 * LBFT_BIG_WAVES_PER_SIMD;
     u64 want = (b->m + resident - 1) / resident;
     lpw = 1;
     while (lpw < want && lpw < 32) lpw <<= 1;
   }
   p.lpw = lpw;
+  // Tile width of the HBM layout (lbft_core.h "HBM layout"): 64 for the small-network classes 0 and 1, the lanes per wavefront for large networks
+  // (LBFT_TILE64=1: 64 everywhere, the round-1 layout, for A/B measurements)
+  {
+    u32 tw = sim_class(p) <= 1 ? 64u : lpw;
+    if (const char* e = getenv("LBFT_TILE64")) if (atoi(e)) tw = 64;
+    p.tw = tw;
+    p.rsh = 2;
+    while ((4u << (p.rsh - 2)) < 4u * tw) p.rsh++;
+  }
   // LDS queue slots per instance: what one CU's LDS affords when it hosts 64/lpw workgroups
   u32 wg_per_cu = (64 / lpw) * 4 / LBFT_RUN_WAVES;  // workgroups of LBFT_RUN_WAVES wavefronts that make up a CU's 256 instances
   if (wg_per_cu < 1) wg_per_cu = 1;
@@ -987,7 +1003,7 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
 static int launch_run(lbft_batch* b) {
   Params& p = b->p;
   int cls = sim_class(p);
-  bool lean = sim_lean(p) && lean_allowed(), lean1 = sim_lean1(p) && lean_allowed();
+  bool lean = sim_lean(p) && lean2_allowed(), lean1 = sim_lean1(p) && lean_allowed();
   const void* run_fn = lean ? reinterpret_cast<const void*>(lbft_k_run2l) : lean1 ? reinterpret_cast<const void*>(lbft_k_run1l) : cls == 0 ? reinterpret_cast<const void*>(lbft_k_run0)
                      : cls == 1 ? reinterpret_cast<const void*>(lbft_k_run<1>) : reinterpret_cast<const void*>(lbft_k_run<2>);
   HIP_TRY(hipFuncSetAttribute(run_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
@@ -1043,7 +1059,7 @@ struct CheckpointHeader {
   u32 n, qcap, scap, bcap, lcap, rcap, total_words, equiv;
   // everything that changes the meaning of the state words without changing their number: the protocol mode, the fault model,
   // the kernel class and the queue discipline / key encoding it implies, the archive capacity of retired record stores
-  u32 quirks, drop_ppm, part_size, rot, sim_class, qpack, qcal, qheap, ecap, pad_;
+  u32 quirks, drop_ppm, part_size, rot, sim_class, qpack, qcal, qheap, ecap, tw;
   i64 part_start, part_end;
   u64 m, cpe;
   i64 max_clock, tci, delta, uni_lo, uni_hi;
@@ -1063,8 +1079,8 @@ static void fill_header(const lbft_batch* b, CheckpointHeader& h) {
   h.equiv = p.equiv; h.m = b->m; h.cpe = c.commands_per_epoch; h.max_clock = b->started_max_clock; h.tci = c.target_commit_interval;
   h.delta = c.delta; h.uni_lo = c.uniform_lo; h.uni_hi = c.uniform_hi; h.mean = c.mean; h.variance = c.variance; h.gamma = c.gamma;
   h.lambda = c.lambda; h.delay_model = c.delay_model; h.weights_hash = weights_hash(b->weights) ^ (p.rot * 0x9e3779b9u);
-  h.quirks = p.quirks; h.drop_ppm = p.drop_ppm; h.part_size = p.part_size; h.rot = p.rot; h.sim_class = (u32)sim_class(p) | ((sim_lean(p) || sim_lean1(p)) ? 256u : 0u);
-  h.qpack = p.qpack; h.qcal = p.qcal; h.qheap = p.qheap; h.ecap = p.ecap; h.part_start = c.partition_start; h.part_end = c.partition_end;
+  h.quirks = p.quirks; h.drop_ppm = p.drop_ppm; h.part_size = p.part_size; h.rot = p.rot; h.sim_class = (u32)sim_class(p) | (((sim_lean(p) && lean2_allowed()) || (sim_lean1(p) && lean_allowed())) ? 256u : 0u);
+  h.qpack = p.qpack; h.qcal = p.qcal; h.qheap = p.qheap; h.ecap = p.ecap; h.tw = p.tw | (p.ring << 8); h.part_start = c.partition_start; h.part_end = c.partition_end;
 }
 size_t lbft_batch_checkpoint_bytes(const lbft_batch* b) {
   if (!b || !b->started) return 0;

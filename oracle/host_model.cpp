@@ -29,6 +29,7 @@ typedef struct lbft_hostmodel_caps {
   uint32_t qcal;           // 1 = calendar event queue (needs max_clock <= LBFT_CAL_MAX_CLOCK and a class >= 1 kernel)
   uint32_t ring;           // > 0 (class 2 + calendar): the cooperative event loop (run_coop / coop_bulk, 64 emulated lanes) with a ring of this many pre-generated draws
   uint32_t ring_topup;     // draws the generator runs ahead per step
+  uint32_t tw;             // tile width of the state layout (0 = 64; the device uses the lanes per wavefront outside kernel class 0)
 } lbft_hostmodel_caps;
 
 // Same outputs as lbft_oracle_run_batch, plus per-instance fault words and max queue/snapshot use.
@@ -45,6 +46,10 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   p.n = cfg->num_nodes;
   p.m = (u32)n_instances;
   p.stride = (u32)((n_instances + 63) / 64 * 64);
+  p.tw = caps->tw ? caps->tw : 64;
+  if (p.tw > 64 || (p.tw & (p.tw - 1))) return -13;
+  p.rsh = 2;
+  while ((1u << p.rsh) < 4u * p.tw) p.rsh++;
   p.qcap = caps->qcap; p.scap = caps->scap; p.bcap = caps->bcap; p.lcap = caps->lcap;
   p.max_clock = (i32)max_clock;
   p.ql = caps->ql;
@@ -114,6 +119,7 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
     s.store_scalars(done);
   };
   int cls = caps->force_generic ? 3 : sim_class(p);
+  if (cls == 0 || cls == 1) { p.tw = 64; p.rsh = 8; }  // the small-network classes address 64-wide tiles at compile time
   auto worker = [&](u32 tid) {
     for (size_t i = tid; i < n_instances; i += threads) {
       { Sim s0(p, state.data(), (u32)i); s0.init(seeds[i]); }

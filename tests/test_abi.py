@@ -121,5 +121,7 @@ def test_run_kernels_keep_their_state_in_registers(hiplib):
     assert len(big) == 2, sorted(kernels)
     for v in big:  # large-network classes: a handful of spilled registers at most, never the whole state
         assert v["private_segment_fixed_size"] <= 128, big
-    lean = [v for k, v in kernels.items() if "lbft_k_run2l" in k or "lbft_k_run1l" in k]  # the lean kernels: two wavefronts per SIMD as well
-    assert len(lean) == 2 and all(v["vgpr_count"] <= 256 and v["private_segment_fixed_size"] <= 192 for v in lean), lean
+    lean = [v for k, v in kernels.items() if "lbft_k_run1l" in k]  # class 1 without record exchange / trace / loss: two wavefronts per SIMD as well
+    assert len(lean) == 1 and all(v["vgpr_count"] <= 256 and v["private_segment_fixed_size"] <= 128 for v in lean), lean
+    lean2 = [v for k, v in kernels.items() if "lbft_k_run2l" in k]  # opt-in (LBFT_LEAN2=1): large networks at 256 registers spill heavily
+    assert len(lean2) == 1 and lean2[0]["vgpr_count"] <= 256, lean2

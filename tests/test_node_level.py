@@ -284,16 +284,16 @@ def test_device_request_response_in_reference_mode_are_self_answered_and_insert_
     dev, ora = DeviceDriver(amd, n), OracleDriver(oracle, n)
     for d in (dev, ora):
         trace = []
-        for clock in range(0, 120):
+        for clock in range(0, 400):
             full_exchange(d, clock, trace, members=[0, 1, 2])
     before = [dev.view(i) for i in range(n)]
     assert before == [ora.view(i) for i in range(n)] and before[0]["highest_quorum_certificate_round"] >= 2
     for node in (0, 3):  # an up-to-date node and the one that heard nothing
         req = dev.request(node)
         resp = dev.respond(node, req)          # self-answered
-        dev.absorb(node, resp, 120)
+        dev.absorb(node, resp, 400)
         oreq = ora.request(node)
-        ora.absorb(node, ora.respond(node, oreq), 120)
+        ora.absorb(node, ora.respond(node, oreq), 400)
         assert dev.view(node) == before[node] == ora.view(node)
         dev.release(req); dev.release(resp)
     req = dev.request(3)
