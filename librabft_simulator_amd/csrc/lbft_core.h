@@ -1431,6 +1431,10 @@ struct SimT {
   // The timeouts of a notification (data_sync.rs:150-163), in author order; the hcbr words of up to four
   // authors are fetched in one burst before they are inserted.
   LBFT_HD void insert_timeouts(u32 node, u32 slot, u32 first_word, u32 mask, u32 round, u32 author0 = 0) const {
+    insert_timeouts_at(node, sfw(slot, first_word), mask, round, author0);
+  }
+  // (`word0`: row of the first author's highest_certified_block_round -- a snapshot slot or an archived record store)
+  LBFT_HD void insert_timeouts_at(u32 node, u32 word0, u32 mask, u32 round, u32 author0 = 0) const {
     // an author whose timeout the node already holds is rejected without side effects (record_store.rs:390-415) and inserting
     // one author never changes that for another: only the new ones are fetched
     mask &= ~am_word(node, NF_TO_MASK, author0 >> 5);
@@ -1442,7 +1446,7 @@ struct SimT {
 #endif
       for (u32 j = 0; j < TB; j++) {
         a[j] = 0; h[j] = 0;
-        if (mask) { a[j] = author0 + ctz32(mask); mask &= mask - 1; h[j] = ld(sfw(slot, first_word + a[j])); k = j + 1; }
+        if (mask) { a[j] = author0 + ctz32(mask); mask &= mask - 1; h[j] = ld(word0 + a[j]); k = j + 1; }
       }
 #if defined(__HIPCC__)
 #pragma unroll
@@ -1729,7 +1733,8 @@ struct SimT {
   // ---- DataSyncNode::create_notification (data_sync.rs:82-111) into snapshot slot ----
   // hcbr words of the authors in `mask` (author = author0 + bit): node buffer -> snapshot, four loads in flight at a
   // time (a load-store-load-store chain would be one memory round trip per author)
-  LBFT_HD void copy_hcbr(u32 node, u32 slot, u32 mask, u32 author0, u32 buf, u32 snap_word0) const {
+  LBFT_HD void copy_hcbr(u32 node, u32 slot, u32 mask, u32 author0, u32 buf, u32 snap_word0) const { copy_hcbr_to(node, sfw(slot, snap_word0), mask, author0, buf); }
+  LBFT_HD void copy_hcbr_to(u32 node, u32 dst_word0, u32 mask, u32 author0, u32 buf) const {
     constexpr u32 B = BIG ? 8 : 4;  // loads in flight per round trip (large networks copy dozens of words per notification)
     while (mask) {
       u32 a[B], h[B], k = 0;
@@ -1744,7 +1749,7 @@ struct SimT {
 #pragma unroll
 #endif
       for (u32 j = 0; j < B; j++)
-        if (j < k) st(sfw(slot, snap_word0 + a[j]), h[j]);
+        if (j < k) st(dst_word0 + a[j], h[j]);
     }
   }
   // ---- quirks bit 0 (reference quirk Q1 fixed): requests are answered by the PEER (bft-driver/src/core.rs:174-178
@@ -1765,8 +1770,9 @@ struct SimT {
       u32 tk = htc ? am_word(node, NF_TC_MASK, k) : 0, ok = am_word(node, NF_TO_MASK, k);
       st(k == 0 ? base + S_TC_MASK : base + S_FIXED_WORDS + 2 * P.n + (k - 1), tk);
       st(k == 0 ? base + S_TO_MASK : base + S_FIXED_WORDS + 2 * P.n + (P.mw - 1) + (k - 1), ok);
-      for (u32 m = tk; m;) { u32 a = 32 * k + ctz32(m); m &= m - 1; st(base + S_FIXED_WORDS + a, nfm(node, NF_FIXED_WORDS + tc_sel * P.n + a)); }
-      for (u32 m = ok; m;) { u32 a = 32 * k + ctz32(m); m &= m - 1; st(base + S_FIXED_WORDS + P.n + a, nfm(node, NF_FIXED_WORDS + (1u - tc_sel) * P.n + a)); }
+      // (several loads in flight per round trip: a load-store-load-store chain is one memory round trip per author)
+      copy_hcbr_to(node, base + S_FIXED_WORDS, tk, 32 * k, tc_sel);
+      copy_hcbr_to(node, base + S_FIXED_WORDS + P.n, ok, 32 * k, 1u - tc_sel);
     }
   }
   LBFT_HD u32 arch_base(u32 node, u32 epoch) const { return P.off_arch + (node * P.ecap + epoch) * P.snap_words; }
@@ -1834,14 +1840,19 @@ struct SimT {
       insert_block(node, b, rb);
       insert_qc(node, b, rb);
     }
+    // A timeout whose round is not the receiver's current round is rejected without side effects, and the current round only
+    // moves forward while a set is inserted (see handle_notification): a set of another round is skipped as a whole, the
+    // authors the node already holds are not fetched, the others several per round trip.
     u32 tc_round = ld(base + S_TC_ROUND), to_round = ld(base + S_TO_ROUND);
     for (u32 k = 0; k < P.mw; k++) {
+      if (tc_round != nf(node, NF_CUR_ROUND)) break;
       u32 tk = ld(k == 0 ? base + S_TC_MASK : base + S_FIXED_WORDS + 2 * P.n + (k - 1));
-      for (u32 m = tk; m;) { u32 a = 32 * k + ctz32(m); m &= m - 1; insert_timeout(node, a, tc_round, ld(base + S_FIXED_WORDS + a)); }
+      insert_timeouts_at(node, base + S_FIXED_WORDS, tk, tc_round, 32 * k);
     }
     for (u32 k = 0; k < P.mw; k++) {
+      if (to_round != nf(node, NF_CUR_ROUND)) break;
       u32 ok = ld(k == 0 ? base + S_TO_MASK : base + S_FIXED_WORDS + 2 * P.n + (P.mw - 1) + (k - 1));
-      for (u32 m = ok; m;) { u32 a = 32 * k + ctz32(m); m &= m - 1; insert_timeout(node, a, to_round, ld(base + S_FIXED_WORDS + P.n + a)); }
+      insert_timeouts_at(node, base + S_FIXED_WORDS + P.n, ok, to_round, 32 * k);
     }
     u32 pb = ld(base + S_PROP_VOTE) & 0xffffu;
     if (pb) insert_block(node, pb);
