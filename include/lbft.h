@@ -163,6 +163,12 @@ int lbft_batch_committed_histories(const lbft_batch* b, lbft_commit* out, size_t
 /* StateFinalizer::last_committed_state() (simulated_context.rs:194-196; State = SipHash-1-3 of the
  * history, :51-55), computed on the device: out[inst * num_nodes + node]. */
 int lbft_batch_last_committed_states(const lbft_batch* b, uint64_t* out);
+/* ConsensusNode::save_node (librabft-v2/src/node.rs:233-238): bincode::serialize(&NodeState) of one node -- record store with every Block /
+ * QuorumCertificate / Vote / Timeout it holds (rebuilt with the reference's BCS + SipHash-1-3 hashes and signatures), pacemaker, tracker --
+ * in bincode 1.3's default encoding with HashMaps in ascending key order (the reference's own order is per-process; its load_node,
+ * node.rs:211-231, accepts any order).  *len = the image's length; copied when cap suffices.  Nodes that have changed epoch are not
+ * supported (LBFT_ERR_UNSUPPORTED: retired record stores are not kept in full on the device). */
+int lbft_batch_save_node(const lbft_batch* b, size_t inst, uint32_t node, void* buf, size_t cap, size_t* len);
 /* ... and of one node: contexts[node].last_committed_state() as librabft-v2/tests/simulated_run.rs:57-65 reads it. */
 int lbft_batch_last_committed_state(const lbft_batch* b, size_t inst, uint32_t node, uint64_t* out);
 /* SimulatedNode::startup_time (simulator.rs:55,217): out[inst * num_nodes + node]. */

@@ -425,6 +425,15 @@ LBFT_HD u64 record_hash_vote(u64 epoch, u64 round, u64 block_hash, u64 state, bo
   return h.finish();
 }
 
+// Timeout_ (record.rs:101-111): epoch_id, round, highest_certified_block_round, author
+LBFT_HD u64 record_hash_timeout(u64 epoch, u64 round, u64 hcbr, u64 author) {
+  SipBytes h; h.init();
+  const char name[] = "Timeout_::";
+  for (u32 i = 0; i < sizeof(name) - 1; i++) h.byte((u32)name[i]);
+  h.u64le(epoch); h.u64le(round); h.u64le(hcbr); h.u64le(author);
+  return h.finish();
+}
+
 // EpochConfiguration::pick_author(SipHash13(round)) (configuration.rs:65-75, pacemaker.rs:100-109)
 // `shift`: author a holds weights[(a + shift) % n] (rotating voting rights; 0 in the reference)
 LBFT_HD u32 compute_leader(const u32* weights, u32 n, u32 total_votes, u64 round, u32 shift = 0) {

@@ -11,11 +11,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
 #include "../../include/lbft.h"
 #include "lbft_core.h"
+#include "lbft_save_node.h"
 #include "lbft_tables.h"
 
 using namespace lbft;
@@ -1269,6 +1271,31 @@ int lbft_batch_committed_record_hashes(const lbft_batch* b, size_t inst, uint32_
   if (e != hipSuccess) return hip_fail(e, "lbft_batch_committed_record_hashes");
   for (size_t i = 0; i < k; i++)
     out[i] = lbft_record_hash{h[4 * i], h[4 * i + 1], h[4 * i + 2], (uint32_t)h[4 * i + 3], (uint32_t)(h[4 * i + 3] >> 32)};
+  return LBFT_OK;
+}
+
+// ---- ConsensusNode::save_node (librabft-v2/src/node.rs:233-238): the bincode image of one node's NodeState -------------
+// The event loop keeps structural ids, masks and denormalised rounds instead of the reference's records; this is the way
+// back: every Block / QuorumCertificate / Vote / Timeout the node's record store holds is rebuilt with the hashes and
+// signatures the reference gives it (BCS + SipHash-1-3, as lbft_batch_committed_record_hashes does for the committed chain)
+// and written in bincode 1.3's default encoding, HashMaps in ascending key order (oracle/lbft_oracle.cpp
+// lbft_oracle_save_node is the format's restatement; the two images are compared byte for byte in tests/).  One instance's
+// rows are copied to the host and serialised there -- a read-back format conversion like the history export, not simulation.
+int lbft_batch_save_node(const lbft_batch* b, size_t inst, uint32_t node, void* buf, size_t cap, size_t* len) {
+  if (!b || !len || inst >= b->m || node >= b->p.n) return LBFT_ERR_INVALID;
+  if (!b->ran && !b->manual) { g_err = "run the batch (or start a node-level session) first"; return LBFT_ERR_STATE; }
+  HIP_TRY(hipSetDevice(b->device));
+  const Params& dp = b->p;
+  // this instance's rows, contiguous on the host (a tile of width 1)
+  std::vector<u32> hw(dp.total_words);
+  HIP_TRY(hipMemcpy2D(hw.data(), sizeof(u32), b->d_state + word_offset(dp, (u32)inst, 0), (size_t)4 * dp.tw, sizeof(u32), dp.total_words,
+                      hipMemcpyDeviceToHost));
+  std::vector<uint8_t> image;
+  std::string err;
+  int rc = build_node_image(dp, hw.data(), node, b->weights.data(), b->cfg.delta, b->cfg.gamma, b->cfg.lambda, b->cfg.target_commit_interval, image, err);
+  if (rc != 0) { g_err = err; return LBFT_ERR_UNSUPPORTED; }
+  *len = image.size();
+  if (buf && cap >= image.size()) memcpy(buf, image.data(), image.size());
   return LBFT_OK;
 }
 

@@ -198,6 +198,11 @@ class BatchResult:
         check(_lib.lib().lbft_batch_committed_record_hashes(self._sim._h, instance, node, out.ctypes.data, n, C.byref(ln)))
         return out[:n]
 
+    def save_node(self, instance, node):
+        """ConsensusNode::save_node (librabft-v2/src/node.rs:233-238): bincode image of the node's NodeState (bytes), HashMaps in
+        ascending key order; what the reference's load_node (node.rs:211-231) deserialises."""
+        return self._sim.save_node(instance, node)
+
     def round_switches(self, instance=0, cap_rounds=None):
         """DataWriter output of one instance (bft-lib/src/data_writer.rs): (rows, number_of_messages) where
         rows[round][node] is the GlobalTime at which the node was first seen in that round or None (empty cell)."""
@@ -312,6 +317,13 @@ class BatchSimulator:
         check(_lib.lib().lbft_batch_manual_finalize(self._h), allow_fault=True)
         return BatchResult(self)
 
+    def save_node(self, instance, node):
+        ln = C.c_size_t()
+        check(_lib.lib().lbft_batch_save_node(self._h, int(instance), int(node), None, 0, C.byref(ln)))
+        buf = np.zeros(ln.value, dtype=np.uint8)
+        check(_lib.lib().lbft_batch_save_node(self._h, int(instance), int(node), buf.ctypes.data, ln.value, C.byref(ln)))
+        return buf.tobytes()
+
     def reset(self):
         check(_lib.lib().lbft_batch_reset(self._h))
 
@@ -401,6 +413,10 @@ class NodeHandle:
     def release(self, message):
         """Drops a notification / request / response handle."""
         check(_lib.lib().lbft_node_release_notification(self._sim._h, self.instance, message[1]))
+
+    def save_node(self):
+        """ConsensusNode::save_node (node.rs:233-238) -> the bincode image of this node's NodeState."""
+        return self._sim.save_node(self.instance, self.author)
 
     def view(self):
         v = LbftNodeView()

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../librabft_simulator_amd/csrc/lbft_core.h"
+#include "../librabft_simulator_amd/csrc/lbft_save_node.h"
 #include "../librabft_simulator_amd/csrc/lbft_tables.h"
 #include "lbft_oracle.h"
 
@@ -18,7 +19,15 @@ static const u64 ZX[257] = LBFT_ZIG_NORM_X_BITS_INIT;
 static const u64 ZF[257] = LBFT_ZIG_NORM_F_BITS_INIT;
 static const u64 ET[256] = LBFT_EXP_TAB_INIT;
 
+// save_node images of instance 0's nodes after the next lbft_hostmodel_run_batch (test hook, not thread-safe): node k's image is written
+// at image_buf + k * image_stride, its length (or (size_t)-1: unsupported) into image_lens[k]
+static uint8_t* g_image_buf = nullptr;
+static size_t g_image_stride = 0;
+static size_t* g_image_lens = nullptr;
+
 extern "C" {
+
+void lbft_hostmodel_capture_node_images(uint8_t* buf, size_t stride, size_t* lens) { g_image_buf = buf; g_image_stride = stride; g_image_lens = lens; }
 
 typedef struct lbft_hostmodel_caps {
   uint32_t qcap, scap, bcap, lcap;
@@ -137,6 +146,18 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
   worker(0);
   for (auto& t : ts) t.join();
 
+  if (g_image_buf && g_image_lens) {  // ConsensusNode::save_node of every node of instance 0 (lbft_save_node.h, the code the product library runs)
+    std::vector<u32> hw(p.total_words);
+    for (u32 w = 0; w < p.total_words; w++) hw[w] = state[word_offset(p, 0, w)];
+    for (u32 k = 0; k < p.n; k++) {
+      std::vector<uint8_t> image;
+      std::string err;
+      int irc = build_node_image(p, hw.data(), k, weights.data(), cfg->delta, cfg->gamma, cfg->lambda, cfg->target_commit_interval, image, err);
+      g_image_lens[k] = irc == 0 ? image.size() : (size_t)-1;
+      if (irc == 0 && image.size() <= g_image_stride) memcpy(g_image_buf + (size_t)k * g_image_stride, image.data(), image.size());
+    }
+    g_image_buf = nullptr; g_image_lens = nullptr;
+  }
   if (counters) memset(counters, 0, sizeof(*counters));
   int rc = 0;
   for (size_t i = 0; i < n_instances; i++) {

@@ -1364,6 +1364,91 @@ size_t lbft_oracle_committed_record_hashes(const lbft_oracle_sim* sim, uint32_t 
   }
   return h.size();
 }
+// ---- ConsensusNode::save_node (node.rs:233-238): bincode::serialize(&NodeState) ---------------------------------------
+// bincode 1.3 with its default options (the reference calls bincode::serialize / deserialize directly): integers fixed-width
+// little-endian (usize as u64), f64 as its 8 IEEE bytes, Option = one tag byte (+ value), Vec / HashMap = u64 length then the
+// elements, enum = u32 variant index then the variant's fields, structs / tuples / newtypes = their fields in order.  The
+// reference's HashMaps serialise in per-process iteration order, which bincode's deserialiser does not care about;
+// this image uses the CANONICAL order -- ascending key -- so that it is reproducible: load_node accepts it like any other.
+namespace {
+struct Bin {
+  std::vector<u8> b;
+  void u64v(u64 v) { for (int i = 0; i < 8; i++) b.push_back((u8)(v >> (8 * i))); }
+  void i64v(i64 v) { u64v((u64)v); }
+  void u32v(u32 v) { for (int i = 0; i < 4; i++) b.push_back((u8)(v >> (8 * i))); }
+  void f64v(double d) { u64 u; memcpy(&u, &d, 8); u64v(u); }
+  void opt(const std::optional<u64>& o) { if (o) { b.push_back(1); u64v(*o); } else b.push_back(0); }
+  void sig(const Signature& g) { u64v(g.author); u64v(g.hash); }
+  void block(const Block& x) { u64v(x.cmd_proposer); u64v(x.cmd_index); i64v(x.time); u64v(x.previous_qc_hash); u64v(x.round); u64v(x.author); sig(x.signature); }
+  void vote(const Vote& v) { u64v(v.epoch_id); u64v(v.round); u64v(v.certified_block_hash); u64v(v.state); opt(v.committed_state); u64v(v.author); sig(v.signature); }
+  void qc(const QuorumCertificate& q) {
+    u64v(q.epoch_id); u64v(q.round); u64v(q.certified_block_hash); u64v(q.state); opt(q.committed_state);
+    u64v(q.votes.size());
+    for (auto& v : q.votes) { u64v(v.first); sig(v.second); }
+    u64v(q.author); sig(q.signature);
+  }
+  void timeout(const Timeout& t) { u64v(t.epoch_id); u64v(t.round); u64v(t.highest_certified_block_round); u64v(t.author); sig(t.signature); }
+  void store(const RecordStore& r) {  // RecordStoreState (record_store.rs:93-119), field by field
+    u64v(r.epoch_id);
+    u64v(r.configuration.authors.size());
+    for (auto& a : r.configuration.authors) { u64v(a.first); u64v(a.second); }
+    std::map<Author, u64> rights(r.configuration.voting_rights.begin(), r.configuration.voting_rights.end());
+    u64v(rights.size());
+    for (auto& a : rights) { u64v(a.first); u64v(a.second); }
+    u64v(r.configuration.total_votes);
+    u64v(r.initial_hash);
+    u64v(r.initial_state);
+    std::map<u64, const Block*> blocks;
+    for (auto& kv : r.blocks) blocks[kv.first] = &kv.second;
+    u64v(blocks.size());
+    for (auto& kv : blocks) { u64v(kv.first); block(*kv.second); }
+    std::map<u64, const QuorumCertificate*> qcs;
+    for (auto& kv : r.quorum_certificates) qcs[kv.first] = &kv.second;
+    u64v(qcs.size());
+    for (auto& kv : qcs) { u64v(kv.first); qc(*kv.second); }
+    opt(r.current_proposed_block);
+    u64v(r.highest_quorum_certificate_round);
+    u64v(r.highest_quorum_certificate_hash);
+    u64v(r.highest_timeout_certificate_round);
+    u64v(r.current_round);
+    u64v(r.highest_committed_round);
+    opt(r.highest_commit_certificate_hash);
+    if (r.highest_timeout_certificate) {
+      b.push_back(1);
+      u64v(r.highest_timeout_certificate->size());
+      for (auto& t : *r.highest_timeout_certificate) timeout(t);
+    } else b.push_back(0);
+    u64v(r.current_timeouts.size());
+    for (auto& kv : r.current_timeouts) { u64v(kv.first); timeout(kv.second); }
+    u64v(r.current_votes.size());
+    for (auto& kv : r.current_votes) { u64v(kv.first); vote(kv.second); }
+    u64v(r.current_timeouts_weight);
+    if (r.election == RecordStore::ONGOING) {
+      u32v(0);
+      u64v(r.ballot.size());
+      for (auto& kv : r.ballot) { u64v(kv.first.first); u64v(kv.first.second); u64v(kv.second); }
+    } else if (r.election == RecordStore::WON) {
+      u32v(1); u64v(r.won_block); u64v(r.won_state);
+    } else u32v(2);
+  }
+};
+}  // namespace
+size_t lbft_oracle_save_node(const lbft_oracle_sim* sim, uint32_t node, uint8_t* out, size_t cap) {
+  if (!sim || node >= sim->nodes.size()) return 0;
+  const NodeState& n = sim->nodes[node].node;
+  Bin w;
+  w.store(*n.record_store);
+  const PacemakerState& pm = n.pacemaker;  // PacemakerState (pacemaker.rs:60-77)
+  w.u64v(pm.active_epoch); w.u64v(pm.active_round);
+  if (pm.active_leader) { w.b.push_back(1); w.u64v(*pm.active_leader); } else w.b.push_back(0);
+  w.i64v(pm.active_round_start_time); w.i64v(pm.active_round_duration); w.i64v(pm.delta); w.f64v(pm.gamma); w.f64v(pm.lambda);
+  w.u64v(n.epoch_id); w.u64v(n.latest_voted_round); w.u64v(n.locked_round); w.i64v(n.latest_query_all_time);
+  w.u64v(n.tracker.epoch_id); w.u64v(n.tracker.highest_committed_round); w.i64v(n.tracker.latest_commit_time); w.i64v(n.tracker.target_commit_interval);
+  w.u64v(n.past_record_stores.size());
+  for (auto& kv : n.past_record_stores) { w.u64v(kv.first); w.store(*kv.second); }
+  if (out && cap >= w.b.size()) memcpy(out, w.b.data(), w.b.size());
+  return w.b.size();
+}
 int lbft_oracle_node_update(lbft_oracle_sim* sim, uint32_t node, int64_t node_time, lbft_oracle_actions* out) {
   if (!sim || !out || node >= sim->nodes.size()) return -1;
   try {

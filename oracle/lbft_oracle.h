@@ -166,6 +166,10 @@ void lbft_oracle_sample_delays(const lbft_oracle_config* cfg, uint64_t seed, int
 void lbft_oracle_shuffle(uint64_t seed, uint32_t* out, size_t n);
 double lbft_oracle_exp_strict(double x);
 double lbft_oracle_log_strict(double x);
+/* ConsensusNode::save_node (librabft-v2/src/node.rs:233-238): the bincode 1.3 image of the node's whole NodeState with every HashMap in
+ * ascending key order (the reference's own order is per-process; its load_node, node.rs:211-231, accepts any).  Returns the image's
+ * length; copies it when cap suffices. */
+size_t lbft_oracle_save_node(const lbft_oracle_sim* sim, uint32_t node, uint8_t* out, size_t cap);
 size_t lbft_oracle_exp_mismatches(const double* x, size_t n);
 size_t lbft_oracle_log_mismatches(const double* x, size_t n, size_t* off_by_one_ulp);
 

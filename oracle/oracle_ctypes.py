@@ -164,6 +164,8 @@ def lib():
         L.lbft_oracle_exp_strict.restype = C.c_double
         L.lbft_oracle_log_strict.argtypes = [C.c_double]
         L.lbft_oracle_log_strict.restype = C.c_double
+        L.lbft_oracle_save_node.argtypes = [vp, C.c_uint32, vp, C.c_size_t]
+        L.lbft_oracle_save_node.restype = C.c_size_t
         L.lbft_oracle_exp_mismatches.argtypes = [vp, C.c_size_t]
         L.lbft_oracle_exp_mismatches.restype = C.c_size_t
         L.lbft_oracle_log_mismatches.argtypes = [vp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -235,6 +237,13 @@ class OracleSim:
         out = np.zeros(n, dtype=RECORD_HASH_DTYPE)
         lib().lbft_oracle_committed_record_hashes(self.h, node, out.ctypes.data, n)
         return out
+
+    def save_node(self, node):
+        """ConsensusNode::save_node (node.rs:233-238): the canonical-order bincode image of the node's NodeState."""
+        n = lib().lbft_oracle_save_node(self.h, node, None, 0)
+        buf = np.zeros(n, dtype=np.uint8)
+        assert lib().lbft_oracle_save_node(self.h, node, buf.ctypes.data, n) == n
+        return buf.tobytes()
 
     def last_committed_states(self):
         return [lib().lbft_oracle_last_committed_state(self.h, n) for n in range(self.cfg.num_nodes)]
@@ -372,6 +381,25 @@ def hostmodel_lib():
         L.lbft_hostmodel_run_batch.restype = C.c_int
         _hm = L
     return _hm
+
+
+def hostmodel_node_images(cfg, seed, max_clock, **caps):
+    """save_node images (bytes, or None when unsupported) of every node of ONE network run on the host model: the image builder of the
+    product library (csrc/lbft_save_node.h) applied to the host model's state rows."""
+    L = hostmodel_lib()
+    n, stride = cfg.num_nodes, 1 << 22
+    buf = np.zeros(n * stride, dtype=np.uint8)
+    lens = (C.c_size_t * n)()
+    L.lbft_hostmodel_capture_node_images.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.lbft_hostmodel_capture_node_images.restype = None
+    L.lbft_hostmodel_capture_node_images(buf.ctypes.data, stride, C.addressof(lens))
+    res = hostmodel_run_batch(cfg, np.array([seed], dtype=np.uint64), max_clock, **caps)
+    assert not res["faults"].any()
+    out = []
+    for k in range(n):
+        ln = int(lens[k])
+        out.append(None if ln == 2 ** 64 - 1 else buf[k * stride:k * stride + ln].tobytes())
+    return out
 
 
 def hostmodel_run_batch(cfg, seeds, max_clock, threads=1, history_cap=0, qcap=256, scap=128, bcap=256, lcap=256, ql=0, qheap=0, force_generic=0, rcap=0, qcal=0,

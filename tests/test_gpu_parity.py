@@ -138,6 +138,48 @@ def test_heap_queue_equals_calendar_queue(amd, oracle, name):
     assert (sim2.layout()["kernel_class"] >> 9) & 1 == 1
 
 
+def test_long_horizon_64_nodes_calendar_equals_heap_equals_oracle(amd, oracle):
+    """Horizons beyond the round-1 calendar (max_clock <= 2047): 64-node networks to clock 3000 on the calendar queue (now up to
+    16383) and on the binary heap (what longer horizons and the round trace fall back to) -- both bit-exact against the oracle.
+    Reference ordering: bft-lib/src/simulator.rs:141-169."""
+    kw, seeds, max_clock = dict(num_nodes=64), np.arange(1, 5, dtype=np.uint64) * 7919, 3000
+    sim, res = run_gpu(amd, kw, seeds, max_clock)
+    assert (sim.layout()["kernel_class"] >> 9) & 1 == 1                 # calendar
+    ref = assert_equal_to_oracle(oracle, res, kw, seeds, max_clock, cap=512)
+    assert ref["commit_counts"].max() >= 80
+    sim2, res2 = run_gpu(amd, kw, seeds, max_clock, calendar_queue=False)
+    assert (sim2.layout()["kernel_class"] >> 9) & 1 == 0 and (sim2.layout()["kernel_class"] >> 8) & 1 == 1   # heap
+    assert_equal_to_oracle(oracle, res2, kw, seeds, max_clock, cap=512)
+    assert res2.counters["max_queue"] == res.counters["max_queue"]
+
+
+def test_bench_two_ranks_on_one_device():
+    """The N > 1 path of bench.py on the HIP path (until an 8-GPU node runs it): two ranks (gloo rendezvous, both on HIP
+    device 0), instances sharded by distributed.shard_seeds, ONE all-gather of the counters.  The aggregate must be the
+    whole-job figure: twice the per-rank instance count, rounds of both shards."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--single-device", "--instances", "4096",
+           "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["faulted_instances"] == 0
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--instances", "8192", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    w = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    # same 8 192 seeds (base_seed + global index), sharded 2 x 4 096: identical aggregate work
+    assert round(d["value"] * d["ms_per_step"]) == round(w["value"] * w["ms_per_step"])
+    assert round(d["events_per_s"] * d["ms_per_step"]) == round(w["events_per_s"] * w["ms_per_step"])
+
+
 def test_multi_launch_equals_single_launch(amd, oracle):
     kw, seeds = dict(num_nodes=4), np.arange(1, 257, dtype=np.uint64)
     _, res = run_gpu(amd, kw, seeds, 1000, max_steps_per_launch=97)

@@ -1,0 +1,96 @@
+"""ConsensusNode::save_node (librabft-v2/src/node.rs:233-238): the bincode image of a node's whole NodeState.
+
+The reference holds no byte-level known answer for it (its HashMaps serialise in per-process order): parity is
+UNPINNED against the reference; what is checked is (a) the oracle's image parses as the struct layout of the reference's source
+(tests/bincode_nodestate.py, written from the struct definitions) and agrees with the oracle's own node view, and (b) the
+device rebuilds the identical image -- every record, hash and signature -- from its structural state (-m gpu)."""
+import numpy as np
+import pytest
+
+from bincode_nodestate import node_state
+
+CASES = {
+    "golden_n3": (dict(num_nodes=3), 52, (1000, 137, 455)),
+    "n4_long_tail_timeouts": (dict(num_nodes=4, mean=10.0, variance=400.0), 7, (1500, 333)),
+    "n7_weighted": (dict(num_nodes=7, voting_rights=[2, 1, 1, 3, 1, 2, 1]), 1234567, (800,)),
+    "n5_equivocators": (dict(num_nodes=5, equivocate_every=2), 99, (700,)),
+    "n5_fast_pacemaker": (dict(num_nodes=5, delta=3, gamma=1.5, lambda_=0.25, target_commit_interval=80), 5, (600,)),
+    "n40": (dict(num_nodes=40), 3, (250,)),
+    "n64_long_tail": (dict(num_nodes=64, mean=10.0, variance=400.0), 11, (300,)),
+    "n4_q1_lossy": (dict(num_nodes=4, quirks=1, drop_per_million=100000), 21, (900,)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_image_has_the_reference_layout(oracle, name):
+    kw, seed, horizons = CASES[name]
+    cfg = oracle.make_config(math_mode=1, **kw)
+    for t in horizons:
+        sim = oracle.OracleSim(cfg, seed).run_until(t)
+        for node in range(kw["num_nodes"]):
+            img = sim.save_node(node)
+            n = node_state(img)  # consumes the image exactly
+            rs = n["record_store"]
+            view = sim.node_view(node)
+            assert rs["current_round"] == view["current_round"] and rs["highest_committed_round"] == view["highest_committed_round"]
+            assert rs["highest_quorum_certificate_round"] == view["highest_quorum_certificate_round"]
+            assert n["pacemaker"]["active_round"] == view["active_round"] and n["latest_voted_round"] == view["latest_voted_round"]
+            assert len(rs["current_timeouts"]) == view["num_current_timeouts"] and len(rs["current_votes"]) == view["num_current_votes"]
+            assert [k for k, _ in rs["blocks"]] == sorted(k for k, _ in rs["blocks"])  # canonical order
+            for h, b in rs["blocks"]:
+                assert b["signature"] == (b["author"], h)  # Signature(author, hash of the record) (simulated_context.rs:259-261)
+            for h, q in rs["quorum_certificates"]:
+                assert q["signature"] == (q["author"], h) and len(q["votes"]) >= 1
+            assert n["past_record_stores"] == [] and n["epoch_id"] == 0
+            assert sim.save_node(node) == img  # deterministic
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_image_builder_on_the_compact_model_equals_oracle_image(oracle, name):
+    """csrc/lbft_save_node.h -- the builder the product library runs on the rows it copies back from the GPU -- applied to the host
+    model's state: every record, hash and signature of every node equals the oracle's image, byte for byte."""
+    kw, seed, horizons = CASES[name]
+    cfg = oracle.make_config(math_mode=1, **kw)
+    n = kw["num_nodes"]
+    special = any(k in kw for k in ("equivocate_every", "drop_per_million")) or kw.get("quirks", 0) & 1
+    for t in horizons:
+        sim = oracle.OracleSim(cfg, seed).run_until(t)
+        caps = dict(qcap=max(4096, 8 * n * n), scap=(n * n + 8 * n + 64) if kw.get("quirks", 0) & 1 else max(64, 16 * n), bcap=512, lcap=512,
+                    ql=48 if n <= 16 and not special else 0, qheap=1 if n > 16 else 0, qcal=1 if n > 32 else 0, ring=256 if n > 32 else 0, tw=8 if n > 32 else 0)
+        images = oracle.hostmodel_node_images(cfg, seed, t, **caps)
+        for node in range(n):
+            a, b = sim.save_node(node), images[node]
+            assert b is not None
+            if a != b:
+                assert node_state(b) == node_state(a), (name, t, node)  # (a readable diff first)
+            assert a == b, (name, t, node)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_image_equals_oracle_image(oracle, name):
+    import librabft_simulator_amd as amd
+    kw, seed, horizons = CASES[name]
+    cfg = oracle.make_config(math_mode=1, **kw)
+    kwd = dict(kw)
+    n = kwd.pop("num_nodes")
+    delay = amd.RandomDelay.new(kwd.pop("mean", 10.0), kwd.pop("variance", 4.0))
+    nc = amd.NodeConfig(kwd.pop("target_commit_interval", 100000), kwd.pop("delta", 20), kwd.pop("gamma", 2.0), kwd.pop("lambda_", 0.5))
+    for t in horizons:
+        sim = oracle.OracleSim(cfg, seed).run_until(t)
+        res = amd.BatchSimulator.new(np.array([seed + 1, seed], dtype=np.uint64), n, delay, nc, **kwd).loop_until(t)
+        for node in range(n):
+            a, b = sim.save_node(node), res.save_node(1, node)
+            if a != b:
+                assert node_state(b) == node_state(a), (name, t, node)  # (a readable diff first)
+            assert a == b, (name, t, node)
+
+
+@pytest.mark.gpu
+def test_device_refuses_nodes_that_changed_epoch():
+    import librabft_simulator_amd as amd
+    res = amd.BatchSimulator.new(np.array([5], dtype=np.uint64), 4, amd.RandomDelay.new(10.0, 4.0), commands_per_epoch=5, quirks=3).loop_until(1000)
+    assert res.epochs.min() >= 1
+    with pytest.raises(amd.LbftError) as e:
+        res.save_node(0, 0)
+    assert e.value.code == -3
