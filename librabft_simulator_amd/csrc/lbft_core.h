@@ -1885,7 +1885,8 @@ struct SimT {
   }
 
   // `twin`: (E2) the copy for even-indexed receivers of an equivocator's notification carries the twin proposal
-  LBFT_HD void write_snapshot(u32 node, u32 slot, bool twin = false) const {
+  // `skip_hcbr`: the caller copies the timeouts' highest_certified_block_round words itself (coop_bulk: all lanes at once)
+  LBFT_HD void write_snapshot(u32 node, u32 slot, bool twin = false, bool skip_hcbr = false) const {
     st(sfw(slot, S_EPOCH), nf(node, NF_EPOCH));
     // highest_commit_certificate (data_sync.rs:84-92): the current store's, else the previous epoch's store's.
     // Reference quirk Q2: EpochId::previous() returns the SAME epoch (base_types.rs:31-37), so that lookup finds
@@ -1911,14 +1912,56 @@ struct SimT {
     st(sfw(slot, S_TC_MASK), tcm);
     st(sfw(slot, S_TO_MASK), tom);
     u32 tc_sel = nf(node, NF_TC_SEL);
-    copy_hcbr(node, slot, tcm, 0, tc_sel, S_FIXED_WORDS);
-    copy_hcbr(node, slot, tom, 0, 1u - tc_sel, S_FIXED_WORDS + P.n);
+    if (!skip_hcbr) {
+      copy_hcbr(node, slot, tcm, 0, tc_sel, S_FIXED_WORDS);
+      copy_hcbr(node, slot, tom, 0, 1u - tc_sel, S_FIXED_WORDS + P.n);
+    }
     for (u32 k = 1; wide() && k < P.mw; k++) {  // authors >= 32 (n > 32 only): extension words of the two sets + their hcbr entries
       u32 tk = htc ? am_word(node, NF_TC_MASK, k) : 0, ok = am_word(node, NF_TO_MASK, k);
       st(sxw(slot, 0, k), tk);
       st(sxw(slot, 1, k), ok);
-      copy_hcbr(node, slot, tk, 32 * k, tc_sel, S_FIXED_WORDS);
-      copy_hcbr(node, slot, ok, 32 * k, 1u - tc_sel, S_FIXED_WORDS + P.n);
+      if (!skip_hcbr) {
+        copy_hcbr(node, slot, tk, 32 * k, tc_sel, S_FIXED_WORDS);
+        copy_hcbr(node, slot, ok, 32 * k, 1u - tc_sel, S_FIXED_WORDS + P.n);
+      }
+    }
+  }
+  // The hcbr words of a snapshot that write_snapshot(.., skip_hcbr) left out, copied by all lanes of the wavefront at once
+  // (lane = author): one load + one store per lane instead of a chain of 8-author batches in the leader lane.  `k` = the
+  // leader lane, whose node cache holds the sets.
+  LBFT_HD void coop_copy_hcbr(u32 k, u32 l4, u32 node, u32 slot) const {
+    const bool is_k = LBFT_IS_LANE(k);
+    u32 tw_[4] = {0, 0, 0, 0}, ow_[4] = {0, 0, 0, 0}, sel_k = 0;
+    if (is_k) {
+      u32 htc = nf(node, NF_HTC_ROUND);
+      sel_k = nf(node, NF_TC_SEL);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 q = 0; q < 4; q++) { tw_[q] = (q < P.mw && htc) ? am_word(node, NF_TC_MASK, q) : 0u; ow_[q] = q < P.mw ? am_word(node, NF_TO_MASK, q) : 0u; }
+    }
+    const u32 tc_sel = LBFT_UNI(sel_k, k);
+    u32 tcw[4], tow[4];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 q = 0; q < 4; q++) { tcw[q] = LBFT_UNI(tw_[q], k); tow[q] = LBFT_UNI(ow_[q], k); }
+    const u32 src_tc = nfw(node, NF_FIXED_WORDS + tc_sel * P.n), src_to = nfw(node, NF_FIXED_WORDS + (1u - tc_sel) * P.n);
+    const u32 dst_tc = sfw(slot, S_FIXED_WORDS), dst_to = sfw(slot, S_FIXED_WORDS + P.n);
+    for (u32 a0 = 0; a0 < P.n; a0 += 64u) {
+      const u32 q0 = a0 >> 5;
+      PL<u32> vt, vo, ht, ho;
+      LBFT_FOR_LANES(l) {
+        u32 wt = l < 32u ? tcw[q0] : tcw[q0 + 1], wo = l < 32u ? tow[q0] : tow[q0 + 1];
+        vt[l] = (a0 + l < P.n) ? (wt >> (l & 31u)) & 1u : 0u;
+        vo[l] = (a0 + l < P.n) ? (wo >> (l & 31u)) & 1u : 0u;
+        ht[l] = vt[l] ? ldc(l4, src_tc + a0 + l) : 0u;
+        ho[l] = vo[l] ? ldc(l4, src_to + a0 + l) : 0u;
+      }
+      LBFT_FOR_LANES(l) {
+        if (vt[l]) stc(l4, dst_tc + a0 + l, ht[l]);
+        if (vo[l]) stc(l4, dst_to + a0 + l, ho[l]);
+      }
     }
   }
 
@@ -2097,7 +2140,9 @@ struct SimT {
     // same time (it is still pending: that time is > clock), only count the duplicate.
     if (t_new <= (i64)P.max_clock && (u32)t_new == nf(node, NF_LAST_TIMER_T)) {
       LBFT_STAT(40);
+#if !defined(LBFT_NO_EXEC_COUNTERS)
       n_fold++;
+#endif
       nfs(node, NF_TIMER_DUPS, nf(node, NF_TIMER_DUPS) + 1);
       nfs(node, NF_DUP_STAMP, stamp);
       stamp++;
@@ -2387,11 +2432,13 @@ struct SimT {
         if (is_k) {
           for (u32 q = 0; q < 2; q++) {
             bool do_twin = (q == 0) == twin_first;
-            if (do_twin && need_t) { st_ = snap_alloc(); if (st_ < 0) st_ = -2; else write_snapshot(node, (u32)st_, true); }
-            if (!do_twin && need_r) { sr = snap_alloc(); if (sr < 0) sr = -2; else write_snapshot(node, (u32)sr); }
+            if (do_twin && need_t) { st_ = snap_alloc(); if (st_ < 0) st_ = -2; else write_snapshot(node, (u32)st_, true, true); }
+            if (!do_twin && need_r) { sr = snap_alloc(); if (sr < 0) sr = -2; else write_snapshot(node, (u32)sr, false, true); }
           }
         }
         sr = (i32)LBFT_UNI((u32)sr, k); st_ = (i32)LBFT_UNI((u32)st_, k);
+        if (need_t && st_ >= 0) coop_copy_hcbr(k, l4, node, (u32)st_);
+        if (need_r && sr >= 0) coop_copy_hcbr(k, l4, node, (u32)sr);
         LBFT_FOR_LANES(l) if (live[l] && (twin[l] ? st_ < 0 : sr < 0)) live[l] = 0;  // no slot: not scheduled, the stamp is consumed
       } else if (rs < 0) {
         LBFT_FOR_LANES(l) live[l] = 0;
@@ -2687,7 +2734,9 @@ struct SimT {
       Actions a;
       a.next = LBFT_NEVER; a.send_to = -1; a.broadcast = false; a.query_all = false;
       if (do_update) {
+#if !defined(LBFT_NO_EXEC_COUNTERS)
         n_upd++;
+#endif
         a = node_update(node);
         if (sync) { sp.sync = 1; sp.sync_stamp = stamp++; }  // the request is scheduled before the timer (simulator.rs:424-440)
         LBFT_MARK(11);
