@@ -162,7 +162,9 @@ extern unsigned long long lbft_host_stats[64];
 // path) uses tw = 64 at compile time (two 32-lane wavefronts of a workgroup share a tile: 256-byte rows).  The other
 // classes run few networks per wavefront (8 or 16 lanes of 64-node networks, down to one), and there a 64-wide tile
 // would make every word access fetch a 128-byte line of which 16-64 bytes are used and spread a 41-word node burst over 41
-// lines: with tw = lanes per wavefront the same burst is 41 * 4 tw contiguous bytes, fully used.
+// lines.  The lanes of such a wavefront work on different nodes (different rows) anyway, so nothing is gained by interleaving
+// instances at all: tw = 1, every instance's words contiguous -- a 41-word node burst is 164 contiguous bytes (two or three
+// lines instead of 41), a block record one line, a notification's hcbr words a few.
 // Inside the run kernel the tile base is wavefront-uniform (an SGPR pair) and a row access is `tile + u32 byte offset`,
 // i.e. the saddr + 32-bit voffset form of global_load/global_store: no 64-bit vector address arithmetic.
 #define LBFT_ROW_BYTES 256u  // kernel class 0 (tw = 64)
@@ -517,6 +519,7 @@ struct SimT {
   // 64-wide tiles addressed at compile time for the small-network classes (many lanes per wavefront); the large-network
   // classes address tiles of P.tw = lanes per wavefront (lbft_core.h "HBM layout")
   static constexpr bool TILE64 = CLS == 0 || CLS == 1 || CLS == 6;
+  static constexpr bool IMAJOR = BIG;  // large networks: tile width 1 = every instance's words contiguous (P.tw == 1), addressed at compile time
   static constexpr bool COOP = BIG;
   static constexpr bool RING = BIG || CLS == 3;
   bool coop_on;  // set by run_coop: the event loop is being run by a whole wavefront
@@ -605,21 +608,23 @@ struct SimT {
   LBFT_HD void attach_weights(const u32* w) { wtab = w; }
   LBFT_HD void attach_round_tables(const u8* leaders, u32 nl, const i64* durs, u32 nd) { leader_lds = leaders; leader_lds_len = nl; dur_lds = durs; dur_lds_len = nd; }
 
-  LBFT_HD u32 rsh() const { return TILE64 ? 8u : P.rsh; }  // log2(row bytes)
+  LBFT_HD u32 rsh() const { return TILE64 ? 8u : IMAJOR ? 2u : P.rsh; }  // log2(row bytes)
   // (a multiplication, not `w << P.rsh`: hipcc 7.2 dies on the variable shift in this address pattern -- "Illegal instruction
   // detected: V_CMP_NE_U32 0, $src_shared_base" --; rows and row bytes are below 2^24, a plain 32-bit multiply is what compiles)
   LBFT_HD static u32 mul24(u32 a, u32 b) { return a * b; }  // (__umul24 trips the same compiler bug)
-  LBFT_HD u32 rowb() const { return TILE64 ? 256u : 4u * P.tw; }  // bytes of a row
-  LBFT_HD u32 boff(u32 w) const { return TILE64 ? (w << 8) + lane4 : mul24(w, rowb()) + lane4; }  // tile-relative byte offset of row w (a tile is < 4 GiB)
+  LBFT_HD u32 rowb() const { return TILE64 ? 256u : IMAJOR ? 4u : 4u * P.tw; }  // bytes of a row
+  LBFT_HD u32 boff(u32 w) const { return TILE64 ? (w << 8) + lane4 : IMAJOR ? (w << 2) + lane4 : mul24(w, rowb()) + lane4; }  // tile-relative byte offset of row w (a tile is < 4 GiB)
   LBFT_HD u32 ld(u32 w) const { return *reinterpret_cast<const u32*>(tile + (size_t)boff(w)); }
   LBFT_HD void st(u32 w, u32 v) const { *reinterpret_cast<u32*>(tile + (size_t)boff(w)) = v; }
   // row (w0 + f) given boff(w0): groups of 16 rows share one 32-bit base, the rest is the instruction's immediate
   LBFT_HD u32 ldf(u32 base, u32 f) const {
     if (TILE64) return *reinterpret_cast<const u32*>(tile + (size_t)(base + (f & ~15u) * LBFT_ROW_BYTES) + (f & 15u) * LBFT_ROW_BYTES);
+    if (IMAJOR) return *reinterpret_cast<const u32*>(tile + (size_t)base + f * 4u);  // (consecutive fields: immediate offsets, wide loads)
     return *reinterpret_cast<const u32*>(tile + (size_t)(base + mul24(f, rowb())));
   }
   LBFT_HD void stf(u32 base, u32 f, u32 v) const {
     if (TILE64) *reinterpret_cast<u32*>(tile + (size_t)(base + (f & ~15u) * LBFT_ROW_BYTES) + (f & 15u) * LBFT_ROW_BYTES) = v;
+    else if (IMAJOR) *reinterpret_cast<u32*>(tile + (size_t)base + f * 4u) = v;
     else *reinterpret_cast<u32*>(tile + (size_t)(base + mul24(f, rowb()))) = v;
   }
 
@@ -2291,8 +2296,8 @@ struct SimT {
   //     bucket instead of one memory round trip per message.
   u32 bulk;       // leader lane: bit 0 = a broadcast is pending, bit 1 = a query-all is pending (set by send_loop)
   u32 bulk_node;  // leader lane: the node whose actions are being processed
-  LBFT_HD u32 ldc(u32 l4, u32 w) const { return *reinterpret_cast<const u32*>(tile + (size_t)(mul24(w, rowb()) + l4)); }
-  LBFT_HD void stc(u32 l4, u32 w, u32 v) const { *reinterpret_cast<u32*>(tile + (size_t)(mul24(w, rowb()) + l4)) = v; }
+  LBFT_HD u32 ldc(u32 l4, u32 w) const { return *reinterpret_cast<const u32*>(tile + (size_t)((IMAJOR ? (w << 2) : mul24(w, rowb())) + l4)); }
+  LBFT_HD void stc(u32 l4, u32 w, u32 v) const { *reinterpret_cast<u32*>(tile + (size_t)((IMAJOR ? (w << 2) : mul24(w, rowb())) + l4)) = v; }
   // the first try of sample_delay() on the draw `bits`: true = accepted (then d is the delay sample_delay() returns)
   LBFT_HD bool fast_delay(u64 bits, i64& d) const {
     if (P.delay_model == 1) {

@@ -106,13 +106,16 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
   // lpw divides 64, so a wavefront's instances share one tile: its base is wavefront-uniform (SGPRs) and
   // every row access is saddr + 32-bit voffset
   // (tile width tw: 64 for the small-network classes -- two 32-lane wavefronts share a tile --, otherwise tw == lpw: one tile per wavefront)
-  const u32 tw = SimT<CLS>::TILE64 ? 64u : p.tw;
+  const u32 tw = SimT<CLS>::TILE64 ? 64u : SimT<CLS>::IMAJOR ? 1u : p.tw;
   u32 tile_idx = __builtin_amdgcn_readfirstlane(((blockIdx.x * LBFT_RUN_WAVES + wave) * p.lpw) / tw);
   char* tile = reinterpret_cast<char*>(state) + (size_t)tile_idx * p.total_words * ((size_t)4 * tw);
   if constexpr (SimT<CLS>::COOP) {
     // Large networks: EVERY lane of the wavefront runs the event loop; the first lpw lanes carry a network each, all 64
     // cooperate on the bulk sends of those networks (SimT::run_coop / coop_bulk).
-    SimT<CLS> s(p, tile, ((active ? i : lane) & (tw - 1u)) * 4u, 0);
+    // (tw may be narrower than the lanes that carry a network: lane j's instance then sits j / tw tiles behind the wavefront's
+    // first tile -- folded into the lane's 32-bit column offset, the tile base stays wavefront-uniform)
+    const u32 li = active ? (i - ((blockIdx.x * LBFT_RUN_WAVES + wave) * p.lpw)) : (lane & (p.lpw - 1u));
+    SimT<CLS> s(p, tile, (li / tw) * (p.total_words * 4u * tw) + (li & (tw - 1u)) * 4u, 0);
     bool lead = false;
     if (active) lead = s.ld(I_DONE) == 0;
     s.attach_queue(keys, metas, p.lpw, p.ql);
@@ -943,11 +946,11 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
     while (lpw < want && lpw < 32) lpw <<= 1;
   }
   p.lpw = lpw;
-  // Tile width of the HBM layout (lbft_core.h "HBM layout"): 64 for the small-network classes 0 and 1, the lanes per wavefront for large networks
-  // (LBFT_TILE64=1: 64 everywhere, the round-1 layout, for A/B measurements)
+  // Tile width of the HBM layout (lbft_core.h "HBM layout"): 64 for the small-network classes 0 and 1, 1 (instance-major) for large networks
   {
-    u32 tw = sim_class(p) <= 1 ? 64u : lpw;
-    if (const char* e = getenv("LBFT_TILE64")) if (atoi(e)) tw = 64;
+    // Measured (16 384 x 64 nodes / 8 192 x 100 nodes / c4live): tw = 64: 652 ms / 3.63 s / --; tw = lanes per wavefront: 596 / 3.20 / 4.94 s;
+    // tw = 4: 555 / 3.17 / 4.43; tw = 2: 550 / 3.10 / 4.28; tw = 1: 541 ms / 3.05 s / 4.14 s -- the large-network kernels address tw = 1 at compile time.
+    u32 tw = sim_class(p) <= 1 ? 64u : 1u;
     p.tw = tw;
     p.rsh = 2;
     while ((4u << (p.rsh - 2)) < 4u * tw) p.rsh++;
