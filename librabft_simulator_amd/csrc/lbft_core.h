@@ -146,6 +146,14 @@ struct Params {
 #define LBFT_MARK(k) do { } while (0)
 #define LBFT_COUNT(k) do { } while (0)
 #endif
+// -DLBFT_COOP_PROF (with LBFT_PHASE_TIMERS): phases 6-10 measure the sub-phases of coop_bulk instead of update_node's
+#if defined(LBFT_COOP_PROF)
+#define LBFT_UMARK(k) do { } while (0)
+#define LBFT_CMARK(k) LBFT_MARK(k)
+#else
+#define LBFT_UMARK(k) LBFT_MARK(k)
+#define LBFT_CMARK(k) do { } while (0)
+#endif
 #if defined(LBFT_HOST_STATS) && !defined(__HIPCC__)
 extern unsigned long long lbft_host_stats[64];
 #define LBFT_STAT(k) (lbft_host_stats[k]++)
@@ -544,6 +552,7 @@ struct SimT {
   // round-switch trace: folded duplicate timers of time vd_time still "pop" in the reference until stamp vd_stamp
   u32 vd_time, vd_stamp;
   u64 snap_mask;  // scap <= 64: free snapshot slots as a bit set held in registers (no free-stack round trip)
+  u32 snap_hint;  // scap > 64: a free slot (+ 1) held back from the stack; returned to it when the launch ends
   u32 ev0, ev1, ev2, ev3;
   u32 n_fold, n_upd;  // duplicate timers folded instead of queued / update_node calls: what the device executes, as opposed to the
                       // reference-equivalent event counts ev0..ev3 (bench.py reports the roofline on both)
@@ -653,6 +662,7 @@ struct SimT {
     for (u32 f = 0; f < NF_FIXED_WORDS; f++) cw[f] = ldf(nb, f);
     cdirty = 0;
     ax_load(node);
+    cur_xk = wide() ? node >> 5 : 0u;
   }
   LBFT_HD void end_node(u32 node) const {
     ax_store(node);
@@ -717,9 +727,12 @@ struct SimT {
   };
   mutable u32 bc_id[LBFT_BLK_CACHE];
   mutable u32 bc_w[LBFT_BLK_CACHE][BC_WORDS];
+  // large networks: the cached records also keep one word triple of their node-set extension rows (the one of word index
+  // bc_xk, 0 = none): for n <= 64 that is the only extension word there is, so mask tests for nodes >= 32 stop costing a round trip
+  mutable u32 bc_x[LBFT_BLK_CACHE][3], bc_xk[LBFT_BLK_CACHE];
   mutable u32 bc_next, bc_ref;  // FIFO hand + "recently used" bits (second chance: a hot old block survives)
   LBFT_HD void blk_cache_reset() const {
-    for (u32 e = 0; e < LBFT_BLK_CACHE; e++) bc_id[e] = 0;
+    for (u32 e = 0; e < LBFT_BLK_CACHE; e++) { bc_id[e] = 0; bc_xk[e] = 0; bc_x[e][0] = bc_x[e][1] = bc_x[e][2] = 0; }
     bc_next = 0; bc_ref = 0;
   }
   LBFT_HD void blk_cache_insert(u32 b, const Blk& r) const {
@@ -745,6 +758,10 @@ struct SimT {
 #pragma unroll
 #endif
       for (u32 f = 0; f < BC_WORDS; f++) bc_w[e][f] = take ? r.w[f] : bc_w[e][f];
+      if (BIG) {
+        bc_xk[e] = take ? r.xk : bc_xk[e];
+        bc_x[e][0] = take ? r.x[0] : bc_x[e][0]; bc_x[e][1] = take ? r.x[1] : bc_x[e][1]; bc_x[e][2] = take ? r.x[2] : bc_x[e][2];
+      }
     }
     bc_next = bc_next + 1 == LBFT_BLK_CACHE ? 0 : bc_next + 1;
   }
@@ -768,6 +785,7 @@ struct SimT {
 #pragma unroll
 #endif
         for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = bc_w[e][f];
+        if (BIG) { r.xk = bc_xk[e]; r.x[0] = bc_x[e][0]; r.x[1] = bc_x[e][1]; r.x[2] = bc_x[e][2]; }
       }
     }
     LBFT_COUNT(26);
@@ -781,6 +799,10 @@ struct SimT {
 #pragma unroll
 #endif
       for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = ldf(bb, f);  // one burst of independent loads
+      if (BIG && LBFT_BX && cur_xk) {  // ... with the extension words the current event's node lives in
+        r.xk = cur_xk;
+        r.x[0] = ld(bxw(b, B_KNOWN, cur_xk)); r.x[1] = ld(bxw(b, B_QC, cur_xk)); r.x[2] = ld(bxw(b, B_PEND, cur_xk));
+      }
       LBFT_DRAIN_VMEM();
       LBFT_MARK(29);
       blk_cache_insert(b, r);
@@ -791,10 +813,22 @@ struct SimT {
   // only) in extension rows behind the cold fields.
   LBFT_HD u32 bxw(u32 b, u32 f, u32 k) const { return bfw(b, B_WORDS + (f - B_KNOWN) * (P.mw - 1) + k - 1); }
   // (one round trip for the three words of this record copy instead of one per test / update)
+  LBFT_HD void bx_cache_put(u32 b, const Blk& rb) const {  // the cached copy of block b (if any) takes rb's extension words
+    if (!BIG) return;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 e = 0; e < LBFT_BLK_CACHE; e++) {  // (value selects: see blk_cache_insert)
+      bool hit = bc_id[e] == b;
+      bc_xk[e] = hit ? rb.xk : bc_xk[e];
+      bc_x[e][0] = hit ? rb.x[0] : bc_x[e][0]; bc_x[e][1] = hit ? rb.x[1] : bc_x[e][1]; bc_x[e][2] = hit ? rb.x[2] : bc_x[e][2];
+    }
+  }
   LBFT_HD void bx_fetch(u32 b, const Blk& rb, u32 k) const {
     if (rb.xk == k) return;
     rb.x[0] = ld(bxw(b, B_KNOWN, k)); rb.x[1] = ld(bxw(b, B_QC, k)); rb.x[2] = ld(bxw(b, B_PEND, k));
     rb.xk = k;
+    bx_cache_put(b, rb);
   }
   LBFT_HD bool bm_test(u32 b, const Blk& rb, u32 f, u32 node) const {
     if (!wide() || node < 32) return (rb.w[f] >> node) & 1u;
@@ -811,6 +845,7 @@ struct SimT {
     bx_fetch(b, rb, node >> 5);
     rb.x[f - B_KNOWN] |= 1u << (node & 31u);
     st(bxw(b, f, node >> 5), rb.x[f - B_KNOWN]);
+    bx_cache_put(b, rb);
 #else
     { u32 w = bxw(b, f, node >> 5); st(w, ld(w) | (1u << (node & 31u))); }
 #endif
@@ -821,6 +856,7 @@ struct SimT {
     bx_fetch(b, rb, node >> 5);
     rb.x[f - B_KNOWN] &= ~(1u << (node & 31u));
     st(bxw(b, f, node >> 5), rb.x[f - B_KNOWN]);
+    bx_cache_put(b, rb);
 #else
     { u32 w = bxw(b, f, node >> 5); st(w, ld(w) & ~(1u << (node & 31u))); }
 #endif
@@ -854,11 +890,12 @@ struct SimT {
     last_node = ld(I_LAST_NODE); vd_time = ld(I_VD_TIME); vd_stamp = ld(I_VD_STAMP);
     cal_cursor = ld(I_CAL_CURSOR); cal_free = ld(I_CAL_FREE); cal_bump = ld(I_CAL_BUMP);
     n_fold = ld(I_NFOLD); n_upd = ld(I_NUPD);
-    sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0;
+    sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0; snap_hint = 0;
     if (RING) { rng.rhead = ld(I_RING_HEAD); rng.rcnt = ld(I_RING_CNT); }
     blk_cache_reset();
   }
   LBFT_HD void store_scalars(bool done) {
+    if (snap_hint) { st(P.off_snap_free + snap_free, snap_hint - 1); snap_free++; snap_hint = 0; }
     st(I_CLOCK, (u32)clock); st(I_STAMP, stamp);
     st(I_RNG0, (u32)rng.s0); st(I_RNG1, (u32)(rng.s0 >> 32)); st(I_RNG2, (u32)rng.s1); st(I_RNG3, (u32)(rng.s1 >> 32));
     st(I_RNG4, (u32)rng.s2); st(I_RNG5, (u32)(rng.s2 >> 32)); st(I_RNG6, (u32)rng.s3); st(I_RNG7, (u32)(rng.s3 >> 32));
@@ -1142,8 +1179,11 @@ struct SimT {
     return (u32)__builtin_popcountll(x);
 #endif
   }
+  // (scap > 64: the free slots are a stack in HBM rows; the most recently freed slot is kept in a register -- snap_hint, slot + 1 --
+  // and handed out first, so that the usual release-then-allocate of a request / response event reads no stack row)
   LBFT_HD void snap_free_slot(u32 slot) {
     if (P.scap <= 64) snap_mask |= 1ULL << slot;
+    else if (snap_hint == 0) snap_hint = slot + 1;
     else { st(P.off_snap_free + snap_free, slot); snap_free++; }
   }
   LBFT_HD i32 snap_alloc() {
@@ -1152,6 +1192,13 @@ struct SimT {
       u32 slot = ctz64(snap_mask);
       snap_mask &= snap_mask - 1;
       u32 live = P.scap - popc64(snap_mask);
+      if (live > maxsnap) maxsnap = live;
+      return (i32)slot;
+    }
+    if (snap_hint) {
+      u32 slot = snap_hint - 1;
+      snap_hint = 0;
+      u32 live = P.scap - snap_free;
       if (live > maxsnap) maxsnap = live;
       return (i32)slot;
     }
@@ -1483,7 +1530,7 @@ struct SimT {
     u32 b = ++nblocks;
     u32 base = prev_blk ? prev_blk : nf(node, NF_INIT_STATE_BLK);
     Blk rb;
-    rb.xk = 0; rb.x[0] = rb.x[1] = rb.x[2] = 0;
+    rb.xk = (BIG && LBFT_BX) ? cur_xk : 0u; rb.x[0] = rb.x[1] = rb.x[2] = 0;  // a new block: nobody knows it yet
     rb.w[B_ROUND] = nf(node, NF_CUR_ROUND);
     rb.w[B_LINK] = prev_blk | (node << 16);
     rb.w[B_PREV_ROUND] = 0; rb.w[B_PP] = 0; rb.w[B_PP_ROUND] = 0; rb.w[B_DEPTH] = 1;
@@ -1695,7 +1742,7 @@ struct SimT {
   LBFT_HD Actions update_node(u32 node, i64 lclock) {
     i64 lqat = (i64)(i32)nf(node, NF_LQAT);
     PmActions pa = update_pacemaker(node, lqat, lclock);
-    LBFT_MARK(6);
+    LBFT_UMARK(6);
     Actions act;
     act.next = pa.next; act.send_to = pa.send_to; act.broadcast = pa.broadcast; act.query_all = pa.query_all;
     // process_pacemaker_actions (node.rs:179-202)
@@ -1713,7 +1760,7 @@ struct SimT {
       // current proposed block, so the twin of an equivocator's own proposal is always "proposed block - 1"
       if (is_equivocator(node)) propose_block(node, pa.propose_prev, lclock);
     }
-    LBFT_MARK(7);
+    LBFT_UMARK(7);
     // vote
     u32 pb = proposed_block(node);
     if (pb) {
@@ -1730,9 +1777,9 @@ struct SimT {
         if (create_vote(node, pb, rpb)) act.send_to = (i32)rpb.author();
       }
     }
-    LBFT_MARK(8);
+    LBFT_UMARK(8);
     if (check_for_new_qc(node)) { LBFT_STAT(10); act.broadcast = true; act.next = lclock; }
-    LBFT_MARK(9);
+    LBFT_UMARK(9);
     process_commits(node);
     LBFT_MARK(27);
     bool tq; i64 tnext;
@@ -1740,7 +1787,7 @@ struct SimT {
     act.query_all = act.query_all || tq;
     if (tnext < act.next) act.next = tnext;
     if (act.query_all) nfs(node, NF_LQAT, (u32)(i32)lclock);
-    LBFT_MARK(10);
+    LBFT_UMARK(10);
     return act;
   }
 
@@ -2338,6 +2385,7 @@ struct SimT {
     }
     const u32 equivocal = LBFT_UNI(eq_k, k);
     const i32 rs = (i32)LBFT_UNI(rs_k, k);
+    LBFT_CMARK(6);  // leader's prework
     // ---- receivers in index order, then SliceRandom::shuffle: for i = cnt - 1 .. 1: swap(i, gen_range_u32(i + 1)) ----
     PL<u32> perm0, perm1;  // entry i of the list: lane i of perm0 (i < 64) / lane i - 64 of perm1
     LBFT_FOR_LANES(l) { perm0[l] = l < node ? l : l + 1u; perm1[l] = 64u + l < node ? 64u + l : 65u + l; }
@@ -2445,6 +2493,7 @@ struct SimT {
         if (need_t && st_ >= 0) coop_copy_hcbr(k, l4, node, (u32)st_);
         if (need_r && sr >= 0) coop_copy_hcbr(k, l4, node, (u32)sr);
         LBFT_FOR_LANES(l) if (live[l] && (twin[l] ? st_ < 0 : sr < 0)) live[l] = 0;  // no slot: not scheduled, the stamp is consumed
+        LBFT_CMARK(7);  // snapshot(s)
       } else if (rs < 0) {
         LBFT_FOR_LANES(l) live[l] = 0;
       }
@@ -2472,6 +2521,7 @@ struct SimT {
             stc(l4, P.off_qmeta + s1[l] - 1u, meta);
           }
         }
+        LBFT_CMARK(8);  // slots + meta
         // lanes whose messages share a bucket (same time; the kind is common): M; sharing a bitmap word (same time >> 3): M3
         PL<u64> M, M3;
         LBFT_FOR_LANES(l) { M[l] = live[l] ? L : 0; M3[l] = M[l]; }
@@ -2490,6 +2540,7 @@ struct SimT {
           succ_lane[l] = upper ? ctz64(upper) : l;
         }
         pl_shfl(succ_slot, s1, succ_lane);
+        LBFT_CMARK(9);  // grouping
         PL<u32> tl;
         LBFT_FOR_LANES(l) {
           tl[l] = 0;
@@ -2510,6 +2561,7 @@ struct SimT {
             if (!has_succ[l]) stc(l4, P.off_cal_tail + idx, s1[l]);
           }
         }
+        LBFT_CMARK(10);  // links, heads, tails
         const u64 NB = pl_ballot(needbit);
         if (NB) {  // occupancy bits of buckets that were empty: one read-modify-write per bitmap word
           PL<u32> bits;
@@ -2610,7 +2662,7 @@ struct SimT {
     for (u32 w = 0; w < I_WORDS; w++) st(w, 0);
     clock = 0; stamp = 0; qlen = 0; nblocks = 0; fault = 0; maxq = 0; maxsnap = 0;
     ev0 = ev1 = ev2 = ev3 = 0; n_fold = 0; n_upd = 0;
-    sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0;
+    sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0; snap_hint = 0;
     blk_cache_reset();
     snap_free = P.scap;
     snap_mask = P.scap >= 64 ? ~0ULL : ((1ULL << P.scap) - 1);
