@@ -552,7 +552,6 @@ struct SimT {
   // round-switch trace: folded duplicate timers of time vd_time still "pop" in the reference until stamp vd_stamp
   u32 vd_time, vd_stamp;
   u64 snap_mask;  // scap <= 64: free snapshot slots as a bit set held in registers (no free-stack round trip)
-  u32 snap_hint;  // scap > 64: a free slot (+ 1) held back from the stack; returned to it when the launch ends
   u32 ev0, ev1, ev2, ev3;
   u32 n_fold, n_upd;  // duplicate timers folded instead of queued / update_node calls: what the device executes, as opposed to the
                       // reference-equivalent event counts ev0..ev3 (bench.py reports the roofline on both)
@@ -662,7 +661,6 @@ struct SimT {
     for (u32 f = 0; f < NF_FIXED_WORDS; f++) cw[f] = ldf(nb, f);
     cdirty = 0;
     ax_load(node);
-    cur_xk = wide() ? node >> 5 : 0u;
   }
   LBFT_HD void end_node(u32 node) const {
     ax_store(node);
@@ -727,12 +725,9 @@ struct SimT {
   };
   mutable u32 bc_id[LBFT_BLK_CACHE];
   mutable u32 bc_w[LBFT_BLK_CACHE][BC_WORDS];
-  // large networks: the cached records also keep one word triple of their node-set extension rows (the one of word index
-  // bc_xk, 0 = none): for n <= 64 that is the only extension word there is, so mask tests for nodes >= 32 stop costing a round trip
-  mutable u32 bc_x[LBFT_BLK_CACHE][3], bc_xk[LBFT_BLK_CACHE];
   mutable u32 bc_next, bc_ref;  // FIFO hand + "recently used" bits (second chance: a hot old block survives)
   LBFT_HD void blk_cache_reset() const {
-    for (u32 e = 0; e < LBFT_BLK_CACHE; e++) { bc_id[e] = 0; bc_xk[e] = 0; bc_x[e][0] = bc_x[e][1] = bc_x[e][2] = 0; }
+    for (u32 e = 0; e < LBFT_BLK_CACHE; e++) bc_id[e] = 0;
     bc_next = 0; bc_ref = 0;
   }
   LBFT_HD void blk_cache_insert(u32 b, const Blk& r) const {
@@ -758,10 +753,6 @@ struct SimT {
 #pragma unroll
 #endif
       for (u32 f = 0; f < BC_WORDS; f++) bc_w[e][f] = take ? r.w[f] : bc_w[e][f];
-      if (BIG) {
-        bc_xk[e] = take ? r.xk : bc_xk[e];
-        bc_x[e][0] = take ? r.x[0] : bc_x[e][0]; bc_x[e][1] = take ? r.x[1] : bc_x[e][1]; bc_x[e][2] = take ? r.x[2] : bc_x[e][2];
-      }
     }
     bc_next = bc_next + 1 == LBFT_BLK_CACHE ? 0 : bc_next + 1;
   }
@@ -785,7 +776,6 @@ struct SimT {
 #pragma unroll
 #endif
         for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = bc_w[e][f];
-        if (BIG) { r.xk = bc_xk[e]; r.x[0] = bc_x[e][0]; r.x[1] = bc_x[e][1]; r.x[2] = bc_x[e][2]; }
       }
     }
     LBFT_COUNT(26);
@@ -799,10 +789,6 @@ struct SimT {
 #pragma unroll
 #endif
       for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = ldf(bb, f);  // one burst of independent loads
-      if (BIG && LBFT_BX && cur_xk) {  // ... with the extension words the current event's node lives in
-        r.xk = cur_xk;
-        r.x[0] = ld(bxw(b, B_KNOWN, cur_xk)); r.x[1] = ld(bxw(b, B_QC, cur_xk)); r.x[2] = ld(bxw(b, B_PEND, cur_xk));
-      }
       LBFT_DRAIN_VMEM();
       LBFT_MARK(29);
       blk_cache_insert(b, r);
@@ -813,22 +799,10 @@ struct SimT {
   // only) in extension rows behind the cold fields.
   LBFT_HD u32 bxw(u32 b, u32 f, u32 k) const { return bfw(b, B_WORDS + (f - B_KNOWN) * (P.mw - 1) + k - 1); }
   // (one round trip for the three words of this record copy instead of one per test / update)
-  LBFT_HD void bx_cache_put(u32 b, const Blk& rb) const {  // the cached copy of block b (if any) takes rb's extension words
-    if (!BIG) return;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (u32 e = 0; e < LBFT_BLK_CACHE; e++) {  // (value selects: see blk_cache_insert)
-      bool hit = bc_id[e] == b;
-      bc_xk[e] = hit ? rb.xk : bc_xk[e];
-      bc_x[e][0] = hit ? rb.x[0] : bc_x[e][0]; bc_x[e][1] = hit ? rb.x[1] : bc_x[e][1]; bc_x[e][2] = hit ? rb.x[2] : bc_x[e][2];
-    }
-  }
   LBFT_HD void bx_fetch(u32 b, const Blk& rb, u32 k) const {
     if (rb.xk == k) return;
     rb.x[0] = ld(bxw(b, B_KNOWN, k)); rb.x[1] = ld(bxw(b, B_QC, k)); rb.x[2] = ld(bxw(b, B_PEND, k));
     rb.xk = k;
-    bx_cache_put(b, rb);
   }
   LBFT_HD bool bm_test(u32 b, const Blk& rb, u32 f, u32 node) const {
     if (!wide() || node < 32) return (rb.w[f] >> node) & 1u;
@@ -845,7 +819,6 @@ struct SimT {
     bx_fetch(b, rb, node >> 5);
     rb.x[f - B_KNOWN] |= 1u << (node & 31u);
     st(bxw(b, f, node >> 5), rb.x[f - B_KNOWN]);
-    bx_cache_put(b, rb);
 #else
     { u32 w = bxw(b, f, node >> 5); st(w, ld(w) | (1u << (node & 31u))); }
 #endif
@@ -856,7 +829,6 @@ struct SimT {
     bx_fetch(b, rb, node >> 5);
     rb.x[f - B_KNOWN] &= ~(1u << (node & 31u));
     st(bxw(b, f, node >> 5), rb.x[f - B_KNOWN]);
-    bx_cache_put(b, rb);
 #else
     { u32 w = bxw(b, f, node >> 5); st(w, ld(w) & ~(1u << (node & 31u))); }
 #endif
@@ -890,12 +862,11 @@ struct SimT {
     last_node = ld(I_LAST_NODE); vd_time = ld(I_VD_TIME); vd_stamp = ld(I_VD_STAMP);
     cal_cursor = ld(I_CAL_CURSOR); cal_free = ld(I_CAL_FREE); cal_bump = ld(I_CAL_BUMP);
     n_fold = ld(I_NFOLD); n_upd = ld(I_NUPD);
-    sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0; snap_hint = 0;
+    sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0;
     if (RING) { rng.rhead = ld(I_RING_HEAD); rng.rcnt = ld(I_RING_CNT); }
     blk_cache_reset();
   }
   LBFT_HD void store_scalars(bool done) {
-    if (snap_hint) { st(P.off_snap_free + snap_free, snap_hint - 1); snap_free++; snap_hint = 0; }
     st(I_CLOCK, (u32)clock); st(I_STAMP, stamp);
     st(I_RNG0, (u32)rng.s0); st(I_RNG1, (u32)(rng.s0 >> 32)); st(I_RNG2, (u32)rng.s1); st(I_RNG3, (u32)(rng.s1 >> 32));
     st(I_RNG4, (u32)rng.s2); st(I_RNG5, (u32)(rng.s2 >> 32)); st(I_RNG6, (u32)rng.s3); st(I_RNG7, (u32)(rng.s3 >> 32));
@@ -1179,11 +1150,8 @@ struct SimT {
     return (u32)__builtin_popcountll(x);
 #endif
   }
-  // (scap > 64: the free slots are a stack in HBM rows; the most recently freed slot is kept in a register -- snap_hint, slot + 1 --
-  // and handed out first, so that the usual release-then-allocate of a request / response event reads no stack row)
   LBFT_HD void snap_free_slot(u32 slot) {
     if (P.scap <= 64) snap_mask |= 1ULL << slot;
-    else if (snap_hint == 0) snap_hint = slot + 1;
     else { st(P.off_snap_free + snap_free, slot); snap_free++; }
   }
   LBFT_HD i32 snap_alloc() {
@@ -1192,13 +1160,6 @@ struct SimT {
       u32 slot = ctz64(snap_mask);
       snap_mask &= snap_mask - 1;
       u32 live = P.scap - popc64(snap_mask);
-      if (live > maxsnap) maxsnap = live;
-      return (i32)slot;
-    }
-    if (snap_hint) {
-      u32 slot = snap_hint - 1;
-      snap_hint = 0;
-      u32 live = P.scap - snap_free;
       if (live > maxsnap) maxsnap = live;
       return (i32)slot;
     }
@@ -1530,7 +1491,7 @@ struct SimT {
     u32 b = ++nblocks;
     u32 base = prev_blk ? prev_blk : nf(node, NF_INIT_STATE_BLK);
     Blk rb;
-    rb.xk = (BIG && LBFT_BX) ? cur_xk : 0u; rb.x[0] = rb.x[1] = rb.x[2] = 0;  // a new block: nobody knows it yet
+    rb.xk = 0; rb.x[0] = rb.x[1] = rb.x[2] = 0;
     rb.w[B_ROUND] = nf(node, NF_CUR_ROUND);
     rb.w[B_LINK] = prev_blk | (node << 16);
     rb.w[B_PREV_ROUND] = 0; rb.w[B_PP] = 0; rb.w[B_PP_ROUND] = 0; rb.w[B_DEPTH] = 1;
@@ -2662,7 +2623,7 @@ struct SimT {
     for (u32 w = 0; w < I_WORDS; w++) st(w, 0);
     clock = 0; stamp = 0; qlen = 0; nblocks = 0; fault = 0; maxq = 0; maxsnap = 0;
     ev0 = ev1 = ev2 = ev3 = 0; n_fold = 0; n_upd = 0;
-    sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0; snap_hint = 0;
+    sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0;
     blk_cache_reset();
     snap_free = P.scap;
     snap_mask = P.scap >= 64 ? ~0ULL : ((1ULL << P.scap) - 1);
