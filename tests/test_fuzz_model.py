@@ -72,6 +72,24 @@ def test_random_configurations_match_the_oracle(oracle, chunk):
                 assert (got[:, 2] == ref["qc_hash"]).all() and ((got[:, 3] >> 32) == 0).all() and ref["has_qc"].all(), kw
 
 
+def draw_large_config(rng):
+    kw = draw_config(rng)
+    n = int(rng.choice([33, 36, 40, 48, 64, 65, 66, 80, 100, 128]))
+    kw["num_nodes"] = n
+    for k in ("voting_rights", "equivocate_every", "partition_size", "partition_start", "partition_end", "rights_rotation"):
+        kw.pop(k, None)
+    if rng.random() < 0.4:
+        kw["voting_rights"] = [int(v) for v in rng.integers(1, 6, n)]
+        if "commands_per_epoch" in kw and rng.random() < 0.6:
+            kw["rights_rotation"] = int(rng.integers(1, n))
+    if rng.random() < 0.4:
+        kw["equivocate_every"] = int(rng.integers(2, 9))
+    if rng.random() < 0.5:
+        kw.pop("drop_per_million", None)
+    max_clock = int(rng.choice([120, 200, 260])) if n <= 66 else 130
+    return kw, n, max_clock
+
+
 @pytest.mark.parametrize("chunk", range(8))
 def test_random_large_configurations_on_the_cooperative_loop(oracle, chunk):
     """The same generator for networks of 33..128 nodes, run through the cooperative event loop of the large-network kernels
@@ -79,20 +97,7 @@ def test_random_large_configurations_on_the_cooperative_loop(oracle, chunk):
     partitions, all quirk modes.  (Random message loss keeps the lane-per-network loop: coop() excludes it.)"""
     rng = np.random.default_rng(90210 + chunk)
     for _ in range(5):
-        kw = draw_config(rng)
-        n = int(rng.choice([33, 36, 40, 48, 64, 65, 66, 80, 100, 128]))
-        kw["num_nodes"] = n
-        for k in ("voting_rights", "equivocate_every", "partition_size", "partition_start", "partition_end", "rights_rotation"):
-            kw.pop(k, None)
-        if rng.random() < 0.4:
-            kw["voting_rights"] = [int(v) for v in rng.integers(1, 6, n)]
-            if "commands_per_epoch" in kw and rng.random() < 0.6:
-                kw["rights_rotation"] = int(rng.integers(1, n))
-        if rng.random() < 0.4:
-            kw["equivocate_every"] = int(rng.integers(2, 9))
-        if rng.random() < 0.5:
-            kw.pop("drop_per_million", None)
-        max_clock = int(rng.choice([120, 200, 260])) if n <= 66 else 130
+        kw, n, max_clock = draw_large_config(rng)
         seeds = rng.integers(1, 2 ** 62, 1, dtype=np.uint64)
         cfg = oracle.make_config(math_mode=1, **kw)
         a = oracle.run_batch(cfg, seeds, max_clock, threads=4, history_cap=64)
@@ -141,3 +146,37 @@ def test_random_configurations_on_the_device_match_the_oracle(oracle, chunk):
         c, rc = res.counters, ref["counters"]
         for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
             assert c[key] == rc[key], (key, kw)
+
+
+# the same for networks of 33..128 nodes: the cooperative large-network kernel (lanes per wavefront 1..32, multi-launch)
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_LARGE_CHUNKS", "3"))))
+def test_random_large_configurations_on_the_device_match_the_oracle(oracle, chunk):
+    import librabft_simulator_amd as amd
+    rng = np.random.default_rng(4242 + chunk)
+    for _ in range(4):
+        kw, n, max_clock = draw_large_config(rng)
+        m = int(rng.choice([1, 3, 20]))
+        seeds = rng.integers(1, 2 ** 62, m, dtype=np.uint64)
+        ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds, max_clock, threads=8, history_cap=64)
+        delay = amd.RandomDelay.uniform(kw["uniform_lo"], kw["uniform_hi"]) if kw.get("delay_model") == 1 else \
+            amd.RandomDelay.new(kw.get("mean", 10.0), kw.get("variance", 4.0))
+        nc = amd.NodeConfig(kw.get("target_commit_interval", 100000), kw.get("delta", 20), kw.get("gamma", 2.0), kw.get("lambda_", 0.5))
+        sim = amd.BatchSimulator.new(seeds, n, delay, nc, commands_per_epoch=kw.get("commands_per_epoch", 30000),
+                                     voting_rights=kw.get("voting_rights"), equivocate_every=kw.get("equivocate_every", 0),
+                                     drop_per_million=kw.get("drop_per_million", 0), quirks=kw.get("quirks", 0),
+                                     rights_rotation=kw.get("rights_rotation", 0),
+                                     calendar_queue=bool(rng.random() < 0.8), max_steps_per_launch=int(rng.choice([0, 0, 997])),
+                                     lanes_per_wavefront=int(rng.choice([0, 0, 1, 4, 32])), block_capacity=max_clock + 64,
+                                     queue_capacity=max(8192, 32 * n * n),
+                                     snapshot_capacity=min(65535, 6 * n * n + 16 * n) if kw.get("quirks", 0) & 1 else 128 * n)
+        res = sim.loop_until(max_clock, allow_faults=True)
+        assert not res.faults.any(), (kw, sorted(set(int(f) for f in res.faults)), res.counters, sim.layout())
+        assert (res.commit_counts == ref["commit_counts"]).all(), kw
+        assert (res.active_rounds == ref["active_rounds"]).all(), kw
+        assert (res.last_committed_states == ref["last_states"]).all(), kw
+        assert (res.committed_histories(64) == ref["histories"]).all(), kw
+        c, rc = res.counters, ref["counters"]
+        for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
+            assert c[key] == rc[key], (key, kw)
+        sim.close()

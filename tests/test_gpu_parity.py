@@ -356,10 +356,21 @@ def test_checkpoint_resume_equals_uninterrupted_run(amd, oracle, tmp_path):
             break
     assert launches >= 2
     assert_equal_to_oracle(oracle, res, kw, seeds, max_clock)
-    # a checkpoint does not load into a differently configured batch
-    sim3 = amd.BatchSimulator.new(seeds, 5, amd.RandomDelay.new(10.0, 4.0))
-    with pytest.raises(amd.LbftError):
-        sim3.load_checkpoint(path)
+    # a checkpoint does not load into a differently configured batch: node count, protocol mode (quirks), fault model (loss,
+    # partition, equivocators), rotating rights, delay model -- everything that changes the meaning or the encoding of the state
+    # words (a class-0 checkpoint holds packed one-word queue entries; a lossy / quirks batch runs another kernel class)
+    others = [dict(num_nodes=5), dict(quirks=1), dict(quirks=2), dict(drop_per_million=1000), dict(partition=(2, 0, 100)), dict(equivocate_every=2),
+              dict(voting_rights=[1, 2, 3, 4], rights_rotation=1), dict(commands_per_epoch=7), dict(variance=9.0)]
+    for o in others:
+        o = dict(o)
+        n = o.pop("num_nodes", 4)
+        delay = amd.RandomDelay.new(10.0, o.pop("variance", 4.0))
+        sim3 = amd.BatchSimulator.new(seeds, n, delay, **o)
+        with pytest.raises(amd.LbftError):
+            sim3.load_checkpoint(path)
+        res3 = sim3.loop_until(200)  # ... and the refused load left the batch usable with its own capacities
+        assert not res3.faults.any()
+        sim3.close()
 
 
 def _prefix_consistent(cc, hist):
