@@ -80,26 +80,33 @@ def measured_traffic_gb():
 
 
 def cpu_baseline(args, nodes, max_clock):
-    """The CPU oracle ("port": C++ restatement of the reference, not the Rust binary) on the host cores,
-    bounded sample of the same workload."""
+    """The CPU oracle ("port": C++ restatement of the reference, not the Rust binary -- no Rust toolchain in this image) on the
+    host cores, bounded sample of the same workload.  `value` is measured with the oracle also paying what the reference pays
+    around the protocol logic on every processed event (reference_overheads: bincode of the whole NodeState = save_node,
+    simulator.rs:307-309, and a deep clone of the notification per receiver, :348-354); the bare protocol logic is reported
+    beside it."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle_ctypes as oc
     cores = os.cpu_count() or 1
-    cfg = oc.make_config(num_nodes=nodes, math_mode=1)
-    probe = 8 * cores
-    t0 = time.perf_counter()
-    oc.run_batch(cfg, np.arange(args.base_seed, args.base_seed + probe, dtype=np.uint64), max_clock, threads=cores)
-    dt = max(time.perf_counter() - t0, 1e-3)
-    m = int(min(max(probe, probe * args.cpu_seconds / dt), 65536))
-    seeds = np.arange(args.base_seed, args.base_seed + m, dtype=np.uint64)
-    t0 = time.perf_counter()
-    r = oc.run_batch(cfg, seeds, max_clock, threads=cores)
-    dt = time.perf_counter() - t0
-    c = r["counters"]
+
+    def timed(reference_overheads, seconds):
+        cfg = oc.make_config(num_nodes=nodes, math_mode=1, reference_overheads=reference_overheads)
+        probe = 8 * cores
+        t0 = time.perf_counter()
+        oc.run_batch(cfg, np.arange(args.base_seed, args.base_seed + probe, dtype=np.uint64), max_clock, threads=cores)
+        dt = max(time.perf_counter() - t0, 1e-3)
+        m = int(min(max(probe, probe * seconds / dt), 65536))
+        seeds = np.arange(args.base_seed, args.base_seed + m, dtype=np.uint64)
+        t0 = time.perf_counter()
+        r = oc.run_batch(cfg, seeds, max_clock, threads=cores)
+        return r["counters"], time.perf_counter() - t0, m
+
+    c, dt, m = timed(1, args.cpu_seconds)
+    cb, dtb, mb = timed(0, args.cpu_seconds / 2)
     # BASELINE.json configs[0], the reference's own CPU-runnable case: 1 instance x 3 nodes, fixed delay 10 (mean 10, variance 0),
     # ~100 rounds (max_clock 2800), one thread
-    c1cfg = oc.make_config(num_nodes=3, mean=10.0, variance=0.0, math_mode=1)
+    c1cfg = oc.make_config(num_nodes=3, mean=10.0, variance=0.0, math_mode=1, reference_overheads=1)
     t1 = time.perf_counter()
     reps = 0
     while time.perf_counter() - t1 < 0.5:
@@ -109,8 +116,11 @@ def cpu_baseline(args, nodes, max_clock):
     return {
         "c1_single_thread_rounds_per_s": c1,
         "value": c["rounds"] / dt, "unit": "rounds/s", "cores": cores, "kind": "port",
-        "sample": "%d instances x %d nodes, LogNormal(10,4), max_clock %d, %d host threads, %.1f s" % (m, nodes, max_clock, cores, dt),
+        "sample": "%d instances x %d nodes, LogNormal(10,4), max_clock %d, %d host threads, %.1f s; C++ port of the reference incl. its per-event "
+                  "save_node serialisation (%.0f MB) and per-receiver notification clones" % (m, nodes, max_clock, cores, dt, c["saved_bytes"] / 1e6),
         "events_per_s": sum(c["events"]) / dt, "commits_per_s": c["commits"] / dt,
+        "protocol_logic_only": {"value": cb["rounds"] / dtb, "events_per_s": sum(cb["events"]) / dtb,
+                                "sample": "%d instances, %.1f s, without save_node / clones" % (mb, dtb)},
     }
 
 

@@ -1129,6 +1129,8 @@ struct SimNode {  // :53-59
 
 }  // namespace
 
+static size_t node_state_image_size(const NodeState& n);  // bincode::serialize(&NodeState) (defined with lbft_oracle_save_node)
+
 struct lbft_oracle_sim {
   lbft_oracle_config cfg;
   std::vector<u64> rights;
@@ -1197,7 +1199,9 @@ struct lbft_oracle_sim {
   }
   void process_node_actions(i64 clk, Author author, const NodeUpdateActions& actions) {  // :296-378
     SimNode& node = nodes[author];
-    // save_node: semantic no-op inside a run (node.rs:233-238)
+    // save_node: a semantic no-op inside a run (node.rs:233-238), but the reference pays for it on every processed event
+    // (simulator.rs:307-309: bincode of the whole NodeState); reference_overheads = 1 pays it too, for an honest CPU baseline
+    if (cfg.reference_overheads) counters.saved_bytes += node_state_image_size(node.node);
     i64 new_scheduled_time = std::max(add_time(actions.next_scheduled_update, node.startup_time), clk + 1);
     node.ignore_scheduled_updates_until = new_scheduled_time - 1;
     {
@@ -1218,6 +1222,7 @@ struct lbft_oracle_sim {
     for (Author r : receivers) {
       Event ev{0, 0, 0};
       ev.sender = author; ev.receiver = r; ev.notification = (alt && r % 2 == 0) ? alt : notification;
+      if (cfg.reference_overheads) ev.notification = std::make_shared<Notification>(*ev.notification);  // notification.clone() per receiver (simulator.rs:348-354)
       schedule_network_event(ev);
     }
     std::vector<Author> senders;
@@ -1433,10 +1438,8 @@ struct Bin {
   }
 };
 }  // namespace
-size_t lbft_oracle_save_node(const lbft_oracle_sim* sim, uint32_t node, uint8_t* out, size_t cap) {
-  if (!sim || node >= sim->nodes.size()) return 0;
-  const NodeState& n = sim->nodes[node].node;
-  Bin w;
+extern "C++" {
+static void node_state_image(const NodeState& n, Bin& w) {
   w.store(*n.record_store);
   const PacemakerState& pm = n.pacemaker;  // PacemakerState (pacemaker.rs:60-77)
   w.u64v(pm.active_epoch); w.u64v(pm.active_round);
@@ -1446,6 +1449,13 @@ size_t lbft_oracle_save_node(const lbft_oracle_sim* sim, uint32_t node, uint8_t*
   w.u64v(n.tracker.epoch_id); w.u64v(n.tracker.highest_committed_round); w.i64v(n.tracker.latest_commit_time); w.i64v(n.tracker.target_commit_interval);
   w.u64v(n.past_record_stores.size());
   for (auto& kv : n.past_record_stores) { w.u64v(kv.first); w.store(*kv.second); }
+}
+static size_t node_state_image_size(const NodeState& n) { Bin w; node_state_image(n, w); return w.b.size(); }
+}  // extern "C++"
+size_t lbft_oracle_save_node(const lbft_oracle_sim* sim, uint32_t node, uint8_t* out, size_t cap) {
+  if (!sim || node >= sim->nodes.size()) return 0;
+  Bin w;
+  node_state_image(sim->nodes[node].node, w);
   if (out && cap >= w.b.size()) memcpy(out, w.b.data(), w.b.size());
   return w.b.size();
 }
@@ -1580,7 +1590,7 @@ int lbft_oracle_run_batch(const lbft_oracle_config* cfg, const uint64_t* seeds, 
         const lbft_oracle_counters& c = sim->counters;
         for (int k = 0; k < 4; k++) p.events[k] += c.events[k];
         p.rng_draws += c.rng_draws; p.rounds += c.rounds; p.commits += c.commits;
-        p.response_inserts += c.response_inserts; p.events_scheduled += c.events_scheduled;
+        p.response_inserts += c.response_inserts; p.events_scheduled += c.events_scheduled; p.saved_bytes += c.saved_bytes;
         p.max_queue = std::max(p.max_queue, c.max_queue);
         lbft_oracle_destroy(sim);
       }
@@ -1595,7 +1605,7 @@ int lbft_oracle_run_batch(const lbft_oracle_config* cfg, const uint64_t* seeds, 
     for (auto& p : partial) {
       for (int k = 0; k < 4; k++) counters->events[k] += p.events[k];
       counters->rng_draws += p.rng_draws; counters->rounds += p.rounds; counters->commits += p.commits;
-      counters->response_inserts += p.response_inserts; counters->events_scheduled += p.events_scheduled;
+      counters->response_inserts += p.response_inserts; counters->events_scheduled += p.events_scheduled; counters->saved_bytes += p.saved_bytes;
       counters->max_queue = std::max(counters->max_queue, p.max_queue);
     }
   }

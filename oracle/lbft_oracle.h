@@ -49,6 +49,9 @@ typedef struct lbft_oracle_config {
                                      configuration follows: the record store of epoch e counts votes and timeouts with these
                                      weights (node.rs:331-348) and elects its leaders with pick_author over them
                                      (configuration.rs:65-75, pacemaker.rs:100-109). */
+  uint32_t reference_overheads;   /* 1 = also pay what the reference pays around the protocol logic (results unchanged): bincode::serialize of the
+                                     whole NodeState after every processed event (save_node, simulator.rs:307-309, node.rs:233-238) and one deep
+                                     clone of the notification per receiver (simulator.rs:348-354) -- for the CPU baseline of bench.py */
 } lbft_oracle_config;
 
 /* Equivocators (extension; the reference has no Byzantine behaviour, simulator.rs:25 / data_sync.rs:120-122 only
@@ -81,6 +84,7 @@ typedef struct lbft_oracle_counters {
   uint64_t response_inserts; /* records successfully inserted by handle_response (0 under reference quirk Q1) */
   uint64_t max_queue;        /* max size of the pending-event heap */
   uint64_t events_scheduled; /* creation stamps handed out */
+  uint64_t saved_bytes;      /* reference_overheads: bytes of NodeState images serialised (save_node after every processed event) */
 } lbft_oracle_counters;
 
 typedef struct lbft_oracle_sim lbft_oracle_sim;

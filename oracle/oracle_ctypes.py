@@ -35,6 +35,7 @@ class OracleConfig(C.Structure):
         ("math_mode", C.c_uint32),
         ("voting_rights", C.POINTER(C.c_uint64)),
         ("rights_rotation", C.c_uint32),
+        ("reference_overheads", C.c_uint32),
     ]
 
 
@@ -47,6 +48,7 @@ class OracleCounters(C.Structure):
         ("response_inserts", C.c_uint64),
         ("max_queue", C.c_uint64),
         ("events_scheduled", C.c_uint64),
+        ("saved_bytes", C.c_uint64),
     ]
 
     def as_dict(self):
@@ -58,6 +60,7 @@ class OracleCounters(C.Structure):
             "response_inserts": self.response_inserts,
             "max_queue": self.max_queue,
             "events_scheduled": self.events_scheduled,
+            "saved_bytes": self.saved_bytes,
         }
 
 
@@ -177,7 +180,7 @@ def lib():
 def make_config(num_nodes=3, mean=10.0, variance=4.0, delay_model=0, uniform_lo=5, uniform_hi=15,
                 commands_per_epoch=30000, target_commit_interval=100000, delta=20, gamma=2.0,
                 lambda_=0.5, quirks=0, math_mode=0, voting_rights=None, equivocate_every=0, drop_per_million=0, partition_size=0,
-                partition_start=0, partition_end=0, rights_rotation=0):
+                partition_start=0, partition_end=0, rights_rotation=0, reference_overheads=0):
     """Defaults = the reference CLI defaults (librabft-v2/src/main.rs:73-140)."""
     cfg = OracleConfig()
     cfg.num_nodes = num_nodes
@@ -199,6 +202,7 @@ def make_config(num_nodes=3, mean=10.0, variance=4.0, delay_model=0, uniform_lo=
     cfg.partition_start = partition_start
     cfg.partition_end = partition_end
     cfg.rights_rotation = rights_rotation
+    cfg.reference_overheads = reference_overheads
     if voting_rights is not None:
         arr = (C.c_uint64 * num_nodes)(*voting_rights)
         cfg._keepalive = arr

@@ -87,3 +87,19 @@ def test_configuration_unit_tests(oracle):
     picks = [L.lbft_oracle_pick_author(w.ctypes.data, 3, s) for s in range(20, 28)]
     assert picks == [1, 0, 1, 2, 1, 2, 1, 1]
     assert sorted(picks.count(a) for a in set(picks)) == [1, 2, 5]
+
+
+def test_reference_overheads_change_nothing_but_the_cost(oracle):
+    """lbft_oracle_config.reference_overheads: the oracle also serialises the whole NodeState after every processed event
+    (save_node, simulator.rs:307-309) and clones the notification per receiver (:348-354), as the reference does -- bench.py's
+    cpu_baseline uses it; results and RNG consumption are untouched."""
+    import numpy as np
+    seeds = np.arange(40, 56, dtype=np.uint64)
+    for kw in (dict(num_nodes=3), dict(num_nodes=8, mean=10.0, variance=400.0), dict(num_nodes=5, quirks=3, commands_per_epoch=9)):
+        a = oracle.run_batch(oracle.make_config(**kw), seeds, 1000, threads=4, history_cap=64)
+        b = oracle.run_batch(oracle.make_config(reference_overheads=1, **kw), seeds, 1000, threads=4, history_cap=64)
+        for key in ("commit_counts", "active_rounds", "last_states", "histories"):
+            assert (a[key] == b[key]).all(), key
+        for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
+            assert a["counters"][key] == b["counters"][key], key
+        assert a["counters"]["saved_bytes"] == 0 and b["counters"]["saved_bytes"] > 1000 * len(seeds)
