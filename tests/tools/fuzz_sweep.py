@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 import oracle_ctypes as oracle  # noqa: E402
-from test_fuzz_model import draw_config  # noqa: E402
+from test_fuzz_model import draw_config, draw_large_config  # noqa: E402
 
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
 base = int(sys.argv[3]) if len(sys.argv) > 3 else 77000
@@ -41,4 +41,22 @@ for chunk in range(lo, hi):
             bad += 1
             print("MISMATCH chunk", chunk, "it", it, kw, "max_clock", max_clock, "scap", scap, "ql", ql, "force_generic", fg, "qheap", qheap,
                   "qcal", qcal, "faults", b["faults"].tolist(), flush=True)
-print("configurations", total, "mismatching or faulted", bad)
+# ... and, every fourth chunk, one large network (33..128 nodes) through the cooperative event loop (64 emulated lanes)
+lbad = ltotal = 0
+for chunk in range(lo, hi, 4):
+    rng = np.random.default_rng(base + 500000 + chunk)
+    kw, n, max_clock = draw_large_config(rng)
+    seeds = rng.integers(1, 2 ** 62, 1, dtype=np.uint64)
+    cfg = oracle.make_config(math_mode=1, **kw)
+    a = oracle.run_batch(cfg, seeds, max_clock, threads=os.cpu_count(), history_cap=64)
+    ring, topup = int(rng.choice([128, 256, 512])), int(rng.choice([0, 4, 16]))
+    b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=os.cpu_count(), history_cap=64, qcap=max(8192, 32 * n * n),
+                                   scap=min(36000, 6 * n * n + 16 * n) if kw.get("quirks", 0) & 1 else 128 * n, bcap=512, lcap=512, ql=0, qheap=1, qcal=1,
+                                   ring=ring, ring_topup=topup)
+    ok = (all((a[k] == b[k]).all() for k in ("commit_counts", "active_rounds", "last_states", "histories")) and not b["faults"].any()
+          and all(a["counters"][k] == b["counters"][k] for k in ("events", "rng_draws", "rounds", "commits", "events_scheduled")))
+    ltotal += 1
+    if not ok:
+        lbad += 1
+        print("MISMATCH (large) chunk", chunk, kw, "max_clock", max_clock, "ring", ring, "topup", topup, "faults", b["faults"].tolist(), flush=True)
+print("configurations", total, "mismatching or faulted", bad, "| large-network configurations (cooperative loop)", ltotal, "mismatching or faulted", lbad)

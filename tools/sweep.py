@@ -11,7 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PHASES = {0: "pop", 1: "node_load", 2: "timer_pre", 3: "snap_release", 4: "request", 5: "response", 6: "pacemaker",
           7: "timeout_propose", 8: "vote", 9: "new_qc", 10: "commits_tracker", 11: "sync_push", 12: "pna_timer",
-          13: "pna_notify", 14: "pna_query", 15: "end_node", 16: "send_prep", 17: "store_drain", 18: "send_sample", 19: "send_push", 27: "commits", 28: "pre_blk_miss", 29: "blk_miss", 20: "hn_hcc", 21: "hn_hqc", 22: "hn_block",
+          13: "pna_notify", 14: "pna_query", 15: "end_node", 16: "send_prep", 17: "store_drain", 18: "send_sample", 19: "send_push", 27: "commits", 28: "pre_blk_miss", 29: "blk_miss", 20: "hn_hcc", 21: "response_walk", 22: "hn_block",
           23: "hn_timeouts", 24: "hn_vote"}
 COUNTS = {25: "blk_miss_sites_per_step", 26: "blk_get_sites_per_step"}
 
