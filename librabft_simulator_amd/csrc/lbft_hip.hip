@@ -951,6 +951,11 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
     // Measured (16 384 x 64 nodes / 8 192 x 100 nodes / c4live): tw = 64: 652 ms / 3.63 s / --; tw = lanes per wavefront: 596 / 3.20 / 4.94 s;
     // tw = 4: 555 / 3.17 / 4.43; tw = 2: 550 / 3.10 / 4.28; tw = 1: 541 ms / 3.05 s / 4.14 s -- the large-network kernels address tw = 1 at compile time.
     u32 tw = sim_class(p) <= 1 ? 64u : 1u;
+    // (instance-major rows: a lane addresses its instance through a 32-bit offset from the wavefront's first instance)
+    if (tw == 1 && (u64)lpw * p.total_words * 4ULL >= (1ULL << 32)) {
+      g_err = "lanes per wavefront x per-instance state exceeds 4 GiB: lower the capacities or the lanes per wavefront";
+      return LBFT_ERR_INVALID;
+    }
     p.tw = tw;
     p.rsh = 2;
     while ((4u << (p.rsh - 2)) < 4u * tw) p.rsh++;

@@ -20,7 +20,7 @@ pass sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_
 pass sq3 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
 pass grbm GRBM_GUI_ACTIVE
 python tools/pmc_summary.py $OUT > $OUT/pmc_lbft_k_run.json 2> $OUT/pmc_summary.err
-# roofline.traffic for bench.py: FETCH/WRITE per launch, stamped with the hash of the kernel sources (copy to profiles/current/)
+# roofline.traffic for bench.py: FETCH/WRITE per launch, stamped with the hash of the kernels' machine code (copy to profiles/current/)
 python - "$OUT" "$TAG" <<'PY'
 import json, sys
 sys.path.insert(0, ".")
