@@ -125,3 +125,14 @@ def test_run_kernels_keep_their_state_in_registers(hiplib):
     assert len(lean) == 1 and all(v["vgpr_count"] <= 256 and v["private_segment_fixed_size"] <= 128 for v in lean), lean
     lean2 = [v for k, v in kernels.items() if "lbft_k_run2l" in k]  # opt-in (LBFT_LEAN2=1): large networks at 256 registers spill heavily
     assert len(lean2) == 1 and lean2[0]["vgpr_count"] <= 256, lean2
+
+
+def test_kernel_hash_reads_the_code_object(hiplib):
+    """build.kernel_hash(): the stamp that ties profiles/current/pmc_traffic.json to the kernels bench.py runs (sha256 of the
+    gfx950 machine code in the built library; parsed without binutils so that it works on the GPU box)."""
+    import json
+    from librabft_simulator_amd import build
+    h = build.kernel_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", h) and h == build.source_hash()
+    stamp = json.load(open(os.path.join(ROOT, "profiles", "current", "pmc_traffic.json"))).get("source_hash")
+    assert re.fullmatch(r"[0-9a-f]{16}", stamp)  # (equal to h while the committed profile belongs to the built kernels; bench.py reports null otherwise)
