@@ -187,7 +187,8 @@ int lbft_batch_last_run_ms(const lbft_batch* b, float* init_ms, float* run_ms);
 size_t lbft_batch_device_bytes(const lbft_batch* b);
 /* Sizes behind the roofline arithmetic (bench.py): out[8] = bytes of one node's rows, of one queued event, of one
  * notification snapshot, of one block record, HBM bytes per instance, LDS-resident queue slots, lanes per wavefront,
- * kernel size class | heap-queue flag << 8 | calendar-queue flag << 9 | lean-large-network-kernel flag << 10. */
+ * kernel size class | heap-queue flag << 8 | calendar-queue flag << 9 | two-wavefronts-per-SIMD ("lean") kernel flag << 10 |
+ * cooperative-bulk-send flag << 11 (large networks on the calendar queue: all lanes of a wavefront execute a network's broadcasts). */
 int lbft_batch_layout(const lbft_batch* b, uint32_t* out);
 /* Events processed per run-kernel launch (0 = whole simulation in one launch). */
 int lbft_batch_set_max_steps(lbft_batch* b, uint32_t max_steps);

@@ -569,9 +569,9 @@ extern "C" {
 
 const char* lbft_last_error(void) { return g_err.c_str(); }
 #if defined(LBFT_PHASE_TIMERS)
-const char* lbft_build_info(void) { return "liblbft_hip gfx950 abi3 lane-per-instance lds-queue phase-timers"; }
+const char* lbft_build_info(void) { return "liblbft_hip gfx950 abi4 lane-per-instance lds-queue coop-bulk-send phase-timers"; }
 #else
-const char* lbft_build_info(void) { return "liblbft_hip gfx950 abi3 lane-per-instance lds-queue"; }
+const char* lbft_build_info(void) { return "liblbft_hip gfx950 abi4 lane-per-instance lds-queue coop-bulk-send"; }
 #endif
 
 int lbft_batch_create(const lbft_config* cfg, const uint64_t* seeds, size_t n_instances, int device, lbft_batch** out) {
