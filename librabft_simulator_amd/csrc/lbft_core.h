@@ -49,6 +49,23 @@ typedef int64_t i64;
 #ifndef LBFT_SPEC
 #define LBFT_SPEC 1  // calendar queue: the entry behind the popped one is fetched ahead
 #endif
+// ... and for the two-wavefronts-per-SIMD large-network kernel (256 registers): every staged word there is a spilled register, and the
+// spills cost more than the round trips they save (16 384 x 64 nodes: 451 ms without, 476 / 504 / 511 ms with AX / SPEC / all three)
+#ifndef LBFT_LEAN_AX
+#define LBFT_LEAN_AX 0
+#endif
+#ifndef LBFT_LEAN_BX
+#define LBFT_LEAN_BX 0
+#endif
+#ifndef LBFT_LEAN_SPEC
+#define LBFT_LEAN_SPEC 0
+#endif
+#ifndef LBFT_LEAN_Q1
+#define LBFT_LEAN_Q1 0   // experiment: the two-wavefronts-per-SIMD large-network kernel also handles the record exchange of quirks bit 0
+#endif
+#ifndef LBFT_BLK_CACHE_LEAN2
+#define LBFT_BLK_CACHE_LEAN2 2  // (two-wavefront large-network kernel: 16 384 x 64 nodes 420 ms at 2 records, 449 ms at 3: ten fewer spilled registers)
+#endif
 #define LBFT_MAX_NODES 128  // node / author sets are 1..4 32-bit words (word 0 in the hot rows, the rest in extension rows)
 
 // Sticky per-instance fault bits (readable after the run; never abort the process).
@@ -528,6 +545,9 @@ struct SimT {
   // classes address tiles of P.tw = lanes per wavefront (lbft_core.h "HBM layout")
   static constexpr bool TILE64 = CLS == 0 || CLS == 1 || CLS == 6;
   static constexpr bool IMAJOR = BIG;  // large networks: tile width 1 = every instance's words contiguous (P.tw == 1), addressed at compile time
+  static constexpr bool F_AX = CLS == 5 ? (LBFT_LEAN_AX != 0) : (LBFT_AX != 0);      // (tuning switches above)
+  static constexpr bool F_BX = CLS == 5 ? (LBFT_LEAN_BX != 0) : (LBFT_BX != 0);
+  static constexpr bool F_SPEC = CLS == 5 ? (LBFT_LEAN_SPEC != 0) : (LBFT_SPEC != 0);
   static constexpr bool COOP = BIG;
   static constexpr bool RING = BIG || CLS == 3;
   bool coop_on;  // set by run_coop: the event loop is being run by a whole wavefront
@@ -535,7 +555,7 @@ struct SimT {
   LBFT_HD bool wide() const { return BIG ? true : (CLS == 3 ? P.n > 32 : false); }
   LBFT_HD bool heap() const { return CLS == 0 ? false : (BIG ? true : P.qheap != 0); }
   LBFT_HD bool tracing() const { return CLS != 0 && !LEAN && P.rcap != 0; }  // round-switch trace (DataWriter); class 0 never traces
-  LBFT_HD bool q1() const { return CLS != 0 && !LEAN && (P.quirks & 1u) != 0; }  // requests are answered by the peer with real payloads
+  LBFT_HD bool q1() const { return CLS != 0 && (!LEAN || (CLS == 5 && LBFT_LEAN_Q1)) && (P.quirks & 1u) != 0; }  // requests are answered by the peer with real payloads
   LBFT_HD bool cal() const { return CLS != 0 && P.qcal != 0; }
   LBFT_HD bool packed() const { return CLS == 0 ? true : (BIG ? false : P.n <= 16); }
   LBFT_HD bool qpacked() const { return CLS == 0 ? true : (CLS == 3 ? P.qpack != 0 : false); }  // one-word queue entries
@@ -723,27 +743,28 @@ struct SimT {
     LBFT_HD u32 epoch() const { return w[B_EPOCH]; }
     LBFT_HD u32 depth() const { return w[B_DEPTH]; }
   };
-  mutable u32 bc_id[LBFT_BLK_CACHE];
-  mutable u32 bc_w[LBFT_BLK_CACHE][BC_WORDS];
+  static constexpr u32 BCN = CLS == 5 ? LBFT_BLK_CACHE_LEAN2 : LBFT_BLK_CACHE;
+  mutable u32 bc_id[BCN];
+  mutable u32 bc_w[BCN][BC_WORDS];
   mutable u32 bc_next, bc_ref;  // FIFO hand + "recently used" bits (second chance: a hot old block survives)
   LBFT_HD void blk_cache_reset() const {
-    for (u32 e = 0; e < LBFT_BLK_CACHE; e++) bc_id[e] = 0;
+    for (u32 e = 0; e < BCN; e++) bc_id[e] = 0;
     bc_next = 0; bc_ref = 0;
   }
   LBFT_HD void blk_cache_insert(u32 b, const Blk& r) const {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (u32 t = 0; t < LBFT_BLK_CACHE; t++) {  // skip (and age) entries used since the hand last passed
+    for (u32 t = 0; t < BCN; t++) {  // skip (and age) entries used since the hand last passed
       if ((bc_ref >> bc_next) & 1u) {
         bc_ref &= ~(1u << bc_next);
-        bc_next = bc_next + 1 == LBFT_BLK_CACHE ? 0 : bc_next + 1;
+        bc_next = bc_next + 1 == BCN ? 0 : bc_next + 1;
       }
     }
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (u32 e = 0; e < LBFT_BLK_CACHE; e++) {
+    for (u32 e = 0; e < BCN; e++) {
       // value selects at fixed entries, NOT `if (hand == e) entry[e] = r`: the compiler sinks such conditional stores
       // into one store through a phi of entry addresses, and an array addressed that way is no longer promoted to
       // registers (the whole cache ended up in scratch memory: 32 scratch loads per lookup)
@@ -754,7 +775,7 @@ struct SimT {
 #endif
       for (u32 f = 0; f < BC_WORDS; f++) bc_w[e][f] = take ? r.w[f] : bc_w[e][f];
     }
-    bc_next = bc_next + 1 == LBFT_BLK_CACHE ? 0 : bc_next + 1;
+    bc_next = bc_next + 1 == BCN ? 0 : bc_next + 1;
   }
   mutable u32 cur_xk;  // extension word of the node sets that the current event's node lives in (0: node < 32 or n <= 32)
   LBFT_HD Blk blk_get(u32 b) const {  // b != 0
@@ -768,7 +789,7 @@ struct SimT {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (u32 e = 0; e < LBFT_BLK_CACHE; e++) {
+    for (u32 e = 0; e < BCN; e++) {
       if (bc_id[e] == b) {
         hit = true;
         bc_ref |= 1u << e;
@@ -806,32 +827,27 @@ struct SimT {
   }
   LBFT_HD bool bm_test(u32 b, const Blk& rb, u32 f, u32 node) const {
     if (!wide() || node < 32) return (rb.w[f] >> node) & 1u;
-#if LBFT_BX
-    bx_fetch(b, rb, node >> 5);
-    return (rb.x[f - B_KNOWN] >> (node & 31u)) & 1u;
-#else
+    if (F_BX) {
+      bx_fetch(b, rb, node >> 5);
+      return (rb.x[f - B_KNOWN] >> (node & 31u)) & 1u;
+    }
     return (ld(bxw(b, f, node >> 5)) >> (node & 31u)) & 1u;
-#endif
   }
   LBFT_HD void bm_set(u32 b, Blk& rb, u32 f, u32 node) const {
     if (!wide() || node < 32) { rb.w[f] |= 1u << node; blk_put(b, f, rb.w[f]); return; }
-#if LBFT_BX
-    bx_fetch(b, rb, node >> 5);
-    rb.x[f - B_KNOWN] |= 1u << (node & 31u);
-    st(bxw(b, f, node >> 5), rb.x[f - B_KNOWN]);
-#else
-    { u32 w = bxw(b, f, node >> 5); st(w, ld(w) | (1u << (node & 31u))); }
-#endif
+    if (F_BX) {
+      bx_fetch(b, rb, node >> 5);
+      rb.x[f - B_KNOWN] |= 1u << (node & 31u);
+      st(bxw(b, f, node >> 5), rb.x[f - B_KNOWN]);
+    } else { u32 w = bxw(b, f, node >> 5); st(w, ld(w) | (1u << (node & 31u))); }
   }
   LBFT_HD void bm_clr(u32 b, Blk& rb, u32 f, u32 node) const {
     if (!wide() || node < 32) { rb.w[f] &= ~(1u << node); blk_put(b, f, rb.w[f]); return; }
-#if LBFT_BX
-    bx_fetch(b, rb, node >> 5);
-    rb.x[f - B_KNOWN] &= ~(1u << (node & 31u));
-    st(bxw(b, f, node >> 5), rb.x[f - B_KNOWN]);
-#else
-    { u32 w = bxw(b, f, node >> 5); st(w, ld(w) & ~(1u << (node & 31u))); }
-#endif
+    if (F_BX) {
+      bx_fetch(b, rb, node >> 5);
+      rb.x[f - B_KNOWN] &= ~(1u << (node & 31u));
+      st(bxw(b, f, node >> 5), rb.x[f - B_KNOWN]);
+    } else { u32 w = bxw(b, f, node >> 5); st(w, ld(w) & ~(1u << (node & 31u))); }
   }
   // Write-through update of one mask word of block b (f is B_KNOWN, B_QC or B_PEND).
   LBFT_HD void blk_put(u32 b, u32 f, u32 v) const {
@@ -839,7 +855,7 @@ struct SimT {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (u32 e = 0; e < LBFT_BLK_CACHE; e++) {  // (value selects: see blk_cache_insert)
+    for (u32 e = 0; e < BCN; e++) {  // (value selects: see blk_cache_insert)
       bool hit = bc_id[e] == b;
       if (f == B_KNOWN) bc_w[e][B_KNOWN] = hit ? v : bc_w[e][B_KNOWN];
       else if (f == B_QC) bc_w[e][B_QC] = hit ? v : bc_w[e][B_QC];
@@ -858,8 +874,10 @@ struct SimT {
     qlen = ld(I_QLEN); snap_free = ld(I_SNAP_FREE); nblocks = ld(I_NBLOCKS); fault = ld(I_FAULT);
     ev0 = ld(I_EV0); ev1 = ld(I_EV1); ev2 = ld(I_EV2); ev3 = ld(I_EV3);
     maxq = ld(I_MAXQ); maxsnap = ld(I_MAXSNAP);
-    snap_mask = ld(I_SNAP_MASK_LO) | ((u64)ld(I_SNAP_MASK_HI) << 32);
-    last_node = ld(I_LAST_NODE); vd_time = ld(I_VD_TIME); vd_stamp = ld(I_VD_STAMP);
+    if (CLS != 5) {  // (state the two-wavefront large-network kernel never touches stays in its rows)
+      snap_mask = ld(I_SNAP_MASK_LO) | ((u64)ld(I_SNAP_MASK_HI) << 32);
+      last_node = ld(I_LAST_NODE); vd_time = ld(I_VD_TIME); vd_stamp = ld(I_VD_STAMP);
+    } else { snap_mask = 0; last_node = 0; vd_time = 0xffffffffu; vd_stamp = 0; }
     cal_cursor = ld(I_CAL_CURSOR); cal_free = ld(I_CAL_FREE); cal_bump = ld(I_CAL_BUMP);
     n_fold = ld(I_NFOLD); n_upd = ld(I_NUPD);
     sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0;
@@ -874,8 +892,10 @@ struct SimT {
     st(I_QLEN, qlen); st(I_SNAP_FREE, snap_free); st(I_NBLOCKS, nblocks); st(I_FAULT, fault);
     st(I_EV0, ev0); st(I_EV1, ev1); st(I_EV2, ev2); st(I_EV3, ev3);
     st(I_MAXQ, maxq); st(I_MAXSNAP, maxsnap);
-    st(I_SNAP_MASK_LO, (u32)snap_mask); st(I_SNAP_MASK_HI, (u32)(snap_mask >> 32));
-    st(I_LAST_NODE, last_node); st(I_VD_TIME, vd_time); st(I_VD_STAMP, vd_stamp);
+    if (CLS != 5) {
+      st(I_SNAP_MASK_LO, (u32)snap_mask); st(I_SNAP_MASK_HI, (u32)(snap_mask >> 32));
+      st(I_LAST_NODE, last_node); st(I_VD_TIME, vd_time); st(I_VD_STAMP, vd_stamp);
+    }
     st(I_CAL_CURSOR, cal_cursor); st(I_CAL_FREE, cal_free); st(I_CAL_BUMP, cal_bump);
     st(I_NFOLD, n_fold); st(I_NUPD, n_upd);
     if (RING) { st(I_RING_HEAD, rng.rhead); st(I_RING_CNT, rng.rcnt); }
@@ -984,7 +1004,7 @@ struct SimT {
       else s1 = ++cal_bump;                   // bounded by the qlen < qcap check above
       st(P.off_qmeta + s1 - 1, meta);
       st(P.off_qhi + s1 - 1, 0);              // next
-      if (tl) { st(P.off_qhi + tl - 1, s1); if (LBFT_SPEC && tl == sp_s1) sp_nx = s1; }  // (the entry pop_event fetched ahead got a successor)
+      if (tl) { st(P.off_qhi + tl - 1, s1); if (F_SPEC && tl == sp_s1) sp_nx = s1; }  // (the entry pop_event fetched ahead got a successor)
       else {
         st(P.off_cal_head + idx, s1);
         u32 bw = P.off_cal_bm + (idx >> 5);
@@ -1020,7 +1040,7 @@ struct SimT {
       // to pop -- no bitmap word, no head row, no entry fetch: the three dependent round trips of a pop are gone.
       u32 idx, s1, nx, w = 0, raw = 0;
       bool have_raw = false;
-      if (LBFT_SPEC && sp_s1 != 0 && cal_cursor == sp_idx) {
+      if (F_SPEC && sp_s1 != 0 && cal_cursor == sp_idx) {
         idx = sp_idx; s1 = sp_s1; meta = sp_meta; nx = sp_nx;
       } else {
         w = cal_cursor >> 5;
@@ -1039,7 +1059,7 @@ struct SimT {
         if (!have_raw) { w = idx >> 5; raw = ld(P.off_cal_bm + w); }
         st(P.off_cal_tail + idx, 0); st(P.off_cal_bm + w, raw & ~(1u << (idx & 31u)));
         sp_s1 = 0;
-      } else if (LBFT_SPEC) {  // fetch the entry behind this one now; a later append to it is patched in by push_event / coop_bulk
+      } else if (F_SPEC) {  // fetch the entry behind this one now; a later append to it is patched in by push_event / coop_bulk
         sp_idx = idx; sp_s1 = nx;
         sp_meta = ld(P.off_qmeta + nx - 1);
         sp_nx = ld(P.off_qhi + nx - 1);
@@ -1150,12 +1170,15 @@ struct SimT {
     return (u32)__builtin_popcountll(x);
 #endif
   }
+  // (the register-resident free mask serves batches of <= 64 slots; the two-wavefront large-network kernel never has that few and
+  // keeps the mask out of its registers)
+  LBFT_HD bool mask_slots() const { return CLS == 5 ? false : P.scap <= 64; }
   LBFT_HD void snap_free_slot(u32 slot) {
-    if (P.scap <= 64) snap_mask |= 1ULL << slot;
+    if (mask_slots()) snap_mask |= 1ULL << slot;
     else { st(P.off_snap_free + snap_free, slot); snap_free++; }
   }
   LBFT_HD i32 snap_alloc() {
-    if (P.scap <= 64) {
+    if (mask_slots()) {
       if (snap_mask == 0) { fault |= F_SNAP_OVERFLOW; return -1; }
       u32 slot = ctz64(snap_mask);
       snap_mask &= snap_mask - 1;
@@ -1251,8 +1274,7 @@ struct SimT {
   mutable u32 axdirty;  // bit (set * 3 + word - 1)
   LBFT_HD void ax_load(u32 node) const {
     axdirty = 0;
-#if LBFT_AX
-    if (!wide()) return;
+    if (!F_AX || !wide()) return;
     u32 base = nfw(node, NF_FIXED_WORDS + 2 * P.n);
 #if defined(__HIPCC__)
 #pragma unroll
@@ -1267,10 +1289,9 @@ struct SimT {
         ax[i][k] = k + 1 < P.mw ? v : 0u;
       }
     }
-#endif
   }
   LBFT_HD void ax_store(u32 node) const {
-    if (!LBFT_AX || !wide() || !axdirty) return;
+    if (!F_AX || !wide() || !axdirty) return;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -1307,45 +1328,24 @@ struct SimT {
     }
     axdirty |= 1u << (i * 3 + k - 1);
   }
-#if LBFT_AX
-  LBFT_HD u32 am_word(u32 node, u32 f, u32 k) const { return k == 0 ? nf(node, f) : ax_get(am_idx(f), k); }
-  LBFT_HD void am_set_word(u32 node, u32 f, u32 k, u32 v) const { if (k == 0) nfs(node, f, v); else ax_put(am_idx(f), k, v); }
+  LBFT_HD u32 am_word(u32 node, u32 f, u32 k) const { return k == 0 ? nf(node, f) : F_AX ? ax_get(am_idx(f), k) : ld(amxw(node, f, k)); }
+  LBFT_HD void am_set_word(u32 node, u32 f, u32 k, u32 v) const { if (k == 0) nfs(node, f, v); else if (F_AX) ax_put(am_idx(f), k, v); else st(amxw(node, f, k), v); }
   LBFT_HD bool am_test(u32 node, u32 f, u32 a) const {
     if (!wide() || a < 32) return (nf(node, f) >> a) & 1u;
-    return (ax_get(am_idx(f), a >> 5) >> (a & 31u)) & 1u;
+    return (am_word(node, f, a >> 5) >> (a & 31u)) & 1u;
   }
   LBFT_HD void am_set(u32 node, u32 f, u32 a) const {
     if (!wide() || a < 32) nfs(node, f, nf(node, f) | (1u << a));
-    else ax_put(am_idx(f), a >> 5, ax_get(am_idx(f), a >> 5) | (1u << (a & 31u)));
+    else am_set_word(node, f, a >> 5, am_word(node, f, a >> 5) | (1u << (a & 31u)));
   }
   LBFT_HD void am_clear(u32 node, u32 f) const {
     nfs(node, f, 0);
-    for (u32 k = 1; wide() && k < P.mw; k++) ax_put(am_idx(f), k, 0);
+    for (u32 k = 1; wide() && k < P.mw; k++) am_set_word(node, f, k, 0);
   }
   LBFT_HD void am_copy(u32 node, u32 dst, u32 src) const {
     nfs(node, dst, nf(node, src));
-    for (u32 k = 1; wide() && k < P.mw; k++) ax_put(am_idx(dst), k, ax_get(am_idx(src), k));
+    for (u32 k = 1; wide() && k < P.mw; k++) am_set_word(node, dst, k, am_word(node, src, k));
   }
-#else
-  LBFT_HD u32 am_word(u32 node, u32 f, u32 k) const { return k == 0 ? nf(node, f) : ld(amxw(node, f, k)); }
-  LBFT_HD void am_set_word(u32 node, u32 f, u32 k, u32 v) const { if (k == 0) nfs(node, f, v); else st(amxw(node, f, k), v); }
-  LBFT_HD bool am_test(u32 node, u32 f, u32 a) const {
-    if (!wide() || a < 32) return (nf(node, f) >> a) & 1u;
-    return (ld(amxw(node, f, a >> 5)) >> (a & 31u)) & 1u;
-  }
-  LBFT_HD void am_set(u32 node, u32 f, u32 a) const {
-    if (!wide() || a < 32) nfs(node, f, nf(node, f) | (1u << a));
-    else { u32 w = amxw(node, f, a >> 5); st(w, ld(w) | (1u << (a & 31u))); }
-  }
-  LBFT_HD void am_clear(u32 node, u32 f) const {
-    nfs(node, f, 0);
-    for (u32 k = 1; wide() && k < P.mw; k++) st(amxw(node, f, k), 0);
-  }
-  LBFT_HD void am_copy(u32 node, u32 dst, u32 src) const {
-    nfs(node, dst, nf(node, src));
-    for (u32 k = 1; wide() && k < P.mw; k++) st(amxw(node, dst, k), ld(amxw(node, src, k)));
-  }
-#endif
 
   // ---- RecordStoreState ----
   LBFT_HD void clear_ballot(u32 node) const {
@@ -2553,7 +2553,7 @@ struct SimT {
       }
     }
     if (is_k) {
-      if (LBFT_SPEC && sp_s1) sp_nx = ld(P.off_qhi + sp_s1 - 1);  // the entry pop_event fetched ahead may have got a successor from another lane
+      if (F_SPEC && sp_s1) sp_nx = ld(P.off_qhi + sp_s1 - 1);  // the entry pop_event fetched ahead may have got a successor from another lane
       stamp += cnt;
       if (stamp >= (1u << 30)) fault |= F_STAMP_OVERFLOW;
       if (which == 0) {
@@ -2681,7 +2681,7 @@ struct SimT {
       i32 t_event = t;
       if (t > clock) clock = t;
       u32 node = meta & 0xffu, sender = (meta >> 8) & 0xffu, slot = meta >> 16;
-      last_node = node;
+      if (!LEAN) last_node = node;
       // One shared site for the node-row burst (and, for a notification, its snapshot words in the same
       // burst), one for update_node + process_node_actions: lanes of a wavefront that handle different
       // event kinds issue their loads together instead of one serialized round trip per kind.
@@ -2702,7 +2702,7 @@ struct SimT {
         LBFT_STAT(0);
         ev3 += 1 + slot;  // slot > 0: a materialised group of folded duplicates (see process_node_actions)
         if ((u32)clock == nf(node, NF_LAST_TIMER_T)) {  // folded duplicates of this timer
-          if (nf(node, NF_TIMER_DUPS) != 0) {  // their pops follow, interleaved by stamp with the other timers of this time
+          if (!LEAN && nf(node, NF_TIMER_DUPS) != 0) {  // their pops follow, interleaved by stamp with the other timers of this time (round trace only)
             u32 ds = nf(node, NF_DUP_STAMP) + 1;
             vd_stamp = (vd_time == (u32)clock && vd_stamp > ds) ? vd_stamp : ds;
             vd_time = (u32)clock;
@@ -2845,7 +2845,7 @@ inline int sim_class(const Params& p) {
 }
 
 // Does a class-2 / class-1 batch qualify for the lean kernel of its class (SimT<5> / SimT<6>)?
-inline bool sim_lean_features(const Params& p) { return !(p.quirks & 1u) && !p.rcap && !p.drop_ppm && !p.part_size; }
+inline bool sim_lean_features(const Params& p) { return (!(p.quirks & 1u) || (LBFT_LEAN_Q1 && p.n > 32)) && !p.rcap && !p.drop_ppm && !p.part_size; }
 inline bool sim_lean(const Params& p) { return sim_class(p) == 2 && sim_lean_features(p); }
 inline bool sim_lean1(const Params& p) { return sim_class(p) == 1 && sim_lean_features(p); }
 

@@ -406,11 +406,13 @@ __global__ void lbft_k_exp_log(const u64* __restrict__ exp_tab, const double* __
 // Host side of the C ABI
 // ------------------------------------------------------------------------------------------------
 static thread_local std::string g_err;
-// Tuning knobs: LBFT_NO_LEAN=1 = always the full-register kernels; LBFT_LEAN2=1 = the two-wavefronts-per-SIMD kernel for
-// large networks as well (round 1's choice; since the register-staged node sets and the narrow tiles of round 2 the
-// full-register kernel with twice the lanes is as fast or faster: 16384 x 64 nodes 584 vs 633 ms, 8192 x 100 nodes 3.09 vs 3.42 s)
+// Kernel selection.  Large networks without record exchange / round trace / message loss run the two-wavefronts-per-SIMD kernel
+// (`lbft_k_run2l`, 8 lanes per wavefront at 16 384 networks) WITHOUT the register-staged node sets and the calendar fetch-ahead: two
+// wavefronts overlap each other's dependent round trips, and at 256 registers every staged word is a spilled one (16 384 x 64 nodes:
+// 451 ms; with the staging 476-511 ms; the full-register kernel with twice the lanes 503 ms; 8 192 x 100 nodes: 2.49 / 2.75-2.85 / 2.85 s).
+// Tuning knobs: LBFT_NO_LEAN=1 = always the full-register kernels; LBFT_LEAN2=0 = the full-register kernel for large networks.
 static bool lean_allowed() { const char* e = getenv("LBFT_NO_LEAN"); return !(e && atoi(e)); }
-static bool lean2_allowed() { const char* e = getenv("LBFT_LEAN2"); return lean_allowed() && e && atoi(e); }
+static bool lean2_allowed() { const char* e = getenv("LBFT_LEAN2"); return lean_allowed() && !(e && !atoi(e)); }
 
 static int hip_fail(hipError_t e, const char* what) {
   g_err = std::string(what) + ": " + hipGetErrorString(e);
