@@ -123,8 +123,9 @@ def test_run_kernels_keep_their_state_in_registers(hiplib):
         assert v["private_segment_fixed_size"] <= 128, big
     lean = [v for k, v in kernels.items() if "lbft_k_run1l" in k]  # class 1 without record exchange / trace / loss: two wavefronts per SIMD as well
     assert len(lean) == 1 and all(v["vgpr_count"] <= 256 and v["private_segment_fixed_size"] <= 128 for v in lean), lean
-    lean2 = [v for k, v in kernels.items() if "lbft_k_run2l" in k]  # opt-in (LBFT_LEAN2=1): large networks at 256 registers spill heavily
-    assert len(lean2) == 1 and lean2[0]["vgpr_count"] <= 256, lean2
+    lean2 = [v for k, v in kernels.items() if "lbft_k_run2l" in k]  # large networks without record exchange: two wavefronts per SIMD pay only while the trimmed loop
+    # keeps its state in registers (15 spilled registers as built; 118 with the staged sets was slower than one wavefront per SIMD)
+    assert len(lean2) == 1 and lean2[0]["vgpr_count"] <= 256 and lean2[0]["vgpr_spill_count"] <= 40, lean2
 
 
 def test_kernel_hash_reads_the_code_object(hiplib):
