@@ -61,7 +61,11 @@ typedef int64_t i64;
 #define LBFT_LEAN_SPEC 0
 #endif
 #ifndef LBFT_LEAN_Q1
-#define LBFT_LEAN_Q1 0   // experiment: the two-wavefronts-per-SIMD large-network kernel also handles the record exchange of quirks bit 0
+#define LBFT_LEAN_Q1 1   // the two-wavefronts-per-SIMD large-network kernel also handles the record exchange of quirks bit 0 (34 spilled registers
+                         // since a response's epochs are separate steps; 16 384 x 64 live: 3.46 s against 4.11 s on the full-register kernel)
+#endif
+#ifndef LBFT_LEAN1_Q1
+#define LBFT_LEAN1_Q1 0  // ... and the two-wavefront kernel of class 1 (networks of <= 32 nodes)
 #endif
 #ifndef LBFT_BLK_CACHE_LEAN2
 #define LBFT_BLK_CACHE_LEAN2 2  // (two-wavefront large-network kernel: 16 384 x 64 nodes 420 ms at 2 records, 449 ms at 3: ten fewer spilled registers)
@@ -200,7 +204,8 @@ enum InstField : u32 {
   I_QLEN, I_SNAP_FREE, I_NBLOCKS, I_FAULT, I_EV0, I_EV1, I_EV2, I_EV3, I_DRAWS, I_DONE,
   I_MAXQ, I_MAXSNAP, I_SNAP_MASK_LO, I_SNAP_MASK_HI, I_LAST_NODE, I_VD_TIME, I_VD_STAMP, I_CAL_CURSOR, I_CAL_FREE, I_CAL_BUMP,
   I_NFOLD /* duplicate timers folded at scheduling time (never queued) */, I_NUPD /* update_node calls */,
-  I_RING_HEAD, I_RING_CNT /* ring of pre-generated draws: draws [head, head + cnt) */, I_WORDS
+  I_RING_HEAD, I_RING_CNT /* ring of pre-generated draws: draws [head, head + cnt) */,
+  I_CONT, I_CONT_META /* a response event whose later epochs are still to be inserted (step_begin): next epoch + 1 (0 = none), the event's queue word */, I_WORDS
 };
 
 // Node-level rows (RecordStoreState record_store.rs:93-119, PacemakerState pacemaker.rs:60-77,
@@ -555,7 +560,7 @@ struct SimT {
   LBFT_HD bool wide() const { return BIG ? true : (CLS == 3 ? P.n > 32 : false); }
   LBFT_HD bool heap() const { return CLS == 0 ? false : (BIG ? true : P.qheap != 0); }
   LBFT_HD bool tracing() const { return CLS != 0 && !LEAN && P.rcap != 0; }  // round-switch trace (DataWriter); class 0 never traces
-  LBFT_HD bool q1() const { return CLS != 0 && (!LEAN || (CLS == 5 && LBFT_LEAN_Q1)) && (P.quirks & 1u) != 0; }  // requests are answered by the peer with real payloads
+  LBFT_HD bool q1() const { return CLS != 0 && (!LEAN || (CLS == 5 && LBFT_LEAN_Q1) || (CLS == 6 && LBFT_LEAN1_Q1)) && (P.quirks & 1u) != 0; }  // requests are answered by the peer with real payloads
   LBFT_HD bool cal() const { return CLS != 0 && P.qcal != 0; }
   LBFT_HD bool packed() const { return CLS == 0 ? true : (BIG ? false : P.n <= 16); }
   LBFT_HD bool qpacked() const { return CLS == 0 ? true : (CLS == 3 ? P.qpack != 0 : false); }  // one-word queue entries
@@ -573,6 +578,7 @@ struct SimT {
   u32 vd_time, vd_stamp;
   u64 snap_mask;  // scap <= 64: free snapshot slots as a bit set held in registers (no free-stack round trip)
   u32 ev0, ev1, ev2, ev3;
+  u32 cont;  // quirks bit 0: epoch + 1 at which the response event in I_CONT_META goes on at the next step (0: none)
   u32 n_fold, n_upd;  // duplicate timers folded instead of queued / update_node calls: what the device executes, as opposed to the
                       // reference-equivalent event counts ev0..ev3 (bench.py reports the roofline on both)
   RngT<RING> rng;
@@ -880,6 +886,7 @@ struct SimT {
     } else { snap_mask = 0; last_node = 0; vd_time = 0xffffffffu; vd_stamp = 0; }
     cal_cursor = ld(I_CAL_CURSOR); cal_free = ld(I_CAL_FREE); cal_bump = ld(I_CAL_BUMP);
     n_fold = ld(I_NFOLD); n_upd = ld(I_NUPD);
+    cont = ld(I_CONT);
     sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0;
     if (RING) { rng.rhead = ld(I_RING_HEAD); rng.rcnt = ld(I_RING_CNT); }
     blk_cache_reset();
@@ -898,6 +905,7 @@ struct SimT {
     }
     st(I_CAL_CURSOR, cal_cursor); st(I_CAL_FREE, cal_free); st(I_CAL_BUMP, cal_bump);
     st(I_NFOLD, n_fold); st(I_NUPD, n_upd);
+    if (q1()) st(I_CONT, cont);
     if (RING) { st(I_RING_HEAD, rng.rhead); st(I_RING_CNT, rng.rcnt); }
     st(I_DONE, done ? 1u : 0u);
   }
@@ -1700,11 +1708,15 @@ struct SimT {
   }
 
   // ---- NodeState::update_node (node.rs:240-304) ----
-  LBFT_HD Actions update_node(u32 node, i64 lclock) {
+  // `tail_only`: only process_commits + update_tracker, results discarded -- the step between two epochs of a response
+  // (data_sync.rs:226-236, see handle_response_epoch)
+  LBFT_HD Actions update_node(u32 node, i64 lclock, bool tail_only = false) {
     i64 lqat = (i64)(i32)nf(node, NF_LQAT);
+    Actions act;
+    act.next = LBFT_NEVER; act.send_to = -1; act.broadcast = false; act.query_all = false;
+    if (!tail_only) {
     PmActions pa = update_pacemaker(node, lqat, lclock);
     LBFT_UMARK(6);
-    Actions act;
     act.next = pa.next; act.send_to = pa.send_to; act.broadcast = pa.broadcast; act.query_all = pa.query_all;
     // process_pacemaker_actions (node.rs:179-202)
     LBFT_STAT(5);
@@ -1741,13 +1753,16 @@ struct SimT {
     LBFT_UMARK(8);
     if (check_for_new_qc(node)) { LBFT_STAT(10); act.broadcast = true; act.next = lclock; }
     LBFT_UMARK(9);
+    }
     process_commits(node);
     LBFT_MARK(27);
     bool tq; i64 tnext;
     update_tracker(node, lqat, lclock, tq, tnext);
-    act.query_all = act.query_all || tq;
-    if (tnext < act.next) act.next = tnext;
-    if (act.query_all) nfs(node, NF_LQAT, (u32)(i32)lclock);
+    if (!tail_only) {
+      act.query_all = act.query_all || tq;
+      if (tnext < act.next) act.next = tnext;
+      if (act.query_all) nfs(node, NF_LQAT, (u32)(i32)lclock);
+    }
     LBFT_UMARK(10);
     return act;
   }
@@ -1879,22 +1894,30 @@ struct SimT {
     u32 pb = ld(base + S_PROP_VOTE) & 0xffffu;
     if (pb) insert_block(node, pb);
   }
-  // DataSyncNode::handle_response (data_sync.rs:209-240): `slot` = the peer's store at request time + the request
-  LBFT_HD void handle_response(u32 node, u32 peer, u32 slot, i64 lclock) {
+  // DataSyncNode::handle_response (data_sync.rs:209-240): `slot` = the peer's store at request time + the request.
+  // The reference inserts the unknown records epoch by epoch and runs process_commits + update_tracker between two epochs
+  // (:226-236).  handle_response_epoch does ONE epoch -- the first one >= e that is the node's current epoch -- and returns true
+  // (e = the next epoch) when that in-between step is due: the event loop runs it at update_node's own process_commits /
+  // update_tracker site (update_node(.., tail_only)) instead of a second inlined copy here, which alone cost the
+  // two-wavefront kernel 160 spilled registers.
+  LBFT_HD bool handle_response_epoch(u32 node, u32 peer, u32 slot, u32& e) {
     u32 rbase = sfw(slot, 0);
     u32 req_epoch = ld(sqw(rbase, 0)), req_certs = ld(sqw(rbase, 1));
     u32 peer_epoch = ld(rbase + S_EPOCH);
-    for (u32 e = req_epoch; e <= peer_epoch; e++) {  // (no entries when the requester was ahead of the peer)
-      u32 mine = nf(node, NF_EPOCH);
-      if (e < mine) continue;
-      if (e > mine) break;
-      u32 base = e == peer_epoch ? rbase : arch_base(peer, e);
-      insert_unknown_records(node, base, e == req_epoch, req_certs >> 16, req_certs & 0xffffu);
-      if (e == peer_epoch) break;
-      process_commits(node);
-      bool tq; i64 tnext;
-      update_tracker(node, (i64)(i32)nf(node, NF_LQAT), lclock, tq, tnext);
-    }
+    u32 mine = nf(node, NF_EPOCH);
+    if (e < mine) e = mine;  // (entries of epochs the node has left are skipped)
+    if (e > peer_epoch || e > mine) return false;  // (no entries when the requester was ahead of the peer)
+    u32 base = e == peer_epoch ? rbase : arch_base(peer, e);
+    insert_unknown_records(node, base, e == req_epoch, req_certs >> 16, req_certs & 0xffffu);
+    if (e == peer_epoch) return false;
+    e++;
+    return true;
+  }
+  LBFT_HD u32 response_first_epoch(u32 slot) const { return ld(sqw(sfw(slot, 0), 0)); }
+  // (the node-level interface: the whole call at once)
+  LBFT_HD void handle_response(u32 node, u32 peer, u32 slot, i64 lclock) {
+    u32 e = response_first_epoch(slot);
+    while (handle_response_epoch(node, peer, slot, e)) update_node(node, lclock, true);
   }
 
   // `twin`: (E2) the copy for even-indexed receivers of an equivocator's notification carries the twin proposal
@@ -2072,7 +2095,7 @@ struct SimT {
   }
 
   // ---- SimulatedNode::update (simulator.rs:176-179) ----
-  LBFT_HD Actions node_update(u32 node) { return update_node(node, (i64)clock - (i64)(i32)nf(node, NF_STARTUP)); }
+  LBFT_HD Actions node_update(u32 node, bool tail_only = false) { return update_node(node, (i64)clock - (i64)(i32)nf(node, NF_STARTUP), tail_only); }
 
   // quirks bit 0: a request carries the requester's epoch and the certificates heading its chains, from which the peer
   // derives known_quorum_certificate_rounds (data_sync.rs:66-71).  Returns a snapshot slot (refcount still 0) or -1.
@@ -2622,7 +2645,7 @@ struct SimT {
   LBFT_HD void init(u64 seed) {
     for (u32 w = 0; w < I_WORDS; w++) st(w, 0);
     clock = 0; stamp = 0; qlen = 0; nblocks = 0; fault = 0; maxq = 0; maxsnap = 0;
-    ev0 = ev1 = ev2 = ev3 = 0; n_fold = 0; n_upd = 0;
+    ev0 = ev1 = ev2 = ev3 = 0; n_fold = 0; n_upd = 0; cont = 0;
     sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0;
     blk_cache_reset();
     snap_free = P.scap;
@@ -2674,10 +2697,18 @@ struct SimT {
   LBFT_HD bool step_begin(StepCtx& c) {  // false: the queue is empty
     {
       i32 t; u32 kind, meta;
-      if (!pop_event(t, kind, meta)) return false;
-      LBFT_MARK(0);
-      LBFT_COUNT(30);
-      if (tracing()) trace_round_switch(last_node, t);
+      // A response that spans several epochs (quirks bit 0) is one event but several steps: between two epochs the reference runs
+      // process_commits + update_tracker (handle_response_epoch), which this loop does at update_node's site, writes the node
+      // back and comes round again -- the event loop itself is the back edge (a loop inside the step kept 50 more
+      // registers alive across it).
+      const bool resumed = q1() && cont != 0;
+      if (resumed) { t = clock; kind = 2; meta = ld(I_CONT_META); }
+      else {
+        if (!pop_event(t, kind, meta)) return false;
+        LBFT_MARK(0);
+        LBFT_COUNT(30);
+        if (tracing()) trace_round_switch(last_node, t);
+      }
       i32 t_event = t;
       if (t > clock) clock = t;
       u32 node = meta & 0xffu, sender = (meta >> 8) & 0xffu, slot = meta >> 16;
@@ -2685,7 +2716,7 @@ struct SimT {
       // One shared site for the node-row burst (and, for a notification, its snapshot words in the same
       // burst), one for update_node + process_node_actions: lanes of a wavefront that handle different
       // event kinds issue their loads together instead of one serialized round trip per kind.
-      bool do_update = true, sync = false;
+      bool do_update = true, sync = false, more = false;
       SendPlan sp;
       sp.response = 0; sp.resp_slot = 0; sp.sync = 0; sp.sync_stamp = 0; sp.sync_epoch = 0; sp.sync_certs = 0; sp.have_actions = 0;
       begin_node((q1() && kind == 1) ? sender : node);  // Q1 fixed: a request is processed on the peer it was sent to
@@ -2742,10 +2773,12 @@ struct SimT {
         do_update = false;
         LBFT_MARK(4);
       } else {  // DataSyncResponseEvent (simulator.rs:454-466): under Q1 handle_response inserts nothing
-        ev2++; LBFT_STAT(4);
+        if (!resumed) { ev2++; LBFT_STAT(4); }
         if (q1()) {
-          handle_response(node, sender, slot, (i64)clock - (i64)(i32)nf(node, NF_STARTUP));
-          snap_release(slot);
+          u32 e = resumed ? cont - 1u : response_first_epoch(slot);
+          more = handle_response_epoch(node, sender, slot, e);
+          if (more) { cont = e + 1u; if (!resumed) st(I_CONT_META, meta); }
+          else { cont = 0; snap_release(slot); }
         }
         LBFT_MARK(5);
       }
@@ -2753,13 +2786,15 @@ struct SimT {
       a.next = LBFT_NEVER; a.send_to = -1; a.broadcast = false; a.query_all = false;
       if (do_update) {
 #if !defined(LBFT_NO_EXEC_COUNTERS)
-        n_upd++;
+        if (!more) n_upd++;
 #endif
-        a = node_update(node);
-        if (sync) { sp.sync = 1; sp.sync_stamp = stamp++; }  // the request is scheduled before the timer (simulator.rs:424-440)
-        LBFT_MARK(11);
-        process_node_actions(node, a);
-        sp.have_actions = 1;
+        a = node_update(node, more);  // (more: only the commit / tracker tail, nothing scheduled or sent; the event goes on at the next step)
+        if (!more) {
+          if (sync) { sp.sync = 1; sp.sync_stamp = stamp++; }  // the request is scheduled before the timer (simulator.rs:424-440)
+          LBFT_MARK(11);
+          process_node_actions(node, a);
+          sp.have_actions = 1;
+        }
       }
       send_loop(node, sender, sp, a);
       c.node = node; c.sender = sender; c.kind = kind; c.t_event = t_event; c.do_update = do_update;
@@ -2845,7 +2880,7 @@ inline int sim_class(const Params& p) {
 }
 
 // Does a class-2 / class-1 batch qualify for the lean kernel of its class (SimT<5> / SimT<6>)?
-inline bool sim_lean_features(const Params& p) { return (!(p.quirks & 1u) || (LBFT_LEAN_Q1 && p.n > 32)) && !p.rcap && !p.drop_ppm && !p.part_size; }
+inline bool sim_lean_features(const Params& p) { return (!(p.quirks & 1u) || (p.n > 32 ? LBFT_LEAN_Q1 : LBFT_LEAN1_Q1)) && !p.rcap && !p.drop_ppm && !p.part_size; }
 inline bool sim_lean(const Params& p) { return sim_class(p) == 2 && sim_lean_features(p); }
 inline bool sim_lean1(const Params& p) { return sim_class(p) == 1 && sim_lean_features(p); }
 

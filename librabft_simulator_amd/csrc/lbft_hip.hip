@@ -191,16 +191,22 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
   unsigned long long pending = __ballot(active && !done);
   if (pending && lane == (u32)(__ffsll((long long)pending) - 1)) atomicAdd(unfinished, (u32)__popcll(pending));
 }
+// (register-budget experiments: -DLBFT_DEV_ONLY_CLASS=k compiles the event loop of class k alone -- seconds instead of minutes; never a product build)
+#if defined(LBFT_DEV_ONLY_CLASS)
+#define LBFT_DEV_ONLY(k) if ((k) != LBFT_DEV_ONLY_CLASS) return;
+#else
+#define LBFT_DEV_ONLY(k)
+#endif
 // Class 0 (the headline small-network path) is compiled for two wavefronts per SIMD; classes 1 and 2 run one 8- or 16-lane
 // wavefront per SIMD and may use the whole register file (VGPRs + AGPRs).
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
-void lbft_k_run0(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { run_body<0>(p, state, unfinished); }
+void lbft_k_run0(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(0) run_body<0>(p, state, unfinished); }
 // Large networks without record exchange / trace / lossy network (sim_lean()): also two wavefronts per SIMD (21 spilled registers)
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
-void lbft_k_run2l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { run_body<5>(p, state, unfinished); }
+void lbft_k_run2l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(5) run_body<5>(p, state, unfinished); }
 // ... and class 1 without them (networks of <= 32 nodes with equivocators, a heap / calendar queue, ...): 13 spilled registers
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
-void lbft_k_run1l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { run_body<6>(p, state, unfinished); }
+void lbft_k_run1l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(6) run_body<6>(p, state, unfinished); }
 #ifndef LBFT_BIG_WAVES_PER_SIMD
 #define LBFT_BIG_WAVES_PER_SIMD 1  // classes 1-2: wavefronts per SIMD the kernels are compiled for (1 = the whole register file;
                                    // measured with 2 -- half the lanes per wavefront, 167 spilled registers: 16384 x 64 nodes
@@ -211,7 +217,7 @@ __global__ __launch_bounds__(LBFT_RUN_BLOCK)
 #if LBFT_BIG_WAVES_PER_SIMD > 1
 __attribute__((amdgpu_waves_per_eu(LBFT_BIG_WAVES_PER_SIMD, LBFT_BIG_WAVES_PER_SIMD)))
 #endif
-void lbft_k_run(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { run_body<CLS>(p, state, unfinished); }
+void lbft_k_run(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(CLS) run_body<CLS>(p, state, unfinished); }
 
 __device__ __forceinline__ u64 wave_sum(u64 v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
