@@ -49,26 +49,26 @@ typedef int64_t i64;
 #ifndef LBFT_SPEC
 #define LBFT_SPEC 1  // calendar queue: the entry behind the popped one is fetched ahead
 #endif
-// ... and for the two-wavefronts-per-SIMD large-network kernel (256 registers): every staged word there is a spilled register, and the
-// spills cost more than the round trips they save (16 384 x 64 nodes: 451 ms without, 476 / 504 / 511 ms with AX / SPEC / all three)
+// ... and for the two-wavefronts-per-SIMD large-network kernels (SimT<5> / SimT<7>, 256 registers), where a staged word that does not fit
+// is a spilled register and costs more than the round trip it saves.  What pays is decided by what else is in the register file: with
+// the trace / free-slot-mask state out of it and ONE cached block record, the staged author sets and the calendar fetch-ahead fit
+// (4 / 12 spilled registers) -- 16 384 x 64: 386 -> 375 ms, 8 192 x 100: 2.23 -> 2.04 s, live: 3.46 -> 3.32 s, 5.80 -> 5.35 s; the
+// blocks' staged node-set words (BX) stay out (+-0), 3 cached records spill 57 / 123 registers (420 ms).
 #ifndef LBFT_LEAN_AX
-#define LBFT_LEAN_AX 0
+#define LBFT_LEAN_AX 1
 #endif
 #ifndef LBFT_LEAN_BX
 #define LBFT_LEAN_BX 0
 #endif
 #ifndef LBFT_LEAN_SPEC
-#define LBFT_LEAN_SPEC 0
+#define LBFT_LEAN_SPEC 1
 #endif
 #ifndef LBFT_LEAN_Q1
-#define LBFT_LEAN_Q1 1   // the two-wavefronts-per-SIMD large-network kernel also handles the record exchange of quirks bit 0 (34 spilled registers
-                         // since a response's epochs are separate steps; 16 384 x 64 live: 3.46 s against 4.11 s on the full-register kernel)
-#endif
-#ifndef LBFT_LEAN1_Q1
-#define LBFT_LEAN1_Q1 0  // ... and the two-wavefront kernel of class 1 (networks of <= 32 nodes)
+#define LBFT_LEAN_Q1 1   // large networks with the record exchange of quirks bit 0 run on a two-wavefronts-per-SIMD kernel too (SimT<7>): possible
+                         // since a response's epochs are separate steps; 16 384 x 64 live: 3.46 s against 4.11 s on the full-register kernel
 #endif
 #ifndef LBFT_BLK_CACHE_LEAN2
-#define LBFT_BLK_CACHE_LEAN2 2  // (two-wavefront large-network kernel: 16 384 x 64 nodes 420 ms at 2 records, 449 ms at 3: ten fewer spilled registers)
+#define LBFT_BLK_CACHE_LEAN2 1
 #endif
 #define LBFT_MAX_NODES 128  // node / author sets are 1..4 32-bit words (word 0 in the hot rows, the rest in extension rows)
 
@@ -542,17 +542,19 @@ struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at
 //      plain large-network path fits 256 registers (21 spilled) and runs two wavefronts per SIMD with half the lanes each
 template <int CLS>
 struct SimT {
-  static constexpr bool BIG = CLS == 2 || CLS == 5;   // multi-word node / author sets
-  static constexpr bool LEAN = CLS == 5 || CLS == 6;  // 6 = class 1 without those three (13 spilled registers at 256)
+  static constexpr bool LEAN2 = CLS == 5 || CLS == 7;  // 7 = 5 plus the record exchange of quirks bit 0 (34 spilled registers; a kernel of its own: with
+                                                       // that code compiled in, the runs without it lose 10 %)
+  static constexpr bool BIG = CLS == 2 || LEAN2;       // multi-word node / author sets
+  static constexpr bool LEAN = LEAN2 || CLS == 6;      // 6 = class 1 without those three (13 spilled registers at 256)
   // Large networks: the lanes of a wavefront cooperate on one network's broadcasts (coop_bulk); every class that may meet such a
   // batch's state (the generic class 3 reads back / steps any batch) honours its ring of pre-generated draws.
   // 64-wide tiles addressed at compile time for the small-network classes (many lanes per wavefront); the large-network
   // classes address tiles of P.tw = lanes per wavefront (lbft_core.h "HBM layout")
   static constexpr bool TILE64 = CLS == 0 || CLS == 1 || CLS == 6;
   static constexpr bool IMAJOR = BIG;  // large networks: tile width 1 = every instance's words contiguous (P.tw == 1), addressed at compile time
-  static constexpr bool F_AX = CLS == 5 ? (LBFT_LEAN_AX != 0) : (LBFT_AX != 0);      // (tuning switches above)
-  static constexpr bool F_BX = CLS == 5 ? (LBFT_LEAN_BX != 0) : (LBFT_BX != 0);
-  static constexpr bool F_SPEC = CLS == 5 ? (LBFT_LEAN_SPEC != 0) : (LBFT_SPEC != 0);
+  static constexpr bool F_AX = LEAN2 ? (LBFT_LEAN_AX != 0) : (LBFT_AX != 0);      // (tuning switches above)
+  static constexpr bool F_BX = LEAN2 ? (LBFT_LEAN_BX != 0) : (LBFT_BX != 0);
+  static constexpr bool F_SPEC = LEAN2 ? (LBFT_LEAN_SPEC != 0) : (LBFT_SPEC != 0);
   static constexpr bool COOP = BIG;
   static constexpr bool RING = BIG || CLS == 3;
   bool coop_on;  // set by run_coop: the event loop is being run by a whole wavefront
@@ -560,7 +562,7 @@ struct SimT {
   LBFT_HD bool wide() const { return BIG ? true : (CLS == 3 ? P.n > 32 : false); }
   LBFT_HD bool heap() const { return CLS == 0 ? false : (BIG ? true : P.qheap != 0); }
   LBFT_HD bool tracing() const { return CLS != 0 && !LEAN && P.rcap != 0; }  // round-switch trace (DataWriter); class 0 never traces
-  LBFT_HD bool q1() const { return CLS != 0 && (!LEAN || (CLS == 5 && LBFT_LEAN_Q1) || (CLS == 6 && LBFT_LEAN1_Q1)) && (P.quirks & 1u) != 0; }  // requests are answered by the peer with real payloads
+  LBFT_HD bool q1() const { return CLS != 0 && (!LEAN || CLS == 7) && (P.quirks & 1u) != 0; }  // requests are answered by the peer with real payloads
   LBFT_HD bool cal() const { return CLS != 0 && P.qcal != 0; }
   LBFT_HD bool packed() const { return CLS == 0 ? true : (BIG ? false : P.n <= 16); }
   LBFT_HD bool qpacked() const { return CLS == 0 ? true : (CLS == 3 ? P.qpack != 0 : false); }  // one-word queue entries
@@ -749,7 +751,7 @@ struct SimT {
     LBFT_HD u32 epoch() const { return w[B_EPOCH]; }
     LBFT_HD u32 depth() const { return w[B_DEPTH]; }
   };
-  static constexpr u32 BCN = CLS == 5 ? LBFT_BLK_CACHE_LEAN2 : LBFT_BLK_CACHE;
+  static constexpr u32 BCN = LEAN2 ? LBFT_BLK_CACHE_LEAN2 : LBFT_BLK_CACHE;
   mutable u32 bc_id[BCN];
   mutable u32 bc_w[BCN][BC_WORDS];
   mutable u32 bc_next, bc_ref;  // FIFO hand + "recently used" bits (second chance: a hot old block survives)
@@ -880,7 +882,7 @@ struct SimT {
     qlen = ld(I_QLEN); snap_free = ld(I_SNAP_FREE); nblocks = ld(I_NBLOCKS); fault = ld(I_FAULT);
     ev0 = ld(I_EV0); ev1 = ld(I_EV1); ev2 = ld(I_EV2); ev3 = ld(I_EV3);
     maxq = ld(I_MAXQ); maxsnap = ld(I_MAXSNAP);
-    if (CLS != 5) {  // (state the two-wavefront large-network kernel never touches stays in its rows)
+    if (!LEAN2) {  // (state the two-wavefront large-network kernels never touch stays in its rows)
       snap_mask = ld(I_SNAP_MASK_LO) | ((u64)ld(I_SNAP_MASK_HI) << 32);
       last_node = ld(I_LAST_NODE); vd_time = ld(I_VD_TIME); vd_stamp = ld(I_VD_STAMP);
     } else { snap_mask = 0; last_node = 0; vd_time = 0xffffffffu; vd_stamp = 0; }
@@ -899,7 +901,7 @@ struct SimT {
     st(I_QLEN, qlen); st(I_SNAP_FREE, snap_free); st(I_NBLOCKS, nblocks); st(I_FAULT, fault);
     st(I_EV0, ev0); st(I_EV1, ev1); st(I_EV2, ev2); st(I_EV3, ev3);
     st(I_MAXQ, maxq); st(I_MAXSNAP, maxsnap);
-    if (CLS != 5) {
+    if (!LEAN2) {
       st(I_SNAP_MASK_LO, (u32)snap_mask); st(I_SNAP_MASK_HI, (u32)(snap_mask >> 32));
       st(I_LAST_NODE, last_node); st(I_VD_TIME, vd_time); st(I_VD_STAMP, vd_stamp);
     }
@@ -1180,7 +1182,7 @@ struct SimT {
   }
   // (the register-resident free mask serves batches of <= 64 slots; the two-wavefront large-network kernel never has that few and
   // keeps the mask out of its registers)
-  LBFT_HD bool mask_slots() const { return CLS == 5 ? false : P.scap <= 64; }
+  LBFT_HD bool mask_slots() const { return LEAN2 ? false : P.scap <= 64; }
   LBFT_HD void snap_free_slot(u32 slot) {
     if (mask_slots()) snap_mask |= 1ULL << slot;
     else { st(P.off_snap_free + snap_free, slot); snap_free++; }
@@ -2880,8 +2882,9 @@ inline int sim_class(const Params& p) {
 }
 
 // Does a class-2 / class-1 batch qualify for the lean kernel of its class (SimT<5> / SimT<6>)?
-inline bool sim_lean_features(const Params& p) { return (!(p.quirks & 1u) || (p.n > 32 ? LBFT_LEAN_Q1 : LBFT_LEAN1_Q1)) && !p.rcap && !p.drop_ppm && !p.part_size; }
+inline bool sim_lean_features(const Params& p) { return (!(p.quirks & 1u) || (LBFT_LEAN_Q1 && p.n > 32)) && !p.rcap && !p.drop_ppm && !p.part_size; }
 inline bool sim_lean(const Params& p) { return sim_class(p) == 2 && sim_lean_features(p); }
+inline bool sim_lean_q1(const Params& p) { return sim_lean(p) && (p.quirks & 1u) != 0; }  // ... SimT<7> instead of SimT<5>
 inline bool sim_lean1(const Params& p) { return sim_class(p) == 1 && sim_lean_features(p); }
 
 // Row layout for a batch; fills the offset fields of `p` and returns words per instance.  Accumulated in 64 bits: a tile is

@@ -137,7 +137,8 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
       if (cls == 0) { SimT<0> s(p, state.data(), (u32)i); run_one(s, i); }
       else if (cls == 1 && sim_lean1(p)) { SimT<6> s(p, state.data(), (u32)i); run_one(s, i); }  // as the device dispatches
       else if (cls == 1) { SimT<1> s(p, state.data(), (u32)i); run_one(s, i); }
-      else if (cls == 2 && sim_lean(p)) { SimT<5> s(p, state.data(), (u32)i); run_one(s, i); }  // as the device dispatches
+      else if (cls == 2 && sim_lean_q1(p)) { SimT<7> s(p, state.data(), (u32)i); run_one(s, i); }  // as the device dispatches
+      else if (cls == 2 && sim_lean(p)) { SimT<5> s(p, state.data(), (u32)i); run_one(s, i); }
       else if (cls == 2) { SimT<2> s(p, state.data(), (u32)i); run_one(s, i); }
       else { Sim s(p, state.data(), (u32)i); run_one(s, i); }
     }

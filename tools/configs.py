@@ -44,7 +44,7 @@ def kernel_name(layout):
     if cls == 0:
         return "lbft_k_run0"
     if lean:
-        return "lbft_k_run2l" if cls == 2 else "lbft_k_run1l"
+        return ("lbft_k_run2q" if k & 4096 else "lbft_k_run2l") if cls == 2 else "lbft_k_run1l"
     return "lbft_k_run<%d>" % cls
 
 
