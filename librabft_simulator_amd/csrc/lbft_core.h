@@ -1797,7 +1797,8 @@ struct SimT {
   // heading the peer's chains plus its timeouts and proposed block -- the same words as a notification snapshot. ----
   LBFT_HD u32 sqw(u32 base, u32 k) const { return base + S_FIXED_WORDS + 2 * P.n + 2 * (P.mw - 1) + k; }
   // RecordStoreState as seen by unknown_records: written into `base` (a snapshot slot or an epoch-archive entry)
-  LBFT_HD void write_store_snapshot(u32 node, u32 base) const {
+  // `skip_hcbr`: the caller has the timeouts' hcbr words copied by all lanes of the wavefront (coop_copy_hcbr_to)
+  LBFT_HD void write_store_snapshot(u32 node, u32 base, bool skip_hcbr = false) const {
     st(base + S_EPOCH, nf(node, NF_EPOCH));
     st(base + S_CERTS, nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16));
     st(base + S_PROP_VOTE, nf(node, NF_PROPOSED_BLK));  // current_proposed_block, whoever proposed it
@@ -1810,8 +1811,10 @@ struct SimT {
       st(k == 0 ? base + S_TC_MASK : base + S_FIXED_WORDS + 2 * P.n + (k - 1), tk);
       st(k == 0 ? base + S_TO_MASK : base + S_FIXED_WORDS + 2 * P.n + (P.mw - 1) + (k - 1), ok);
       // (several loads in flight per round trip: a load-store-load-store chain is one memory round trip per author)
-      copy_hcbr_to(node, base + S_FIXED_WORDS, tk, 32 * k, tc_sel);
-      copy_hcbr_to(node, base + S_FIXED_WORDS + P.n, ok, 32 * k, 1u - tc_sel);
+      if (!skip_hcbr) {
+        copy_hcbr_to(node, base + S_FIXED_WORDS, tk, 32 * k, tc_sel);
+        copy_hcbr_to(node, base + S_FIXED_WORDS + P.n, ok, 32 * k, 1u - tc_sel);
+      }
     }
   }
   LBFT_HD u32 arch_base(u32 node, u32 epoch) const { return P.off_arch + (node * P.ecap + epoch) * P.snap_words; }
@@ -1821,6 +1824,8 @@ struct SimT {
   // chain) pair keeps a cursor that moves down the requester's chain monotonically (one light two-word fetch per block,
   // not through the block cache: nothing else looks at these old records) instead of restarting from the top for every
   // query: O(gap) block fetches per response instead of O(gap^2).
+  struct Snap { u32 w[S_FIXED_WORDS]; u32 refs; u32 to_hcbr[4]; };  // (see load_snapshot)
+  struct Resp { u32 epoch, certs, prop, req_epoch, req_certs; };  // (see load_response)
   struct KnownCursor { u32 x, i, xr; };  // requester-chain block x at position i with round xr (x == 0: end of the chain)
   LBFT_HD void chain_fetch(u32 x, u32& round, u32& prev) const {
     u32 bb = boff(bfw(x, 0));
@@ -1843,29 +1848,38 @@ struct SimT {
   }
   // unknown_records (record_store.rs:801-831) of the store described at `base`, inserted into node's current store in
   // the order the reference sends them: (block, QC) pairs by ascending round, the timeouts, the proposed block.
-  LBFT_HD void insert_unknown_records(u32 node, u32 base, bool filter, u32 k_hqc, u32 k_hcc) {
-    u32 certs = ld(base + S_CERTS);
+  // `rp` / `have`: the words of `base` that decide what is walked, already fetched (load_response: the response's own store; an
+  // archived store of an earlier epoch is read from its rows -- and so are the timeout words, which are needed last).  Most responses carry nothing the requester lacks (16 384 x 64 live: 325 new
+  // records in 24.6 k responses per network), so the path to "nothing to insert" is two round trips: everything that decides it --
+  // the heads of the peer's two chains (round + previous block: two words each, not through the block cache), the heads of the
+  // requester's two chains, the "known" word of the proposed block -- is fetched in ONE burst.
+  LBFT_HD void insert_unknown_records(u32 node, u32 base, bool filter, u32 k_hqc, u32 k_hcc, const Resp& rp, bool have) {
+    u32 certs = have ? rp.certs : ld(base + S_CERTS);
     u32 x1 = certs >> 16, x2 = certs & 0xffffu, cnt = 0;
+    const u32 pb = (have ? rp.prop : ld(base + S_PROP_VOTE)) & 0xffffu;
+    u32 r1r = 0, r1p = 0, r2r = 0, r2p = 0, pbk = 0;
+    if (x1) chain_fetch(x1, r1r, r1p);
+    if (x2) chain_fetch(x2, r2r, r2p);
+    if (pb) pbk = ld((!wide() || node < 32) ? bfw(pb, B_KNOWN) : bxw(pb, B_KNOWN, node >> 5));
     // cursors [peer chain][requester chain]
     KnownCursor q1q = known_start(filter ? k_hqc : 0), q1c = known_start(filter ? k_hcc : 0), q2q = q1q, q2c = q1c;
-    Blk r1, r2;
-    for (u32 f = 0; f < BC_WORDS; f++) { r1.w[f] = 0; r2.w[f] = 0; }
-    r1.xk = r2.xk = 0; r1.x[0] = r1.x[1] = r1.x[2] = 0; r2.x[0] = r2.x[1] = r2.x[2] = 0;
-    bool fresh1 = true, fresh2 = true;  // x1 / x2 moved to a block that has not been looked at yet
+    bool fresh1 = false, fresh2 = false;  // x1 / x2 moved to a block that has not been looked at yet (the heads have)
+    if (x1 && filter && (known_at(q1q, r1r) || known_at(q1c, r1r))) x1 = 0;
+    if (x2 && filter && (known_at(q2q, r2r) || known_at(q2c, r2r))) x2 = 0;
     for (;;) {  // util.rs merge_sort of the two chains by descending round, identical certificates once
-      if (x1 && fresh1) { r1 = blk_get(x1); fresh1 = false; if (filter && (known_at(q1q, r1.round()) || known_at(q1c, r1.round()))) x1 = 0; }
-      if (x2 && fresh2) { r2 = blk_get(x2); fresh2 = false; if (filter && (known_at(q2q, r2.round()) || known_at(q2c, r2.round()))) x2 = 0; }
+      if (x1 && fresh1) { chain_fetch(x1, r1r, r1p); fresh1 = false; if (filter && (known_at(q1q, r1r) || known_at(q1c, r1r))) x1 = 0; }
+      if (x2 && fresh2) { chain_fetch(x2, r2r, r2p); fresh2 = false; if (filter && (known_at(q2q, r2r) || known_at(q2c, r2r))) x2 = 0; }
       if (!x1 && !x2) break;
       u32 e1 = 0, e2 = 0;
       if (x1 && x2) {
-        if (r2.round() < r1.round()) e1 = x1;
-        else if (r2.round() == r1.round()) { e1 = x1; if (x2 != x1) e2 = x2; }
+        if (r2r < r1r) e1 = x1;
+        else if (r2r == r1r) { e1 = x1; if (x2 != x1) e2 = x2; }
         else e2 = x2;
-        bool adv1 = r2.round() <= r1.round(), adv2 = r2.round() >= r1.round();
-        if (adv1) { x1 = r1.prev(); fresh1 = true; }
-        if (adv2) { x2 = r2.prev(); fresh2 = true; }
-      } else if (x1) { e1 = x1; x1 = r1.prev(); fresh1 = true; }
-      else { e2 = x2; x2 = r2.prev(); fresh2 = true; }
+        bool adv1 = r2r <= r1r, adv2 = r2r >= r1r;
+        if (adv1) { x1 = r1p; fresh1 = true; }
+        if (adv2) { x2 = r2p; fresh2 = true; }
+      } else if (x1) { e1 = x1; x1 = r1p; fresh1 = true; }
+      else { e2 = x2; x2 = r2p; fresh2 = true; }
       if (e1) { if (cnt < P.bcap) st(P.off_sync + cnt, e1); else fault |= F_EPOCH_OVERFLOW; cnt++; }
       if (e2) { if (cnt < P.bcap) st(P.off_sync + cnt, e2); else fault |= F_EPOCH_OVERFLOW; cnt++; }
     }
@@ -1893,8 +1907,8 @@ struct SimT {
       u32 ok = ld(k == 0 ? base + S_TO_MASK : base + S_FIXED_WORDS + 2 * P.n + (P.mw - 1) + (k - 1));
       insert_timeouts_at(node, base + S_FIXED_WORDS + P.n, ok, to_round, 32 * k);
     }
-    u32 pb = ld(base + S_PROP_VOTE) & 0xffffu;
-    if (pb) insert_block(node, pb);
+    // the proposed block, unless the burst above found it known to the node already (a bit that is only ever set)
+    if (pb && !((pbk >> (node & 31u)) & 1u)) insert_block(node, pb);
   }
   // DataSyncNode::handle_response (data_sync.rs:209-240): `slot` = the peer's store at request time + the request.
   // The reference inserts the unknown records epoch by epoch and runs process_commits + update_tracker between two epochs
@@ -1902,24 +1916,35 @@ struct SimT {
   // (e = the next epoch) when that in-between step is due: the event loop runs it at update_node's own process_commits /
   // update_tracker site (update_node(.., tail_only)) instead of a second inlined copy here, which alone cost the
   // two-wavefront kernel 160 spilled registers.
-  LBFT_HD bool handle_response_epoch(u32 node, u32 peer, u32 slot, u32& e) {
+  LBFT_HD bool handle_response_epoch(u32 node, u32 peer, u32 slot, u32& e, const Resp& rp) {
     u32 rbase = sfw(slot, 0);
-    u32 req_epoch = ld(sqw(rbase, 0)), req_certs = ld(sqw(rbase, 1));
-    u32 peer_epoch = ld(rbase + S_EPOCH);
+    u32 req_epoch = rp.req_epoch, req_certs = rp.req_certs;
+    u32 peer_epoch = rp.epoch;
     u32 mine = nf(node, NF_EPOCH);
     if (e < mine) e = mine;  // (entries of epochs the node has left are skipped)
     if (e > peer_epoch || e > mine) return false;  // (no entries when the requester was ahead of the peer)
-    u32 base = e == peer_epoch ? rbase : arch_base(peer, e);
-    insert_unknown_records(node, base, e == req_epoch, req_certs >> 16, req_certs & 0xffffu);
-    if (e == peer_epoch) return false;
+    bool cur = e == peer_epoch;
+    u32 base = cur ? rbase : arch_base(peer, e);
+    insert_unknown_records(node, base, e == req_epoch, req_certs >> 16, req_certs & 0xffffu, rp, cur);
+    if (cur) return false;
     e++;
     return true;
   }
-  LBFT_HD u32 response_first_epoch(u32 slot) const { return ld(sqw(sfw(slot, 0), 0)); }
+  // The words of a response that decide its walk (the peer's store at request time: epoch, certificates, proposed block) and the
+  // request it answers (epoch, certificates), in one burst.
+  LBFT_HD Resp load_response(u32 slot) const {
+    Resp rp;
+    u32 sb = boff(P.off_snap + slot * P.snap_words);
+    rp.epoch = ldf(sb, S_EPOCH); rp.certs = ldf(sb, S_CERTS); rp.prop = ldf(sb, S_PROP_VOTE);
+    u32 qb = sqw(sfw(slot, 0), 0);
+    rp.req_epoch = ld(qb); rp.req_certs = ld(qb + 1);
+    return rp;
+  }
   // (the node-level interface: the whole call at once)
   LBFT_HD void handle_response(u32 node, u32 peer, u32 slot, i64 lclock) {
-    u32 e = response_first_epoch(slot);
-    while (handle_response_epoch(node, peer, slot, e)) update_node(node, lclock, true);
+    Resp rp = load_response(slot);
+    u32 e = rp.req_epoch;
+    while (handle_response_epoch(node, peer, slot, e, rp)) update_node(node, lclock, true);
   }
 
   // `twin`: (E2) the copy for even-indexed receivers of an equivocator's notification carries the twin proposal
@@ -1967,7 +1992,8 @@ struct SimT {
   // The hcbr words of a snapshot that write_snapshot(.., skip_hcbr) left out, copied by all lanes of the wavefront at once
   // (lane = author): one load + one store per lane instead of a chain of 8-author batches in the leader lane.  `k` = the
   // leader lane, whose node cache holds the sets.
-  LBFT_HD void coop_copy_hcbr(u32 k, u32 l4, u32 node, u32 slot) const {
+  LBFT_HD void coop_copy_hcbr(u32 k, u32 l4, u32 node, u32 slot) const { coop_copy_hcbr_to(k, l4, node, sfw(slot, 0)); }
+  LBFT_HD void coop_copy_hcbr_to(u32 k, u32 l4, u32 node, u32 base) const {
     const bool is_k = LBFT_IS_LANE(k);
     u32 tw_[4] = {0, 0, 0, 0}, ow_[4] = {0, 0, 0, 0}, sel_k = 0;
     if (is_k) {
@@ -1985,7 +2011,7 @@ struct SimT {
 #endif
     for (u32 q = 0; q < 4; q++) { tcw[q] = LBFT_UNI(tw_[q], k); tow[q] = LBFT_UNI(ow_[q], k); }
     const u32 src_tc = nfw(node, NF_FIXED_WORDS + tc_sel * P.n), src_to = nfw(node, NF_FIXED_WORDS + (1u - tc_sel) * P.n);
-    const u32 dst_tc = sfw(slot, S_FIXED_WORDS), dst_to = sfw(slot, S_FIXED_WORDS + P.n);
+    const u32 dst_tc = base + S_FIXED_WORDS, dst_to = base + S_FIXED_WORDS + P.n;
     for (u32 a0 = 0; a0 < P.n; a0 += 64u) {
       const u32 q0 = a0 >> 5;
       PL<u32> vt, vo, ht, ho;
@@ -2008,7 +2034,6 @@ struct SimT {
   // fixed words, the slot's reference count and (networks of <= 4 nodes) the highest_certified_block_round of the
   // sender's current timeouts -- every later dependent fetch would be a memory round trip of its own, serialised
   // with those of the lanes on other paths.
-  struct Snap { u32 w[S_FIXED_WORDS]; u32 refs; u32 to_hcbr[4]; };
   LBFT_HD bool small_sets() const { return CLS == 0 && P.n <= 4; }
   LBFT_HD Snap load_snapshot(u32 slot) const {
     Snap sn;
@@ -2328,6 +2353,7 @@ struct SimT {
   //     (= stamp) order, and one lane per bucket appends the chain to the bucket's tail -- one dependent load per distinct
   //     bucket instead of one memory round trip per message.
   u32 bulk;       // leader lane: bit 0 = a broadcast is pending, bit 1 = a query-all is pending (set by send_loop)
+  u32 bulk_copy;  // leader lane: bit 0 = the hcbr words of a response snapshot are to be copied (a request under quirks bit 0), slot << 8
   u32 bulk_node;  // leader lane: the node whose actions are being processed
   LBFT_HD u32 ldc(u32 l4, u32 w) const { return *reinterpret_cast<const u32*>(tile + (size_t)((IMAJOR ? (w << 2) : mul24(w, rowb())) + l4)); }
   LBFT_HD void stc(u32 l4, u32 w, u32 v) const { *reinterpret_cast<u32*>(tile + (size_t)((IMAJOR ? (w << 2) : mul24(w, rowb())) + l4)) = v; }
@@ -2766,7 +2792,10 @@ struct SimT {
           i32 rs = snap_alloc();
           if (rs >= 0) {
             u32 rb = sfw((u32)rs, 0);
-            write_store_snapshot(sender, rb);
+            // (cooperative kernels: the up to 2n hcbr words of the peer's timeouts are copied by all lanes of the wavefront right
+            // after this step's sends, lane = author, instead of eight per round trip here: bit 2 of `bulk`, the slot above it)
+            write_store_snapshot(sender, rb, coop());
+            if (coop()) bulk_copy = 1u | ((u32)rs << 8);
             st(sqw(rb, 0), req_epoch); st(sqw(rb, 1), req_certs);
           }
           sp.resp_slot = (u32)rs;
@@ -2777,9 +2806,12 @@ struct SimT {
       } else {  // DataSyncResponseEvent (simulator.rs:454-466): under Q1 handle_response inserts nothing
         if (!resumed) { ev2++; LBFT_STAT(4); }
         if (q1()) {
-          u32 e = resumed ? cont - 1u : response_first_epoch(slot);
-          more = handle_response_epoch(node, sender, slot, e);
-          if (more) { cont = e + 1u; if (!resumed) st(I_CONT_META, meta); }
+          // (fetched here, one round trip after the node rows: carried through the node-row burst these five words cost the
+          // two-wavefront kernel 36 more spilled registers)
+          Resp rp = load_response(slot);
+          u32 e = resumed ? cont - 1u : rp.req_epoch;
+          more = handle_response_epoch(node, sender, slot, e, rp);
+          if (more) { LBFT_STAT(46); cont = e + 1u; if (!resumed) st(I_CONT_META, meta); }
           else { cont = 0; snap_release(slot); }
         }
         LBFT_MARK(5);
@@ -2836,7 +2868,7 @@ struct SimT {
     u32 steps = 0;
     u32 max_steps = P.max_steps ? P.max_steps : 0xffffffffu;
     bool go = leader, drained = true;
-    bulk = 0; bulk_node = 0;
+    bulk = 0; bulk_node = 0; bulk_copy = 0;
     coop_on = true;
     for (;;) {
       if (go && steps >= max_steps) { go = false; drained = false; }
@@ -2847,7 +2879,7 @@ struct SimT {
 #endif
       StepCtx c;
       c.node = 0; c.sender = 0; c.kind = 0; c.t_event = 0; c.do_update = false;
-      bulk = 0;
+      bulk = 0; bulk_copy = 0;
       bool act = go;
       if (act) {
         // the generator runs ahead of the consumers in every network of the wavefront at once (see RngT)
@@ -2855,9 +2887,9 @@ struct SimT {
         if (!step_begin(c)) { go = false; act = false; } else steps++;
       }
 #if defined(__HIP_DEVICE_COMPILE__)
-      unsigned long long need = __ballot(act && bulk != 0);
+      unsigned long long need = __ballot(act && (bulk | bulk_copy) != 0);
 #else
-      unsigned long long need = (act && bulk != 0) ? 1ULL : 0ULL;
+      unsigned long long need = (act && (bulk | bulk_copy) != 0) ? 1ULL : 0ULL;
 #endif
       while (need) {
         u32 k = ctz64(need);
@@ -2865,6 +2897,10 @@ struct SimT {
         u32 bk = LBFT_UNI(bulk, k);
         if (bk & 1u) coop_bulk(k, 0);
         if (bk & 2u) coop_bulk(k, 1);
+        if (q1()) {  // a request answered in lane k: the peer (the node in its cache) is the event's sender
+          u32 bc = LBFT_UNI(bulk_copy, k);
+          if (bc & 1u) coop_copy_hcbr_to(k, LBFT_UNI(lane4, k), LBFT_UNI(c.sender, k), sfw(bc >> 8, 0));
+        }
       }
       if (act) step_end(c);
     }

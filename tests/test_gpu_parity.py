@@ -191,6 +191,17 @@ def test_multi_launch_equals_single_launch(amd, oracle):
     assert_equal_to_oracle(oracle, res, kw, seeds, 1000)
 
 
+@pytest.mark.parametrize("name,steps", [("rot3_n7_q3_cpe9", 5), ("rot5_n36_q3_cpe3", 211), ("rot7_n100_q3_cpe2", 1999)])
+def test_multi_launch_with_responses_spanning_epochs(amd, oracle, name, steps):
+    """Quirks bit 0 + epoch changes: a response whose records span several epochs is several steps of the event loop (its
+    continuation lives in the instance's scalar rows), so launches bounded to a few steps end between them."""
+    kw, m, max_clock = CASES[name]
+    seeds = np.arange(3, 3 + m, dtype=np.uint64) * 7919
+    _, res = run_gpu(amd, kw, seeds, max_clock, max_steps_per_launch=steps)
+    assert res.counters["launches"] > 10
+    assert_equal_to_oracle(oracle, res, kw, seeds, max_clock)
+
+
 def test_reset_reruns_identically(amd):
     seeds = np.arange(1, 129, dtype=np.uint64)
     sim, r1 = run_gpu(amd, dict(num_nodes=4), seeds, 1000)
