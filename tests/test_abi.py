@@ -123,9 +123,12 @@ def test_run_kernels_keep_their_state_in_registers(hiplib):
         assert v["private_segment_fixed_size"] <= 128, big
     lean = [v for k, v in kernels.items() if "lbft_k_run1l" in k]  # class 1 without record exchange / trace / loss: two wavefronts per SIMD as well
     assert len(lean) == 1 and all(v["vgpr_count"] <= 256 and v["private_segment_fixed_size"] <= 128 for v in lean), lean
-    lean2 = [v for k, v in kernels.items() if "lbft_k_run2l" in k]  # large networks without record exchange: two wavefronts per SIMD pay only while the trimmed loop
-    # keeps its state in registers (15 spilled registers as built; 118 with the staged sets was slower than one wavefront per SIMD)
-    assert len(lean2) == 1 and lean2[0]["vgpr_count"] <= 256 and lean2[0]["vgpr_spill_count"] <= 40, lean2
+    # large networks, two wavefronts per SIMD: without (run2l) and with (run2q) the record exchange of quirks bit 0.  They only pay while the
+    # trimmed loop keeps its state in registers: 4 / 24 spilled registers as built; 118 (staged sets) and 325 (a second inlined copy of
+    # update_node's tail inside handle_response) were slower than one wavefront per SIMD
+    for name, cap in (("lbft_k_run2l", 16), ("lbft_k_run2q", 48)):
+        lean2 = [v for k, v in kernels.items() if name in k]
+        assert len(lean2) == 1 and lean2[0]["vgpr_count"] <= 256 and lean2[0]["vgpr_spill_count"] <= cap, (name, lean2)
 
 
 def test_kernel_hash_reads_the_code_object(hiplib):
