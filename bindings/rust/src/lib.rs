@@ -77,6 +77,7 @@ extern "C" {
     fn lbft_last_error() -> *const c_char;
     fn lbft_batch_create(cfg: *const LbftConfig, seeds: *const u64, n: usize, device: c_int, out: *mut *mut c_void) -> c_int;
     fn lbft_batch_run_until(b: *mut c_void, max_clock: i64) -> c_int;
+    fn lbft_batch_save_node(b: *const c_void, inst: usize, node: u32, buf: *mut c_void, cap: usize, len: *mut usize) -> c_int;
     fn lbft_batch_commit_counts(b: *const c_void, out: *mut u32) -> c_int;
     fn lbft_batch_committed_history(b: *const c_void, inst: usize, node: u32, out: *mut LbftCommit, cap: usize, len: *mut usize) -> c_int;
     fn lbft_batch_last_committed_state(b: *const c_void, inst: usize, node: u32, out: *mut u64) -> c_int;
@@ -255,6 +256,8 @@ pub struct GpuRequest(pub Arc<DeviceMessage>);
 pub struct GpuResponse(pub Arc<DeviceMessage>);
 
 const SAVE_KEY: &str = "lbft_hip_node_saved_at";
+/// The key under which the reference stores `bincode::serialize(&NodeState)` (librabft-v2/src/node.rs:233-238).
+const NODE_IMAGE_KEY: &str = "node_state";
 
 impl GpuNode {
     fn message(&self, handle: u32) -> Arc<DeviceMessage> {
@@ -303,11 +306,30 @@ impl ConsensusNode<SimulatedContext> for GpuNode {
         }
     }
 
-    /// node.rs:233-238: the reference serialises the whole `NodeState`; the device state is already durable for the
-    /// lifetime of the batch (a whole-batch image is `lbft_batch_checkpoint_save`), so only the save marker is stored.
+    /// node.rs:233-238: `bincode::serialize(&NodeState)` under the reference's key.  `lbft_batch_save_node` builds that image
+    /// from the device state (HashMaps in ascending key order; the reference's `load_node` accepts any order), so a
+    /// reference node can be restored from what a GPU node saved.  A node that has changed epoch is not supported by
+    /// the device image (retired record stores are not kept in full): then only the save marker is stored -- the device
+    /// state itself stays durable for the lifetime of the batch (`lbft_batch_checkpoint_save` images the whole batch).
     fn save_node<'a>(&'a mut self, context: &'a mut SimulatedContext) -> AsyncResult<'a, ()> {
-        let value = self.last_saved.0.to_le_bytes().to_vec();
-        Box::pin(async move { context.store_value(SAVE_KEY.to_string(), value).await })
+        let marker = self.last_saved.0.to_le_bytes().to_vec();
+        let handle = self.batch.batch.handle as *const c_void;
+        let (inst, author) = (self.inst, self.author);
+        let mut len = 0usize;
+        let mut image = Vec::new();
+        let rc = unsafe { lbft_batch_save_node(handle, inst, author, std::ptr::null_mut(), 0, &mut len) };
+        if rc == 0 && len > 0 {
+            image.resize(len, 0u8);
+            if unsafe { lbft_batch_save_node(handle, inst, author, image.as_mut_ptr() as *mut c_void, len, &mut len) } != 0 {
+                image.clear();
+            }
+        }
+        Box::pin(async move {
+            if !image.is_empty() {
+                context.store_value(NODE_IMAGE_KEY.to_string(), image).await?;
+            }
+            context.store_value(SAVE_KEY.to_string(), marker).await
+        })
     }
 }
 
