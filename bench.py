@@ -124,6 +124,16 @@ def cpu_baseline(args, nodes, max_clock):
     }
 
 
+def run_kernel_name(kc):
+    """The run kernel a batch executes, from lbft_batch_layout's flag word (include/lbft.h)."""
+    cls = kc & 255
+    if cls == 0:
+        return "lbft_k_run0"
+    if kc & 1024:  # the two-wavefronts-per-SIMD kernels
+        return ("lbft_k_run2q" if kc & 4096 else "lbft_k_run2l") if cls == 2 else "lbft_k_run1l"
+    return "lbft_k_run<%d>" % cls
+
+
 def main():
     args = parse()
     import numpy as np
@@ -199,7 +209,7 @@ def main():
             "faulted_instances": faulted,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["gb_corrected"] if traffic else None, "traffic_unit": "GB per launch",
-                         "traffic_detail": traffic, "kernel": "lbft_k_run0" if layout.get("kernel_class", 0) == 0 else ("lbft_k_run2l" if (layout["kernel_class"] & 255) == 2 else "lbft_k_run1l") if layout["kernel_class"] & 1024 else "lbft_k_run<%d>" % (layout["kernel_class"] & 255), "kernel_ms": k_ms,
+                         "traffic_detail": traffic, "kernel": run_kernel_name(layout.get("kernel_class", 0)), "kernel_ms": k_ms,
                          "algorithmic_bytes_per_event": bpe, "algorithmic_gb_per_launch": local_events * bpe / 1e9,
                          "events_per_launch": local_events,
                          # the same roofline with traffic charged only where the device moves rows (folded duplicate timers never
