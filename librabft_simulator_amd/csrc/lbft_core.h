@@ -175,13 +175,23 @@ struct Params {
 #define LBFT_UMARK(k) LBFT_MARK(k)
 #define LBFT_CMARK(k) do { } while (0)
 #endif
-#if defined(LBFT_HOST_STATS) && !defined(__HIPCC__)
+#if defined(LBFT_HOST_SIG) && !defined(__HIPCC__)
+// (tests/tools/divergence_model.cpp: which of the LBFT_STAT points an event passed, one bit each, reported per step)
+extern unsigned long long lbft_host_sig;
+void lbft_host_step_done();
+#define LBFT_STAT(k) (lbft_host_sig |= 1ULL << (k))
+#define LBFT_STATN(k, n) do { } while (0)
+#define LBFT_STEP_DONE() lbft_host_step_done()
+#elif defined(LBFT_HOST_STATS) && !defined(__HIPCC__)
 extern unsigned long long lbft_host_stats[64];
 #define LBFT_STAT(k) (lbft_host_stats[k]++)
 #define LBFT_STATN(k, n) (lbft_host_stats[k] += (n))
 #else
 #define LBFT_STAT(k) do { } while (0)
 #define LBFT_STATN(k, n) do { } while (0)
+#endif
+#ifndef LBFT_STEP_DONE
+#define LBFT_STEP_DONE() do { } while (0)
 #endif
 
 // HBM layout: instances are grouped in tiles of `tw` (the instances one wavefront advances); a tile is contiguous and holds
@@ -2860,6 +2870,7 @@ struct SimT {
       // (a kernel class with cooperative bulk sends that is run lane-per-network -- the generic read-back class, the host
       // model's scalar mode -- never defers a list: coop() is false outside run_coop's classes)
       step_end(c);
+      LBFT_STEP_DONE();
     }
   }
   // The same loop for the kernels whose lanes cooperate (COOP): EVERY lane of the wavefront runs it; `leader` lanes carry a
