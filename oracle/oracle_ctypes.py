@@ -374,7 +374,8 @@ def hostmodel_lib():
     global _hm
     if _hm is None:
         build()
-        path = os.path.join(_HERE, "liblbft_hostmodel.so")
+        # LBFT_HOSTMODEL_LIB: an experimental build of the kernel logic (e.g. liblbft_hostmodel_coop0.so, `make -C oracle coop0`)
+        path = os.environ.get("LBFT_HOSTMODEL_LIB") or os.path.join(_HERE, "liblbft_hostmodel.so")
         if not os.path.exists(path):
             subprocess.check_call(["make", "-C", _HERE, "-s"])
         L = C.CDLL(path)
