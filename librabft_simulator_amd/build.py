@@ -9,7 +9,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "lbft_hip.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("lbft_core.h", "lbft_coop0.inc", "lbft_math.h", "lbft_tables.h", "lbft_save_node.h")] + [
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("lbft_core.h", "lbft_math.h", "lbft_tables.h", "lbft_save_node.h")] + [
     os.path.join(HERE, "..", "include", "lbft.h")]
 OUT = os.path.join(HERE, "liblbft_hip.so")
 

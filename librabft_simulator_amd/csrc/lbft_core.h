@@ -67,9 +67,6 @@ typedef int64_t i64;
 #define LBFT_LEAN_Q1 1   // large networks with the record exchange of quirks bit 0 run on a two-wavefronts-per-SIMD kernel too (SimT<7>): possible
                          // since a response's epochs are separate steps; 16 384 x 64 live: 3.46 s against 4.11 s on the full-register kernel
 #endif
-#ifndef LBFT_COOP0
-#define LBFT_COOP0 0   // EXPERIMENTAL (lbft_coop0.inc): kernel class 0 sends the messages of all networks of a wavefront lanes = messages
-#endif
 #ifndef LBFT_BLK_CACHE_LEAN2
 #define LBFT_BLK_CACHE_LEAN2 1
 #endif
@@ -519,10 +516,6 @@ LBFT_HD u32 pl_read(const PL<u32>& src, u32 k) { return (u32)__builtin_amdgcn_re
 LBFT_HD void pl_write(PL<u32>& d, u32 k, u32 val) { d.v = lbft_lane_id() == k ? val : d.v; }  // (compare + select: this compiler has no writelane builtin)
 #define LBFT_UNI(x, k) ((u32)__builtin_amdgcn_readlane((int)(x), (int)(k)))  // lane k's value of x, in every lane
 #define LBFT_IS_LANE(k) (lbft_lane_id() == (k))
-#define LBFT_ANY(x) (__ballot(x) != 0)
-#define LBFT_MINE(l) (true)
-// lanes of one wavefront exchanging data through LDS: LDS operations complete in order, so all it takes is lgkmcnt(0) and a compiler fence
-#define LBFT_WAVE_SYNC() do { __atomic_signal_fence(__ATOMIC_SEQ_CST); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); __atomic_signal_fence(__ATOMIC_SEQ_CST); } while (0)
 #else
 template <class T> struct PL {
   T v[64];
@@ -536,9 +529,6 @@ inline u32 pl_read(const PL<u32>& src, u32 k) { return src.v[k]; }
 inline void pl_write(PL<u32>& d, u32 k, u32 val) { d.v[k] = val; }
 #define LBFT_UNI(x, k) ((u32)(x))  // the host model runs one network per simulator object: it is its own lane k
 #define LBFT_IS_LANE(k) (true)
-#define LBFT_ANY(x) (x)
-#define LBFT_MINE(l) ((l) == 0)  // (LBFT_COOP0's host emulation: the simulator object is lane 0 of its wavefront)
-#define LBFT_WAVE_SYNC() do { } while (0)
 #endif
 
 struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at most one element
@@ -562,7 +552,6 @@ struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at
 //      plain large-network path fits 256 registers (21 spilled) and runs two wavefronts per SIMD with half the lanes each
 template <int CLS>
 struct SimT {
-  static constexpr int KCLS = CLS;
   static constexpr bool LEAN2 = CLS == 5 || CLS == 7;  // 7 = 5 plus the record exchange of quirks bit 0 (34 spilled registers; a kernel of its own: with
                                                        // that code compiled in, the runs without it lose 10 %)
   static constexpr bool BIG = CLS == 2 || LEAN2;       // multi-word node / author sets
@@ -625,9 +614,6 @@ struct SimT {
   LBFT_HD SimT(const Params& p, char* tile_base, u32 lane_byte_offset, int) : P(p), tile(tile_base), lane4(lane_byte_offset), qk(nullptr), qm(nullptr), qstr(0), qsh(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab),
         leader_lds(nullptr), dur_lds(nullptr), leader_lds_len(0), dur_lds_len(0), hc(nullptr), plist_lds(nullptr) {
     coop_on = false; cur_xk = 0; wtab = p.weights;
-#if LBFT_COOP0
-    c0 = nullptr; c0_qbase = nullptr; c0_seg = 4; c0_prepared = false;
-#endif
     if (RING) { rng.rtile = tile; rng.rrsh = rsh(); rng.rbase = boff(P.off_ring); rng.rmask = P.ring ? P.ring - 1u : 0xffffffffu; rng.rhead = 0; rng.rcnt = 0; }
   }
   LBFT_HD void attach_queue(u64* keys, u32* metas, u32 stride, u32 slots) {
@@ -2269,13 +2255,7 @@ struct SimT {
     u32 sync_epoch, sync_certs;
     u32 have_actions;  // update_node ran: act is valid
   };
-#if LBFT_COOP0
-  LBFT_HD void send_loop(u32 node, u32 sender, const SendPlan& sp, const Actions& act, u32 prepared = 0) {  // prepared: bit 0 / 1 = list A / B is shuffled already
-    if (CLS == 0) { c0_plan(node, sender, sp, act); return; }  // (lbft_coop0.inc: sent by the cooperative passes of run_coop0 -- class 0 has no other path in such a build)
-#else
   LBFT_HD void send_loop(u32 node, u32 sender, const SendPlan& sp, const Actions& act) {
-    const u32 prepared = 0;
-#endif
     u32 n_a = 0, n_b = 0;
     if (sp.have_actions) {
       if (act.broadcast) n_a = P.n - 1;
@@ -2302,7 +2282,7 @@ struct SimT {
       // receivers.shuffle(rng) (simulator.rs:343) / create_request + senders.shuffle(rng) (simulator.rs:365-370): each
       // drawn right before the delays of its list; one site for both lists (they never start at the same j)
       bool start_a = j == first_a && n_a != 0, start_b = j == first_b && n_b != 0;
-      if ((start_a && !(prepared & 1u)) || (start_b && !(prepared & 2u))) {
+      if (start_a || start_b) {
         if (start_b || act.broadcast) peers_all_but(node); else peers_one((u32)act.send_to);
         if (start_b) rs = q1() ? make_request_slot(nf(node, NF_EPOCH), nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16)) : 0;
         peers_shuffle(start_a ? n_a : n_b);
@@ -2937,9 +2917,6 @@ struct SimT {
     }
     return drained;
   }
-#if LBFT_COOP0
-#include "lbft_coop0.inc"
-#endif
 };
 
 typedef SimT<3> Sim;

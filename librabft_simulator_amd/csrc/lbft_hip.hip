@@ -68,11 +68,7 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restr
 static inline size_t run_lds_bytes(u32 ql, u32 lpw, u32 n, u32 slot_bytes) {
   return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * ql * lpw * slot_bytes + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8 + 8 +
          (n > 16 ? (size_t)LBFT_RUN_WAVES * lpw * LBFT_MAX_NODES : 0) +
-         (n <= 4 && slot_bytes == 8 ? (size_t)LBFT_RUN_WAVES * lpw * LBFT_LDS_HCBR_WORDS * 4 : 0)  // class 0, n <= 4: hcbr buffers
-#if LBFT_COOP0
-         + (slot_bytes == 8 ? (size_t)LBFT_RUN_WAVES * sizeof(SimT<0>::C0Stage) + 8 : 0)  // (experimental: staging area of the cooperative sends)
-#endif
-      ;
+         (n <= 4 && slot_bytes == 8 ? (size_t)LBFT_RUN_WAVES * lpw * LBFT_LDS_HCBR_WORDS * 4 : 0);  // class 0, n <= 4: hcbr buffers
 }
 
 __device__ __forceinline__ size_t run_lds_bytes_dev(u32 ql, u32 lpw, u32 slot_bytes) {  // = run_lds_bytes(ql, lpw, 0, ..): where the receiver lists start
@@ -81,9 +77,6 @@ __device__ __forceinline__ size_t run_lds_bytes_dev(u32 ql, u32 lpw, u32 slot_by
 #ifndef LBFT_RUN_WAVES_PER_SIMD
 #define LBFT_RUN_WAVES_PER_SIMD 2  // register budget of the class-0 run kernel: 512 / 2 = 256 VGPRs + AGPRs per lane (the
                                    // large-network classes run one 8- or 16-lane wavefront per SIMD and may use all 512)
-#endif
-#if LBFT_COOP0 && defined(LBFT_PHASE_TIMERS)
-#error "LBFT_COOP0 is not instrumented for LBFT_PHASE_TIMERS"
 #endif
 template <int CLS>
 __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ state, u32* __restrict__ unfinished) {
@@ -155,40 +148,6 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
     }
 #endif
   } else
-#if LBFT_COOP0
-  // EXPERIMENTAL (lbft_coop0.inc): every lane of the wavefront runs the event loop; the lanes that carry a network execute its events,
-  // all 64 send the wavefront's messages (lanes = messages).  Needs the owners in lanes 0..31 and an LDS queue front.
-  if constexpr (CLS == 0) {  // (such a build runs class 0 only this way: prepare_run keeps lpw <= 32 and ql >= 8)
-    SimT<CLS> s(p, tile, (i & (tw - 1u)) * 4u, 0);  // (a lane without a network never touches its column)
-    bool lead = false;
-    if (active) lead = s.ld(I_DONE) == 0;
-    s.attach_queue(keys, metas, p.lpw, p.ql);
-    s.attach_tables(t_zx, t_zf, t_et);
-    s.attach_round_tables(t_leader, n_leader, t_dur, n_dur);
-    s.attach_weights(t_weights);
-    {
-      u8* after = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 8u) + (p.n <= 4 ? (size_t)LBFT_RUN_WAVES * p.lpw * LBFT_LDS_HCBR_WORDS * 4 : 0);
-      after += (8 - (reinterpret_cast<size_t>(after) & 7)) & 7;
-      s.attach_coop0(reinterpret_cast<typename SimT<CLS>::C0Stage*>(after) + wave, lds + LBFT_TABLE_U64 + (size_t)wave * p.ql * p.lpw);
-    }
-    if (lead) {
-      if (p.n <= 4) {
-        u32* hcb = reinterpret_cast<u32*>(reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 8u));
-        s.attach_hcbr(hcb + (size_t)wave * LBFT_LDS_HCBR_WORDS * p.lpw + lane);
-      }
-      s.load_scalars();
-      s.queue_to_lds();
-      s.hcbr_to_lds();
-    }
-    bool drained = s.run_coop0(lead);
-    if (lead) {
-      done = drained;
-      s.queue_from_lds();
-      s.hcbr_from_lds();
-      s.store_scalars(done);
-    }
-  } else
-#endif
   if (active) {
     SimT<CLS> s(p, tile, (i & (tw - 1u)) * 4u, 0);
     if (s.ld(I_DONE) == 0) {
@@ -1025,9 +984,6 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   u32 ql = b->ql < 0 ? ql_auto : (u32)b->ql;
   if (ql > qcap) ql = qcap;
   if (p.qpack) ql &= ~7u;  // scanned in batches of 8
-#if LBFT_COOP0
-  if (p.qpack && ql < 8) ql = 8;  // (experimental cooperative sends: the messages are written into the LDS front)
-#endif
   if (p.qcal) ql = 0;  // the calendar lives in HBM rows
   if (run_lds_bytes(ql, lpw, n, slot_bytes) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
   p.ql = ql;

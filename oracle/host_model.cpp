@@ -121,13 +121,6 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
     s.queue_to_lds();
     s.hcbr_to_lds();
     bool done;
-#if LBFT_COOP0
-    typename std::remove_reference<decltype(s)>::type::C0Stage stage;  // (the wavefront's LDS staging area; this network is its lane 0)
-    memset(&stage, 0, sizeof(stage));
-    constexpr int kCls = std::remove_reference<decltype(s)>::type::KCLS;
-    if (kCls == 0) s.attach_coop0(&stage, keys.data());
-    if (kCls == 0) done = s.run_coop0(true); else
-#endif
     if constexpr (std::remove_reference<decltype(s)>::type::COOP) done = p.ring ? s.run_coop(true) : s.run();
     else done = s.run();
     s.queue_from_lds();
@@ -135,9 +128,6 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
     s.store_scalars(done);
   };
   int cls = caps->force_generic ? 3 : sim_class(p);
-#if LBFT_COOP0
-  if (cls == 0) { p.ql = p.ql < 8 ? 8 : (p.ql & ~7u); }  // (experimental build: class 0 sends through the LDS front only)
-#endif
   if (cls == 0 || cls == 1) { p.tw = 64; p.rsh = 8; }  // the small-network classes address 64-wide tiles at compile time
   if (cls == 2) { p.tw = 1; p.rsh = 2; }                 // ... and the large-network class instance-major rows
   auto worker = [&](u32 tid) {

@@ -18,8 +18,7 @@ static const char* kNames[64] = {
     /*36*/ "timeouts of the current round", "carries a vote", nullptr, nullptr,
     /*40*/ "timers folded into a pending one", "timers scheduled", "... beyond max_clock", nullptr,
     /*44*/ "block-record lookups", "... missing the register cache", "responses going on with a later epoch at the next step (quirks bit 0)", nullptr,
-    /*48*/ "pops at queue length 0-7", "8-15", "16-23", "24-31", "32-39", "40-47", "48-55", ">= 56",
-    /*56*/ "LBFT_COOP0: segments sent cooperatively", "... sent by send_loop after all (staged draws / queue room ran out)", "... extra draws of rejected first tries"};
+    /*48*/ "pops at queue length 0-7", "8-15", "16-23", "24-31", "32-39", "40-47", "48-55", ">= 56"};
 
 int main(int argc, char** argv) {
   lbft_oracle_config cfg;
