@@ -52,7 +52,7 @@ typedef int64_t i64;
 // ... and for the two-wavefronts-per-SIMD large-network kernels (SimT<5> / SimT<7>, 256 registers), where a staged word that does not fit
 // is a spilled register and costs more than the round trip it saves.  What pays is decided by what else is in the register file: with
 // the trace / free-slot-mask state out of it and ONE cached block record, the staged author sets and the calendar fetch-ahead fit
-// (4 / 12 spilled registers) -- 16 384 x 64: 386 -> 375 ms, 8 192 x 100: 2.23 -> 2.04 s, live: 3.46 -> 3.32 s, 5.80 -> 5.35 s; the
+// (4 / 24 spilled registers with the response bursts of DESIGN.md section 5) -- 16 384 x 64: 386 -> 375 ms, 8 192 x 100: 2.23 -> 2.04 s, live: 3.46 -> 3.32 s, 5.80 -> 5.35 s; the
 // blocks' staged node-set words (BX) stay out (+-0), 3 cached records spill 57 / 123 registers (420 ms).
 #ifndef LBFT_LEAN_AX
 #define LBFT_LEAN_AX 1
@@ -552,10 +552,10 @@ struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at
 //      plain large-network path fits 256 registers (21 spilled) and runs two wavefronts per SIMD with half the lanes each
 template <int CLS>
 struct SimT {
-  static constexpr bool LEAN2 = CLS == 5 || CLS == 7;  // 7 = 5 plus the record exchange of quirks bit 0 (34 spilled registers; a kernel of its own: with
+  static constexpr bool LEAN2 = CLS == 5 || CLS == 7;  // 7 = 5 plus the record exchange of quirks bit 0 (24 spilled registers; a kernel of its own: with
                                                        // that code compiled in, the runs without it lose 10 %)
   static constexpr bool BIG = CLS == 2 || LEAN2;       // multi-word node / author sets
-  static constexpr bool LEAN = LEAN2 || CLS == 6;      // 6 = class 1 without those three (13 spilled registers at 256)
+  static constexpr bool LEAN = LEAN2 || CLS == 6;      // 6 = class 1 without those three (22 spilled registers at 256)
   // Large networks: the lanes of a wavefront cooperate on one network's broadcasts (coop_bulk); every class that may meet such a
   // batch's state (the generic class 3 reads back / steps any batch) honours its ring of pre-generated draws.
   // 64-wide tiles addressed at compile time for the small-network classes (many lanes per wavefront); the large-network

@@ -201,13 +201,13 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
 // wavefront per SIMD and may use the whole register file (VGPRs + AGPRs).
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run0(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(0) run_body<0>(p, state, unfinished); }
-// Large networks without record exchange / trace / lossy network (sim_lean()): also two wavefronts per SIMD (21 spilled registers)
+// Large networks without record exchange / trace / lossy network (sim_lean()): also two wavefronts per SIMD (4 spilled registers)
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run2l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(5) run_body<5>(p, state, unfinished); }
-// ... and with the record exchange of quirks bit 0 (sim_lean_q1(): requests answered by the peer, responses inserted): 34 spilled registers
+// ... and with the record exchange of quirks bit 0 (sim_lean_q1(): requests answered by the peer, responses inserted): 24 spilled registers
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run2q(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(7) run_body<7>(p, state, unfinished); }
-// ... and class 1 without them (networks of <= 32 nodes with equivocators, a heap / calendar queue, ...): 13 spilled registers
+// ... and class 1 without them (networks of <= 32 nodes with equivocators, a heap / calendar queue, ...): 22 spilled registers
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run1l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(6) run_body<6>(p, state, unfinished); }
 #ifndef LBFT_BIG_WAVES_PER_SIMD
