@@ -140,3 +140,17 @@ def test_kernel_hash_reads_the_code_object(hiplib):
     assert re.fullmatch(r"[0-9a-f]{16}", h) and h == build.source_hash()
     stamp = json.load(open(os.path.join(ROOT, "profiles", "current", "pmc_traffic.json"))).get("source_hash")
     assert re.fullmatch(r"[0-9a-f]{16}", stamp)  # (equal to h while the committed profile belongs to the built kernels; bench.py reports null otherwise)
+
+
+def test_kernel_names_from_the_layout_flag_word():
+    """bench.py and tools/configs.py name the run kernel of a batch from lbft_batch_layout's flag word (include/lbft.h:
+    class | heap << 8 | calendar << 9 | two-wavefront kernel << 10 | cooperative sends << 11 | ... with record exchange << 12)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench
+    import configs
+    for kc, name in ((0, "lbft_k_run0"), (1 | 1024, "lbft_k_run1l"), (1, "lbft_k_run<1>"), (2 | 256 | 512 | 2048, "lbft_k_run<2>"),
+                     (2 | 256 | 512 | 1024 | 2048, "lbft_k_run2l"), (2 | 256 | 512 | 1024 | 2048 | 4096, "lbft_k_run2q")):
+        assert bench.run_kernel_name(kc) == name
+        assert configs.kernel_name({"kernel_class": kc}) == name
