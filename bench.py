@@ -25,7 +25,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--instances", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--instances", type=int, default=65536, help="instances per GPU (weak scaling: the default mode)")
+    ap.add_argument("--total-instances", type=int, default=0,
+                    help="strong scaling: this many instances in total, sharded over the ranks (BASELINE.json config 3 read as ONE 65 536-instance batch on 1..8 GPUs)")
+    ap.add_argument("--parity-instances", type=int, default=1024, help="instances of the timed batch (strided) re-run on the CPU oracle and compared (0 = no gate)")
     ap.add_argument("--nodes", type=int, default=4)
     ap.add_argument("--max-clock", type=int, default=1000)
     ap.add_argument("--base-seed", type=int, default=1)
@@ -113,15 +116,43 @@ def cpu_baseline(args, nodes, max_clock):
         r1 = oc.run_batch(c1cfg, np.array([args.base_seed + reps], dtype=np.uint64), 2800, threads=1)
         reps += 1
     c1 = r1["counters"]["rounds"] * reps / (time.perf_counter() - t1)
+    # `value` = the port's bare protocol logic (what the port measures reliably).  The figure with the reference's per-event
+    # save_node / clone costs emulated is an ESTIMATE of the Rust binary (the emulation sorts maps and appends bytewise, costlier than
+    # bincode: round-2 advisor) and is reported beside it, never as the baseline.
     return {
         "c1_single_thread_rounds_per_s": c1,
-        "value": c["rounds"] / dt, "unit": "rounds/s", "cores": cores, "kind": "port",
-        "sample": "%d instances x %d nodes, LogNormal(10,4), max_clock %d, %d host threads, %.1f s; C++ port of the reference incl. its per-event "
-                  "save_node serialisation (%.0f MB) and per-receiver notification clones" % (m, nodes, max_clock, cores, dt, c["saved_bytes"] / 1e6),
-        "events_per_s": sum(c["events"]) / dt, "commits_per_s": c["commits"] / dt,
-        "protocol_logic_only": {"value": cb["rounds"] / dtb, "events_per_s": sum(cb["events"]) / dtb,
-                                "sample": "%d instances, %.1f s, without save_node / clones" % (mb, dtb)},
+        "value": cb["rounds"] / dtb, "unit": "rounds/s", "cores": cores, "kind": "port",
+        "sample": "%d instances x %d nodes, LogNormal(10,4), max_clock %d, %d host threads, %.1f s; C++ port of the reference's protocol logic "
+                  "(hash maps keyed by BCS+SipHash record hashes, history clones, real payloads), without its per-event save_node" % (mb, nodes, max_clock, cores, dtb),
+        "events_per_s": sum(cb["events"]) / dtb, "commits_per_s": cb["commits"] / dtb,
+        "with_reference_overheads_estimate": {
+            "value": c["rounds"] / dt, "events_per_s": sum(c["events"]) / dt,
+            "sample": "%d instances, %.1f s, plus an emulation of bincode(NodeState) per event (%.0f MB) and a notification clone per receiver: an "
+                      "upper bound of what the Rust reference pays, not measured against it" % (m, dt, c["saved_bytes"] / 1e6)},
     }
+
+
+def parity_gate(args, sim, res, seeds, nodes, max_clock):
+    """every number is accompanied by a parity gate.  A strided sample of the TIMED batch's instances is re-run
+    on the CPU oracle (test infrastructure, allowed in this leg only) and compared with what the device produced in the timed
+    region: commit counts, active rounds and last_committed_state (SipHash of the whole committed history) of every node."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle_ctypes as oc
+    n = len(seeds)
+    k = min(args.parity_instances, n)
+    idx = np.unique(np.linspace(0, n - 1, k).astype(np.int64))
+    cfg = oc.make_config(num_nodes=nodes, math_mode=1)
+    t0 = time.perf_counter()
+    ref = oc.run_batch(cfg, np.ascontiguousarray(seeds[idx]), max_clock, threads=os.cpu_count() or 1)
+    dt = time.perf_counter() - t0
+    cc, ar, st = res.commit_counts[idx], res.active_rounds[idx], res.last_committed_states[idx]
+    bad = (cc != ref["commit_counts"]).any(axis=1) | (ar != ref["active_rounds"]).any(axis=1) | (st != ref["last_states"]).any(axis=1)
+    return {"checked_instances": int(len(idx)), "checked_nodes": int(len(idx) * nodes), "mismatches": int(bad.sum()),
+            "compared": "commit counts, active rounds, State hash of the committed history, every node",
+            "states_xor": "%016x" % int(np.bitwise_xor.reduce(st.astype(np.uint64).ravel())),
+            "oracle_states_xor": "%016x" % int(np.bitwise_xor.reduce(ref["last_states"].astype(np.uint64).ravel())),
+            "oracle_seconds": dt, "oracle": "oracle/lbft_oracle.cpp, math_mode 1"}
 
 
 def run_kernel_name(kc):
@@ -157,8 +188,12 @@ def main():
 
     from librabft_simulator_amd import BatchSimulator, NodeConfig, RandomDelay
     from librabft_simulator_amd.distributed import shard_seeds
-    m = args.instances  # per GPU (weak scaling); seed_i = base_seed + global instance index
-    seeds = shard_seeds(args.base_seed, m * world, rank, world)
+    # weak scaling (default): `--instances` per GPU; strong scaling: `--total-instances` sharded over the ranks.
+    # seed_i = base_seed + global instance index in both modes
+    strong = args.total_instances > 0
+    total = args.total_instances if strong else args.instances * world
+    seeds = shard_seeds(args.base_seed, total, rank, world)
+    m = len(seeds)
     sim = BatchSimulator.new(seeds, args.nodes, RandomDelay.new(10.0, 4.0), NodeConfig(), device=local_rank, lanes_per_wavefront=args.lpw)
 
     def barrier():
@@ -191,21 +226,29 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         layout = sim.layout()
         bpe = algorithmic_bytes_per_event(layout, c)
-        traffic = measured_traffic_gb() if (args.instances, args.nodes, args.max_clock) == (65536, 4, 1000) else None
+        traffic = measured_traffic_gb() if (m, args.nodes, args.max_clock) == (65536, 4, 1000) else None
         local_events = sum(c["events"])
         achieved = local_events * bpe / (k_ms * 1e-3) / 1e9
         ex_bytes, pops = executed_bytes(layout, c)
         achieved_ex = ex_bytes / (k_ms * 1e-3) / 1e9
         out = {
-            "metric": "simulated consensus rounds/sec (whole node), 65 536 x 4-node instances per GPU",
+            "metric": "simulated consensus rounds/sec (whole node), 65 536 x 4-node instances per GPU" if not strong else
+                      "simulated consensus rounds/sec (whole node), %d x %d-node instances in total" % (total, args.nodes),
             "value": rounds / per_step, "unit": "rounds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": per_step * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "int32/u64 + f64 delay sampling", "data": "synthetic",
-            "config": {"workload": "%d instances x %d nodes (f=1) per GPU, LogNormal(mean 10, variance 4) delays, max_clock %d, "
-                                   "delta 20 gamma 2 lambda 0.5, seeds base+i; reference quirks Q1-Q6" % (m, args.nodes, args.max_clock),
-                       "instances_per_gpu": m, "nodes": args.nodes, "max_clock": args.max_clock, "parallelism": "instances sharded, %d ranks" % world},
-            "committed_blocks_per_s": commits / per_step, "events_per_s": events / per_step,
-            "events_note": "reference-equivalent events (incl. duplicate timers the device folds); device queue pops: roofline.executed",
+            "config": {"workload": "%d instances x %d nodes (f=1) %s, LogNormal(mean 10, variance 4) delays, max_clock %d, "
+                                   "delta 20 gamma 2 lambda 0.5, seeds base+i; reference quirks Q1-Q6" % (
+                                       total if strong else m, args.nodes, "in total" if strong else "per GPU", args.max_clock),
+                       "instances_per_gpu": m, "total_instances": total, "nodes": args.nodes, "max_clock": args.max_clock,
+                       "parallelism": "%s scaling: %s, %d ranks, contiguous instance shards, one counter all-gather" % (
+                           "strong" if strong else "weak", "%d instances in total" % total if strong else "%d instances per GPU" % m, world)},
+            "committed_blocks_per_s": commits / per_step,
+            # what the device executes (queue pops) leads; the reference-equivalent total also counts the duplicate timers the device
+            # folds at scheduling time (they never reach the queue)
+            "queue_pops_per_s": (events - float(agg.get("timers_folded", 0))) / per_step,
+            "events_per_s": events / per_step,
+            "events_note": "queue_pops_per_s = events the device executes; events_per_s = reference-equivalent events (adds the duplicate timers folded at scheduling time)",
             "faulted_instances": faulted,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["gb_corrected"] if traffic else None, "traffic_unit": "GB per launch",
@@ -220,9 +263,16 @@ def main():
                                       "queue_pops_per_s": pops / (k_ms * 1e-3)},
                          "layout": layout},
         }
+        if args.parity_instances > 0:  # (rank 0's shard of the timed batch; oracle = test infrastructure, used only as the checker)
+            out["parity"] = parity_gate(args, sim, res, seeds, args.nodes, args.max_clock)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.nodes, args.max_clock)
         print(json.dumps(out))
+        if out.get("parity", {}).get("mismatches", 0) != 0:
+            sys.stderr.write("bench.py: PARITY GATE FAILED: %s\n" % json.dumps(out["parity"]))
+            if dist is not None:
+                dist.destroy_process_group()
+            sys.exit(3)
     if dist is not None:
         dist.destroy_process_group()
 

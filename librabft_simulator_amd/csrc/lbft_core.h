@@ -28,6 +28,7 @@
 #define LBFT_CORE_H
 
 #include <stdint.h>
+#include <math.h>
 
 #include "lbft_math.h"
 
@@ -69,6 +70,30 @@ typedef int64_t i64;
 #endif
 #ifndef LBFT_BLK_CACHE_LEAN2
 #define LBFT_BLK_CACHE_LEAN2 1
+#endif
+// Kernel class 0 (the headline small-network path): instance-major rows (tile width 1) instead of 64-instance word-interleaved tiles.
+// The lanes of a class-0 wavefront work on different nodes, snapshot slots and blocks of their instances, i.e. on different ROWS: in a
+// word-interleaved tile every such word access touches one 128-byte line per distinct row (a 41-word node burst: 4 lines per word, a
+// snapshot or block record: up to one line per lane and word).  Instance-major, a lane's node / snapshot / block record is one
+// contiguous run of words: wide loads, one or two lines per record.
+#ifndef LBFT_C0_IMAJOR
+#define LBFT_C0_IMAJOR 1
+#endif
+#ifndef LBFT_C0_ALIGN
+#define LBFT_C0_ALIGN 0   // (with LBFT_C0_IMAJOR) records padded and aligned so that none straddles a 128-byte line needlessly
+#endif
+#ifndef LBFT_C0_HCREG
+#define LBFT_C0_HCREG 0   // (with LBFT_C0_IMAJOR, networks of <= 4 nodes) the node's hcbr buffers ride in the node burst and live in registers
+#endif
+#ifndef LBFT_FAST_TRUNC_EXP
+#define LBFT_FAST_TRUNC_EXP 1  // the delay sampler decides trunc(exp(y)) from a single-precision estimate when that is safe (SimT::trunc_exp)
+#endif
+#ifndef LBFT_C0_QLANE
+#define LBFT_C0_QLANE 0
+#endif
+#define LBFT_QLANE_PAD 2u  // (u64 words)
+#ifndef LBFT_POP_BATCH
+#define LBFT_POP_BATCH 16u // packed LDS queue front (class 0): independent loads in flight per batch of the pop's scan (a power of two)
 #endif
 #define LBFT_MAX_NODES 128  // node / author sets are 1..4 32-bit words (word 0 in the hot rows, the rest in extension rows)
 
@@ -221,21 +246,49 @@ enum InstField : u32 {
 // Node-level rows (RecordStoreState record_store.rs:93-119, PacemakerState pacemaker.rs:60-77,
 // NodeState node.rs:28-45, CommitTracker node.rs:50-59, SimulatedNode simulator.rs:53-59,
 // SimulatedContext simulated_context.rs:75-83).
+// Memory order = the groups of fields end_node writes back together (each group one contiguous run of words: with instance-major
+// rows a group is a few wide stores).
+#if defined(LBFT_NF_ORDER_OLD)
 enum NodeField : u32 {
   NF_STARTUP = 0, NF_IGNORE_UNTIL, NF_EPOCH, NF_INIT_STATE_BLK, NF_PROPOSED_BLK, NF_HQC_ROUND, NF_HQC_BLK,
   NF_HTC_ROUND, NF_CUR_ROUND, NF_HC_ROUND, NF_HCC_BLK, NF_TC_MASK, NF_TO_MASK, NF_TO_WEIGHT,
-  NF_ELECTION,  // 0 ongoing, 1 won, 2 closed; won block in bits 8..31
+  NF_ELECTION,
   NF_BAL0_BLK, NF_BAL0_WEIGHT, NF_BAL0_AUTHORS, NF_BAL1_BLK, NF_BAL1_WEIGHT, NF_BAL1_AUTHORS,
   NF_PM_EPOCH, NF_PM_ROUND, NF_PM_LEADER, NF_PM_START, NF_PM_DUR_LO, NF_PM_DUR_HI,
   NF_LVR, NF_LOCKED, NF_LQAT, NF_TR_EPOCH, NF_TR_HCR, NF_TR_LCT,
   NF_NEXT_CMD, NF_LAST_COMMITTED_BLK, NF_NCOMMITS,
+  NF_LAST_TIMER_T, NF_TIMER_DUPS,
+  NF_DUP_STAMP,
+  NF_PREV_EPOCH_HCC,
+  NF_TC_SEL,
+  NF_FIXED_WORDS
+};
+
+#else
+enum NodeField : u32 {
+  // (set once per epoch)
+  NF_STARTUP = 0, NF_EPOCH, NF_INIT_STATE_BLK,
+  NF_PREV_EPOCH_HCC,  // commit-certificate block of the previous epoch's record store (quirks bit 1: Q2 fixed)
+  // (timer bookkeeping: nearly every event)
+  NF_IGNORE_UNTIL,
   NF_LAST_TIMER_T, NF_TIMER_DUPS,  // duplicate-timer folding (see process_node_actions)
   NF_DUP_STAMP,  // creation stamp of the most recently folded duplicate timer (round-switch trace)
-  NF_PREV_EPOCH_HCC,  // commit-certificate block of the previous epoch's record store (quirks bit 1: Q2 fixed)
+  // (the current round of the record store)
+  NF_PROPOSED_BLK, NF_CUR_ROUND, NF_TO_MASK, NF_TO_WEIGHT,
+  NF_ELECTION,  // 0 ongoing, 1 won, 2 closed; won block in bits 8..31
+  NF_BAL0_BLK, NF_BAL0_WEIGHT, NF_BAL0_AUTHORS, NF_BAL1_BLK, NF_BAL1_WEIGHT, NF_BAL1_AUTHORS,
+  // (certificates)
+  NF_HQC_ROUND, NF_HQC_BLK, NF_HTC_ROUND, NF_HC_ROUND, NF_HCC_BLK, NF_TC_MASK,
   NF_TC_SEL,  // which of the two hcbr[n] buffers holds the timeout certificate (the other: current timeouts)
+  // (pacemaker)
+  NF_PM_EPOCH, NF_PM_ROUND, NF_PM_LEADER, NF_PM_START, NF_PM_DUR_LO, NF_PM_DUR_HI,
+  // (voting constraints, tracker, ledger)
+  NF_LVR, NF_LOCKED, NF_LQAT, NF_TR_EPOCH, NF_TR_HCR, NF_TR_LCT,
+  NF_NEXT_CMD, NF_LAST_COMMITTED_BLK, NF_NCOMMITS,
   NF_FIXED_WORDS  // followed by hcbr[2][n]: highest_certified_block_round per timeout author
 };
 
+#endif
 // Block rows.  The first BC_WORDS rows are the "hot record" that the event loop works on (held in a small
 // register-resident cache, see Sim::blk_get): the block's round and links, the rounds of its parent and
 // grandparent (denormalised at proposal time, so the 3-chain commit rule record_store.rs:221-235 and the
@@ -560,8 +613,10 @@ struct SimT {
   // batch's state (the generic class 3 reads back / steps any batch) honours its ring of pre-generated draws.
   // 64-wide tiles addressed at compile time for the small-network classes (many lanes per wavefront); the large-network
   // classes address tiles of P.tw = lanes per wavefront (lbft_core.h "HBM layout")
-  static constexpr bool TILE64 = CLS == 0 || CLS == 1 || CLS == 6;
-  static constexpr bool IMAJOR = BIG;  // large networks: tile width 1 = every instance's words contiguous (P.tw == 1), addressed at compile time
+  static constexpr bool C0I = CLS == 0 && LBFT_C0_IMAJOR != 0;
+  static constexpr bool TILE64 = (CLS == 0 && !C0I) || CLS == 1 || CLS == 6;
+  static constexpr bool HCREG = C0I && LBFT_C0_HCREG != 0;
+  static constexpr bool IMAJOR = BIG || C0I;  // tile width 1 = every instance's words contiguous (P.tw == 1), addressed at compile time
   static constexpr bool F_AX = LEAN2 ? (LBFT_LEAN_AX != 0) : (LBFT_AX != 0);      // (tuning switches above)
   static constexpr bool F_BX = LEAN2 ? (LBFT_LEAN_BX != 0) : (LBFT_BX != 0);
   static constexpr bool F_SPEC = LEAN2 ? (LBFT_LEAN_SPEC != 0) : (LBFT_SPEC != 0);
@@ -596,11 +651,17 @@ struct SimT {
   RngT<RING> rng;
 
   // Front of the event queue: slots [0, ql) live in LDS on the device (lane-private column: element k of
-  // this instance is qk[k << qsh], so any per-lane slot index is bank-conflict free); slots >= ql spill to
+  // this instance is qk[qx(k)], so any per-lane slot index is bank-conflict free); slots >= ql spill to
   // the HBM rows.  The host build (oracle/host_model.cpp) passes plain arrays.  ql == 0: HBM rows only.
   u64* qk;
   u32* qm;
   u32 qstr, qsh, ql;  // column stride (lanes per wavefront, a power of two) and its log2: element k of a column is [k << qsh]
+  u32 hsh;            // the same for the hcbr column (attach_hcbr)
+  // LBFT_C0_QLANE (kernel class 0): the LDS queue front is lane-major instead -- a lane's slots are consecutive words (slot offsets are
+  // instruction immediates, two keys per ds_read_b128), lanes LBFT_QLANE_PAD words apart beyond the slots so that the lanes of a
+  // wavefront reading the same slot fall into different banks
+  static constexpr bool QLANE = CLS == 0 && LBFT_C0_QLANE != 0;
+  LBFT_HD u32 qx(u32 k) const { return QLANE ? k : k << qsh; }
   // read-only tables (LDS copies on the device)
   const u64 *zig_x, *zig_f, *exp_tab;
   const u8* leader_lds;   // first leader_lds_len rounds of the leader table
@@ -617,10 +678,11 @@ struct SimT {
     if (RING) { rng.rtile = tile; rng.rrsh = rsh(); rng.rbase = boff(P.off_ring); rng.rmask = P.ring ? P.ring - 1u : 0xffffffffu; rng.rhead = 0; rng.rcnt = 0; }
   }
   LBFT_HD void attach_queue(u64* keys, u32* metas, u32 stride, u32 slots) {
-    qk = keys; qm = metas; qstr = stride; ql = qpacked() ? (slots & ~7u) : slots;  // packed entries are scanned in batches of 8
+    qk = keys; qm = metas; qstr = stride; ql = qpacked() ? (slots & ~(LBFT_POP_BATCH - 1u)) : slots;  // packed entries are scanned in batches of LBFT_POP_BATCH
     qsh = 0;
     while ((1u << qsh) < stride) qsh++;  // (a shift instead of a quarter-rate 32-bit multiply per slot access)
-    LBFT_PIN_VGPR(qsh);
+    hsh = qsh;
+    if (!QLANE) LBFT_PIN_VGPR(qsh);
     LBFT_PIN_VGPR(ql);
   }
   // highest_certified_block_round buffers of the nodes' timeouts (hcbr[node][2][n], behind the fixed node rows): for
@@ -629,24 +691,73 @@ struct SimT {
   // event and a row fetch there is a full memory round trip in the middle of the send loop.
   u32* hc;  // nullptr = the HBM rows
   LBFT_HD void attach_hcbr(u32* column) { hc = column; }
-  LBFT_HD bool hc_lds() const { return small_sets() && hc != nullptr; }
+  LBFT_HD bool hc_lds() const { return small_sets() && hc != nullptr && !hc_reg(); }
+  // ... or, with instance-major rows, in registers: the 2n words of the event's node lie right behind its fixed words and come with the
+  // node burst (every hcbr access is for the node of the current event); indices stay compile-time (value selects).
+  mutable u32 hcw[8];
+  mutable u32 hcdirty;
+  LBFT_HD bool hc_reg() const { return HCREG && P.n <= 4; }
+  LBFT_HD void hc_load(u32 nb) const {
+    if (!hc_reg()) return;
+    hcdirty = 0;
+    if (P.n == 4) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 k = 0; k < 8; k++) hcw[k] = ldf(nb, NF_FIXED_WORDS + k);
+    } else {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 k = 0; k < 8; k++) hcw[k] = (k & 3u) < P.n ? ldf(nb, NF_FIXED_WORDS + (k >> 2) * P.n + (k & 3u)) : 0u;
+    }
+  }
+  LBFT_HD void hc_store(u32 nb) const {
+    if (!hc_reg() || !hcdirty) return;
+    if (P.n == 4) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 k = 0; k < 8; k++) stf(nb, NF_FIXED_WORDS + k, hcw[k]);
+    } else {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 k = 0; k < 8; k++) if ((k & 3u) < P.n) stf(nb, NF_FIXED_WORDS + (k >> 2) * P.n + (k & 3u), hcw[k]);
+    }
+  }
   LBFT_HD u32 hc_get(u32 node, u32 buf, u32 a) const {
-    if (hc_lds()) return hc[(node * 8u + buf * 4u + a) << qsh];
+    if (hc_reg()) {
+      u32 idx = buf * 4u + a;
+      u32 v01 = (idx & 1u) ? hcw[1] : hcw[0], v23 = (idx & 1u) ? hcw[3] : hcw[2], v45 = (idx & 1u) ? hcw[5] : hcw[4], v67 = (idx & 1u) ? hcw[7] : hcw[6];
+      u32 v03 = (idx & 2u) ? v23 : v01, v47 = (idx & 2u) ? v67 : v45;
+      return (idx & 4u) ? v47 : v03;
+    }
+    if (hc_lds()) return hc[(node * 8u + buf * 4u + a) << hsh];
     return nfm(node, NF_FIXED_WORDS + buf * P.n + a);
   }
   LBFT_HD void hc_set(u32 node, u32 buf, u32 a, u32 v) const {
-    if (hc_lds()) hc[(node * 8u + buf * 4u + a) << qsh] = v;
+    if (hc_reg()) {
+      u32 idx = buf * 4u + a;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 k = 0; k < 8; k++) hcw[k] = idx == k ? v : hcw[k];
+      hcdirty = 1;
+      return;
+    }
+    if (hc_lds()) hc[(node * 8u + buf * 4u + a) << hsh] = v;
     else nfms(node, NF_FIXED_WORDS + buf * P.n + a, v);
   }
   LBFT_HD void hcbr_to_lds() const {
     if (!hc_lds()) return;
     for (u32 node = 0; node < P.n; node++)
-      for (u32 k = 0; k < 2 * P.n; k++) hc[(node * 8u + (k / P.n) * 4u + k % P.n) << qsh] = nfm(node, NF_FIXED_WORDS + k);
+      for (u32 k = 0; k < 2 * P.n; k++) hc[(node * 8u + (k / P.n) * 4u + k % P.n) << hsh] = nfm(node, NF_FIXED_WORDS + k);
   }
   LBFT_HD void hcbr_from_lds() const {
     if (!hc_lds()) return;
     for (u32 node = 0; node < P.n; node++)
-      for (u32 k = 0; k < 2 * P.n; k++) nfms(node, NF_FIXED_WORDS + k, hc[(node * 8u + (k / P.n) * 4u + k % P.n) << qsh]);
+      for (u32 k = 0; k < 2 * P.n; k++) nfms(node, NF_FIXED_WORDS + k, hc[(node * 8u + (k / P.n) * 4u + k % P.n) << hsh]);
   }
   LBFT_HD void attach_tables(const u64* zx, const u64* zf, const u64* et) { zig_x = zx; zig_f = zf; exp_tab = et; }
   LBFT_HD void attach_peer_list(u8* list) { plist_lds = list; }
@@ -698,11 +809,13 @@ struct SimT {
 #endif
     for (u32 f = 0; f < NF_FIXED_WORDS; f++) cw[f] = ldf(nb, f);
     cdirty = 0;
+    hc_load(nb);
     ax_load(node);
   }
   LBFT_HD void end_node(u32 node) const {
     ax_store(node);
     u32 nb = boff(P.off_node + node * P.node_words);
+    hc_store(nb);
 #if !defined(LBFT_END_NODE_PER_ROW)
     // rows are written back by groups of fields that change together: 6 tests instead of 41 (A/B on the 65536 x 4 batch in
     // one GPU call: 24.6 ms vs 25.1 ms per-row; writing all rows unconditionally had measured 9 % slower)
@@ -948,10 +1061,31 @@ struct SimT {
       if (f1 + (f0 - f1) * f01 < lbft_exp(-x * x / 2.0, exp_tab)) return x;
     }
   }
+  // (i64) exp(y) as the reference truncates it (simulator.rs:115-117), without evaluating the exact exp when a cheap estimate
+  // already decides the integer: a = 2^(float)(y log2 e) from the hardware's single-precision exp2 is within 8e-7 (relative) of
+  // exp(y) for |y log2 e| < 20 -- 6.6e-7 from rounding the argument to single precision (half an ulp of 2^-19, times ln 2),
+  // 1.2e-7 from the instruction (1 ulp), the double-precision product is exact to 1e-15 -- and lbft_exp (= glibc's exp) is within
+  // 1e-16 of it.  So whenever a lies further than 2e-6 a from both neighbouring integers, trunc(exp(y)) = floor(a); otherwise
+  // (one sample in ~10^4) the exact routine decides.  The result is the reference's in every case; only the work differs.
+  LBFT_HD i64 trunc_exp(double y) const {
+#if LBFT_FAST_TRUNC_EXP
+    float t = (float)(y * 1.4426950408889634);
+    if (t > -20.0f && t < 20.0f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      float a = __builtin_amdgcn_exp2f(t);
+#else
+      float a = exp2f(t);
+#endif
+      float fl = __builtin_floorf(a), fr = a - fl, m = a * 2e-6f;
+      if (fr > m && fr < 1.0f - m) return (i64)(i32)fl;
+    }
+#endif
+    return f64_to_i64_sat(lbft_exp(y, exp_tab));
+  }
   LBFT_HD i64 sample_delay() {
     if (P.delay_model == 1) return P.uni_lo + (i64)rng.gen_range_u64(P.uni_span);
     double nrm = standard_normal();
-    return f64_to_i64_sat(lbft_exp(P.mu + P.sigma * nrm, exp_tab));
+    return trunc_exp(P.mu + P.sigma * nrm);
   }
 
   // ---- event queue: unsorted compact array, ordered by (time asc, kind desc, stamp asc)
@@ -967,38 +1101,38 @@ struct SimT {
 #define LBFT_QP_STAMP_BITS 25
   LBFT_HD void q_set(u32 k, u64 key, u32 meta) const {
     if (qpacked()) {
-      if (k < ql) qk[k << qsh] = key;
+      if (k < ql) qk[qx(k)] = key;
       else { st(P.off_qhi + k, (u32)(key >> 32)); st(P.off_qlo + k, (u32)key); }
       return;
     }
-    if (k < ql) { qk[k << qsh] = key; qm[k << qsh] = meta; }
+    if (k < ql) { qk[qx(k)] = key; qm[qx(k)] = meta; }
     else { st(P.off_qhi + k, (u32)(key >> 32)); st(P.off_qlo + k, (u32)key); st(P.off_qmeta + k, meta); }
   }
   LBFT_HD void q_get(u32 k, u64& key, u32& meta) const {
     if (qpacked()) {
       meta = 0;
-      if (k < ql) key = qk[k << qsh];
+      if (k < ql) key = qk[qx(k)];
       else key = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k);
       return;
     }
-    if (k < ql) { key = qk[k << qsh]; meta = qm[k << qsh]; }
+    if (k < ql) { key = qk[qx(k)]; meta = qm[qx(k)]; }
     else { key = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k); meta = ld(P.off_qmeta + k); }
   }
   // The LDS front is a cache of the HBM rows between launches.
   LBFT_HD void queue_to_lds() const {
     u32 nl = qlen < ql ? qlen : ql;
     for (u32 k = 0; k < nl; k++) {
-      qk[k << qsh] = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k);
-      if (!qpacked()) qm[k << qsh] = ld(P.off_qmeta + k);
+      qk[qx(k)] = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k);
+      if (!qpacked()) qm[qx(k)] = ld(P.off_qmeta + k);
     }
-    if (qpacked()) for (u32 k = nl; k < ql; k++) qk[k << qsh] = ~0ULL;
+    if (qpacked()) for (u32 k = nl; k < ql; k++) qk[qx(k)] = ~0ULL;
   }
   LBFT_HD void queue_from_lds() const {
     u32 nl = qlen < ql ? qlen : ql;
     for (u32 k = 0; k < nl; k++) {
-      u64 key = qk[k << qsh];
+      u64 key = qk[qx(k)];
       st(P.off_qhi + k, (u32)(key >> 32)); st(P.off_qlo + k, (u32)key);
-      if (!qpacked()) st(P.off_qmeta + k, qm[k << qsh]);
+      if (!qpacked()) st(P.off_qmeta + k, qm[qx(k)]);
     }
   }
   // `reuse_stamp` != ~0u: the event takes that (already handed out, otherwise unused) creation stamp.
@@ -1049,6 +1183,17 @@ struct SimT {
     qlen++;
     if (qlen > maxq) maxq = qlen;
     return true;
+  }
+  // smallest of kk[LO .. LO + N) and its index: a tree of compare-selects over values (constant indices at the leaves)
+  template <u32 LO, u32 N> LBFT_HD static void qmin(const u64* kk, u64& m, u32& i) {
+    if constexpr (N == 1) { m = kk[LO]; i = LO; }
+    else {
+      u64 ma, mb; u32 ia, ib;
+      qmin<LO, N / 2>(kk, ma, ia);
+      qmin<LO + N / 2, N / 2>(kk, mb, ib);
+      bool lt = mb < ma;
+      m = lt ? mb : ma; i = lt ? ib : ia;
+    }
   }
   // Removes the minimum; returns false when the queue is empty.
   LBFT_HD bool pop_event(i32& time, u32& kind, u32& meta) {
@@ -1127,20 +1272,15 @@ struct SimT {
     if (qpacked()) {
       // ql is a multiple of 8 and slots >= qlen hold the sentinel: eight independent loads in flight per batch, then a
       // tree of compare-selects (a sequential min pays one LDS round trip per slot)
-      for (u32 k0 = 0; k0 < nl; k0 += 8) {
-        u64 kk[8];
+      for (u32 k0 = 0; k0 < nl; k0 += LBFT_POP_BATCH) {
+        u64 kk[LBFT_POP_BATCH];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-        for (u32 j = 0; j < 8; j++) kk[j] = qk[(k0 + j) << qsh];
-        u64 m01 = kk[0] < kk[1] ? kk[0] : kk[1]; u32 i01 = kk[0] < kk[1] ? 0u : 1u;
-        u64 m23 = kk[2] < kk[3] ? kk[2] : kk[3]; u32 i23 = kk[2] < kk[3] ? 2u : 3u;
-        u64 m45 = kk[4] < kk[5] ? kk[4] : kk[5]; u32 i45 = kk[4] < kk[5] ? 4u : 5u;
-        u64 m67 = kk[6] < kk[7] ? kk[6] : kk[7]; u32 i67 = kk[6] < kk[7] ? 6u : 7u;
-        u64 m03 = m01 < m23 ? m01 : m23; u32 i03 = m01 < m23 ? i01 : i23;
-        u64 m47 = m45 < m67 ? m45 : m67; u32 i47 = m45 < m67 ? i45 : i67;
-        u64 m07 = m03 < m47 ? m03 : m47; u32 i07 = m03 < m47 ? i03 : i47;
-        if (m07 < bkey) { bkey = m07; best = k0 + i07; }
+        for (u32 j = 0; j < LBFT_POP_BATCH; j++) kk[j] = qk[qx(k0 + j)];
+        u64 bm; u32 bi;
+        qmin<0, LBFT_POP_BATCH>(kk, bm, bi);
+        if (bm < bkey) { bkey = bm; best = k0 + bi; }
       }
       for (u32 k = ql; k < qlen; k++) {  // spilled tail (rare when ql covers the high-water mark)
         u64 key = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k);
@@ -1154,14 +1294,14 @@ struct SimT {
       qlen--;
       u64 lk = ~0ULL; u32 lm = 0;
       if (best != qlen) { q_get(qlen, lk, lm); q_set(best, lk, 0); }
-      if (qlen < ql) qk[qlen << qsh] = ~0ULL;  // the vacated last slot becomes a sentinel again
+      if (qlen < ql) qk[qx(qlen)] = ~0ULL;  // the vacated last slot becomes a sentinel again
       return true;
     }
 #if defined(__HIPCC__)
 #pragma unroll 4
 #endif
     for (u32 k = 0; k < nl; k++) {
-      u64 key = qk[k << qsh];
+      u64 key = qk[qx(k)];
       if (key < bkey) { bkey = key; best = k; }
     }
     for (u32 k = ql; k < qlen; k++) {  // spilled tail (rare when ql covers the high-water mark)
@@ -1171,7 +1311,7 @@ struct SimT {
     time = (i32)(u32)(bkey >> 32);
     kind = 3u - ((u32)bkey >> 30);
     ev_stamp = (u32)bkey & 0x3fffffffu;
-    meta = best < ql ? qm[best << qsh] : ld(P.off_qmeta + best);
+    meta = best < ql ? qm[qx(best)] : ld(P.off_qmeta + best);
     qlen--;
     if (best != qlen) {
       u64 lk; u32 lm;
@@ -1985,6 +2125,18 @@ struct SimT {
     st(sfw(slot, S_TC_MASK), tcm);
     st(sfw(slot, S_TO_MASK), tom);
     u32 tc_sel = nf(node, NF_TC_SEL);
+    if (hc_reg()) {
+      // both buffers whole, no loop over the sets: a receiver only reads the words of authors in the sets
+      u32 sb = sfw(slot, S_FIXED_WORDS);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 a = 0; a < 4; a++) if (a < P.n) st(sb + a, tc_sel ? hcw[4 + a] : hcw[a]);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 a = 0; a < 4; a++) if (a < P.n) st(sb + P.n + a, tc_sel ? hcw[a] : hcw[4 + a]);
+    } else
     if (!skip_hcbr) {
       copy_hcbr(node, slot, tcm, 0, tc_sel, S_FIXED_WORDS);
       copy_hcbr(node, slot, tom, 0, 1u - tc_sel, S_FIXED_WORDS + P.n);
@@ -2937,10 +3089,20 @@ inline bool sim_lean1(const Params& p) { return sim_class(p) == 1 && sim_lean_fe
 // Row layout for a batch; fills the offset fields of `p` and returns words per instance.  Accumulated in 64 bits: a tile is
 // addressed with 32-bit byte offsets (boff(): row << rsh, at most 8), so a layout is only usable while it stays below 2^24 rows; the
 // caller rejects larger ones (layout_fits) instead of letting row offsets wrap.
+inline u32 node_words_used(const Params& p) { return NF_FIXED_WORDS + 2 * p.n + 4 * ((p.n + 31) / 32 - 1); }
+inline u32 snap_words_used(const Params& p) { return S_FIXED_WORDS + 2 * p.n + 2 * ((p.n + 31) / 32 - 1) + ((p.quirks & 1u) ? 2 : 0); }
+inline u32 layout_tile_width(const Params& p) { return sim_class(p) == 0 ? (LBFT_C0_IMAJOR ? 1u : 64u) : sim_class(p) == 1 ? 64u : 1u; }
 inline u64 compute_layout(Params& p) {
   u64 w = I_WORDS;
   p.mw = (p.n + 31) / 32;
-  p.off_node = (u32)w; p.node_words = NF_FIXED_WORDS + 2 * p.n + 4 * (p.mw - 1); w += (u64)p.n * p.node_words;
+  // (class 0, instance-major, LBFT_C0_ALIGN: node rows start on a 128-byte line and are padded to whole lines; snapshots and
+  // block records are padded to 64 bytes and aligned to them; every instance starts on a line)
+  const bool c0a = LBFT_C0_IMAJOR && LBFT_C0_ALIGN && sim_class(p) == 0;
+  auto up = [](u64 x, u64 a) { return (x + a - 1) / a * a; };
+  if (c0a) w = up(w, 32);
+  p.off_node = (u32)w; p.node_words = NF_FIXED_WORDS + 2 * p.n + 4 * (p.mw - 1);
+  if (c0a) p.node_words = (u32)up(p.node_words, 32);
+  w += (u64)p.n * p.node_words;
   p.off_qhi = (u32)w; w += p.qcap;
   p.off_qlo = (u32)w; w += p.qcap;  // (the calendar stores no keys: these rows hold its stack of freed slots)
   p.off_qmeta = (u32)w; w += p.qcap;
@@ -2949,10 +3111,12 @@ inline u64 compute_layout(Params& p) {
   p.off_cal_tail = (u32)w; w += p.cal_buckets;
   p.off_cal_bm = (u32)w; w += (p.cal_buckets + 31) / 32 + (p.qcal ? 1 : 0);
   p.snap_words = S_FIXED_WORDS + 2 * p.n + 2 * (p.mw - 1) + ((p.quirks & 1u) ? 2 : 0);  // + the request's (epoch, certificates)
+  if (c0a) { p.snap_words = (u32)up(p.snap_words, 16); w = up(w, 16); }
   p.off_snap = (u32)w; w += (u64)p.scap * p.snap_words;
   p.off_snap_ref = (u32)w; w += p.scap;
   p.off_snap_free = (u32)w; w += p.scap;
   p.blk_words = B_WORDS + 4 * (p.mw - 1);  // + extension words (nodes / authors >= 32) of KNOWN, QC, PEND and VOTERS
+  if (c0a) { p.blk_words = (u32)up(p.blk_words, 16); w = up(w, 16); }
   p.off_blk = (u32)w; w += (u64)p.bcap * p.blk_words;
   p.off_log = (u32)w; w += (u64)p.n * p.lcap;
   p.off_list = (u32)w; w += p.n > 16 ? p.n : 0;
@@ -2960,6 +3124,7 @@ inline u64 compute_layout(Params& p) {
   p.off_arch = (u32)w; w += (p.quirks & 1u) ? (u64)p.n * p.ecap * p.snap_words : 0;
   p.off_sync = (u32)w; w += (p.quirks & 1u) ? p.bcap : 0;
   p.off_ring = (u32)w; w += 2ULL * p.ring;
+  if (c0a) w = up(w, 32);
   p.total_words = w > 0xffffffffULL ? 0xffffffffu : (u32)w;
   p.qpack = sim_class(p) == 0 ? 1u : 0u;
   return w;

@@ -65,14 +65,16 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restr
 
 // [tables][queue keys][queue metas][diagnostics: LBFT_NPHASES u64 per wavefront][n > 16: one 128-byte receiver list per instance]
 // `slot_bytes`: 12 (key + meta) or 8 (packed one-word entries, kernel class 0)
+// (class 0 with a lane-major queue front, LBFT_C0_QLANE: LBFT_QLANE_PAD more words per lane)
+#define LBFT_QPAD(slot_bytes) ((slot_bytes) == 8 && LBFT_C0_QLANE ? LBFT_QLANE_PAD : 0u)
 static inline size_t run_lds_bytes(u32 ql, u32 lpw, u32 n, u32 slot_bytes) {
-  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * ql * lpw * slot_bytes + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8 + 8 +
+  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * (ql + LBFT_QPAD(slot_bytes)) * lpw * slot_bytes + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8 + 8 +
          (n > 16 ? (size_t)LBFT_RUN_WAVES * lpw * LBFT_MAX_NODES : 0) +
-         (n <= 4 && slot_bytes == 8 ? (size_t)LBFT_RUN_WAVES * lpw * LBFT_LDS_HCBR_WORDS * 4 : 0);  // class 0, n <= 4: hcbr buffers
+         (n <= 4 && slot_bytes == 8 && !(LBFT_C0_IMAJOR && LBFT_C0_HCREG) ? (size_t)LBFT_RUN_WAVES * lpw * LBFT_LDS_HCBR_WORDS * 4 : 0);  // class 0, n <= 4: hcbr buffers
 }
 
 __device__ __forceinline__ size_t run_lds_bytes_dev(u32 ql, u32 lpw, u32 slot_bytes) {  // = run_lds_bytes(ql, lpw, 0, ..): where the receiver lists start
-  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * ql * lpw * slot_bytes + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8 + 8;
+  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * (ql + LBFT_QPAD(slot_bytes)) * lpw * slot_bytes + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8 + 8;
 }
 #ifndef LBFT_RUN_WAVES_PER_SIMD
 #define LBFT_RUN_WAVES_PER_SIMD 2  // register budget of the class-0 run kernel: 512 / 2 = 256 VGPRs + AGPRs per lane (the
@@ -96,8 +98,9 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
   for (u32 t = threadIdx.x; t < p.n; t += LBFT_RUN_BLOCK) t_weights[t] = p.weights[t];
   __syncthreads();
   u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  u64* keys = lds + LBFT_TABLE_U64 + (size_t)wave * p.ql * p.lpw + lane;
-  u32* metas = reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)LBFT_RUN_WAVES * p.ql * p.lpw) + (size_t)wave * p.ql * p.lpw + lane;  // (CLS 0: unused, not allocated)
+  const u32 qslots = p.ql + (SimT<CLS>::QLANE ? LBFT_QLANE_PAD : 0u);  // u64 words per instance in the key area
+  u64* keys = SimT<CLS>::QLANE ? lds + LBFT_TABLE_U64 + ((size_t)wave * p.lpw + lane) * qslots : lds + LBFT_TABLE_U64 + (size_t)wave * p.ql * p.lpw + lane;
+  u32* metas = reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)LBFT_RUN_WAVES * qslots * p.lpw) + (size_t)wave * p.ql * p.lpw + lane;  // (CLS 0: unused, not allocated)
   const u32 meta_words = CLS == 0 ? 0u : LBFT_RUN_WAVES * p.ql * p.lpw;
   // Only the first p.lpw lanes of a wavefront carry an instance (occupancy vs lane-utilisation knob).
   u32 i = (blockIdx.x * LBFT_RUN_WAVES + wave) * p.lpw + lane;
@@ -129,7 +132,7 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
       s.queue_to_lds();
     }
 #if defined(LBFT_PHASE_TIMERS)
-    u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)LBFT_RUN_WAVES * p.ql * p.lpw) +
+    u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)LBFT_RUN_WAVES * qslots * p.lpw) +
                                         (size_t)meta_words + (meta_words & 1u)) + wave * LBFT_NPHASES;
     if (lane == 0) { for (int k = 0; k < LBFT_NPHASES; k++) wprof[k] = 0; wprof[31] = __builtin_readcyclecounter(); }
     s.wprof = wprof;
@@ -149,7 +152,8 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
 #endif
   } else
   if (active) {
-    SimT<CLS> s(p, tile, (i & (tw - 1u)) * 4u, 0);
+    // (instance-major classes: lane j's instance sits j instances behind the wavefront's first one -- folded into the lane's 32-bit column offset)
+    SimT<CLS> s(p, tile, SimT<CLS>::IMAJOR ? lane * (p.total_words * 4u) : (i & (tw - 1u)) * 4u, 0);
     if (s.ld(I_DONE) == 0) {
       s.attach_queue(keys, metas, p.lpw, p.ql);
       s.attach_tables(t_zx, t_zf, t_et);
@@ -159,7 +163,7 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
         u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, CLS == 0 ? 8u : 12u);
         s.attach_peer_list(lists + ((size_t)wave * p.lpw + lane) * LBFT_MAX_NODES);
       }
-      if (CLS == 0 && p.n <= 4) {  // the nodes' hcbr buffers (same place as the receiver lists of large networks)
+      if (CLS == 0 && p.n <= 4 && !SimT<CLS>::HCREG) {  // the nodes' hcbr buffers (same place as the receiver lists of large networks)
         u32* hcb = reinterpret_cast<u32*>(reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 8u));
         s.attach_hcbr(hcb + (size_t)wave * LBFT_LDS_HCBR_WORDS * p.lpw + lane);
       }
@@ -168,7 +172,7 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
       s.hcbr_to_lds();
 #if defined(LBFT_PHASE_TIMERS)
       // per-wavefront accumulators behind the queue columns (8-byte aligned: the meta area is a multiple of 8 words)
-      u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)LBFT_RUN_WAVES * p.ql * p.lpw) +
+      u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)LBFT_RUN_WAVES * qslots * p.lpw) +
                                           (size_t)meta_words + (meta_words & 1u)) + wave * LBFT_NPHASES;
       if (lane == 0) { for (int k = 0; k < LBFT_NPHASES; k++) wprof[k] = 0; wprof[31] = __builtin_readcyclecounter(); }
       s.wprof = wprof;
@@ -835,10 +839,10 @@ int lbft_batch_layout(const lbft_batch* b, uint32_t* out) {
   if (!b || !out) return LBFT_ERR_INVALID;
   if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
   const Params& p = b->p;
-  out[0] = p.node_words * 4;  // bytes of one node's rows (fixed rows + hcbr buffers + extension words)
+  out[0] = node_words_used(p) * 4;  // bytes of one node's rows (fixed rows + hcbr buffers + extension words; without alignment padding)
   out[1] = p.qpack ? 8 : 12;  // bytes of one queued event (packed word / 64-bit key + meta word)
-  out[2] = p.snap_words * 4;  // bytes of one notification snapshot
-  out[3] = p.blk_words * 4;   // bytes of one block record
+  out[2] = snap_words_used(p) * 4;  // bytes of one notification snapshot
+  out[3] = (B_WORDS + 4 * (p.mw - 1)) * 4;   // bytes of one block record
   out[4] = p.total_words * 4; // HBM bytes per instance
   out[5] = p.ql;              // event-queue slots per instance resident in LDS
   out[6] = p.lpw;             // lanes per wavefront carrying an instance
@@ -962,7 +966,7 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   {
     // Measured (16 384 x 64 nodes / 8 192 x 100 nodes / c4live): tw = 64: 652 ms / 3.63 s / --; tw = lanes per wavefront: 596 / 3.20 / 4.94 s;
     // tw = 4: 555 / 3.17 / 4.43; tw = 2: 550 / 3.10 / 4.28; tw = 1: 541 ms / 3.05 s / 4.14 s -- the large-network kernels address tw = 1 at compile time.
-    u32 tw = sim_class(p) <= 1 ? 64u : 1u;
+    u32 tw = layout_tile_width(p);
     // (instance-major rows: a lane addresses its instance through a 32-bit offset from the wavefront's first instance)
     if (tw == 1 && (u64)lpw * p.total_words * 4ULL >= (1ULL << 32)) {
       g_err = "lanes per wavefront x per-instance state exceeds 4 GiB: lower the capacities or the lanes per wavefront";
@@ -979,11 +983,11 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   size_t budget = (160u * 1024u) / wg_per_cu;
   // 2 KiB slack per workgroup: with less, two workgroups of 32-lane wavefronts do not become co-resident on a CU
   u32 slot_bytes = p.qpack ? 8u : 12u;  // kernel class 0 keeps one-word entries
-  u32 ql_auto = (u32)((budget - run_lds_bytes(0, lpw, n, slot_bytes) - 2048) / (slot_bytes * LBFT_RUN_WAVES * lpw));
+  u32 ql_auto = (u32)((budget - run_lds_bytes(0, lpw, n, slot_bytes) - 2048) / (slot_bytes * LBFT_RUN_WAVES * lpw));  // (run_lds_bytes(0, ..) includes the lane padding)
   if (p.qpack && ql_auto > LBFT_PACKED_QL_MAX) ql_auto = LBFT_PACKED_QL_MAX;
   u32 ql = b->ql < 0 ? ql_auto : (u32)b->ql;
   if (ql > qcap) ql = qcap;
-  if (p.qpack) ql &= ~7u;  // scanned in batches of 8
+  if (p.qpack) ql &= ~(LBFT_POP_BATCH - 1u);  // scanned in batches of LBFT_POP_BATCH
   if (p.qcal) ql = 0;  // the calendar lives in HBM rows
   if (run_lds_bytes(ql, lpw, n, slot_bytes) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
   p.ql = ql;

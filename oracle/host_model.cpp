@@ -128,8 +128,11 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
     s.store_scalars(done);
   };
   int cls = caps->force_generic ? 3 : sim_class(p);
-  if (cls == 0 || cls == 1) { p.tw = 64; p.rsh = 8; }  // the small-network classes address 64-wide tiles at compile time
-  if (cls == 2) { p.tw = 1; p.rsh = 2; }                 // ... and the large-network class instance-major rows
+  if (cls <= 2) {  // the tile width each class addresses at compile time (64-wide tiles or instance-major rows)
+    p.tw = layout_tile_width(p);
+    p.rsh = 2;
+    while ((1u << p.rsh) < 4u * p.tw) p.rsh++;
+  }
   auto worker = [&](u32 tid) {
     for (size_t i = tid; i < n_instances; i += threads) {
       { Sim s0(p, state.data(), (u32)i); s0.init(seeds[i]); }
