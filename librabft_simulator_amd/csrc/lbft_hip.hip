@@ -39,8 +39,8 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restr
 
 // Simulator::loop_until for every instance (simulator.rs:380-475).
 //
-// Workgroup = 4 wavefronts; wavefront w of workgroup g advances instances
-// [(g * 4 + w) * lpw, +lpw).  LDS (dynamic, up to the CU's whole 160 KiB):
+// Workgroup = LBFT_RUN_WAVES (8) wavefronts = both wavefront slots of a CU's four SIMDs (256 registers per lane: two per SIMD);
+// wavefront w of workgroup g advances instances [(g * 8 + w) * lpw, +lpw).  LDS (dynamic, up to the CU's whole 160 KiB):
 //   [zig_x 257][zig_f 257][exp_tab 256]  u64   read-only tables of the delay sampler, one copy per workgroup
 //   [dur 128] i64, [leader 1024] u8            pacemaker duration / leader tables (first rounds)
 //   keys  [wave][slot][lane]              u64   event-queue keys, lane-private columns: class 0 one packed word per event
@@ -50,8 +50,12 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restr
 //                                               hcbr buffers, 32 words per instance ([wave][word][lane])
 // A lane only ever touches its own column (address = slot * lpw + lane), so data-dependent slot
 // indices are bank-conflict free and no workgroup barrier is needed after the table fill.
+// (round 3: 8 instead of 4.  Equal for every batch that fills the chip -- 65 536 x 4: 21.61 vs 21.67 ms, 32 768: 18.4 vs 18.6, 16 384: 15.7 vs
+// 15.5 -- but a batch of <= 1 024 networks then packs two wavefronts on every SIMD of half the CUs instead of one on each SIMD of all
+// of them, and a wavefront that shares its SIMD runs FASTER per step (phase timers, one network per wavefront: 13.2 k cycles per step
+// with a partner, 17.3 k alone): 1 024 x 4 nodes 9.8 -> 7.0 ms.)
 #ifndef LBFT_RUN_WAVES
-#define LBFT_RUN_WAVES 4
+#define LBFT_RUN_WAVES 8
 #endif
 #define LBFT_RUN_BLOCK (64 * LBFT_RUN_WAVES)
 #define LBFT_LDS_HCBR_WORDS 32  // class 0, n <= 4: hcbr[node][2][4] per instance
