@@ -8,7 +8,7 @@ OUT=gpurun_out/profile_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 600 python bench.py --steps 5 --warmup 1 > $OUT/bench_line.json 2> $OUT/bench.err
-CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --parity-instances 0"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- $CMD > $OUT/stats.log 2>&1
 cp $OUT/stats/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
 pass() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$name -o pmc --output-format csv -- $CMD > $OUT/$name.log 2>&1 || tail -3 $OUT/$name.log; }
