@@ -843,9 +843,14 @@ int lbft_batch_layout(const lbft_batch* b, uint32_t* out) {
   if (!b || !out) return LBFT_ERR_INVALID;
   if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
   const Params& p = b->p;
-  out[0] = node_words_used(p) * 4;  // bytes of one node's rows (fixed rows + hcbr buffers + extension words; without alignment padding)
-  out[1] = p.qpack ? 8 : 12;  // bytes of one queued event (packed word / 64-bit key + meta word)
-  out[2] = snap_words_used(p) * 4;  // bytes of one notification snapshot
+  // what one event moves (the roofline's S_node / S_notif, bench.py, tools/configs.py), not the padded row sizes: a node burst is the
+  // fixed words + the extension words of the four author sets (begin_node / end_node); the hcbr buffers (2n words behind them) are
+  // only touched where a timeout is inserted or copied -- for networks of <= 4 nodes they live in LDS for the whole launch.  A
+  // notification snapshot: its fixed words + set extension words; for <= 4 nodes also its 2n hcbr words (always fetched with it), for
+  // larger networks the hcbr words an event happens to carry are NOT counted (the figure is a lower bound there).
+  out[0] = (NF_FIXED_WORDS + 4 * (p.mw - 1)) * 4;
+  out[1] = (p.qpack ? 8 : 12);
+  out[2] = (S_FIXED_WORDS + 2 * (p.mw - 1) + (p.n <= 4 ? 2 * p.n : 0)) * 4;
   out[3] = (B_WORDS + 4 * (p.mw - 1)) * 4;   // bytes of one block record
   out[4] = p.total_words * 4; // HBM bytes per instance
   out[5] = p.ql;              // event-queue slots per instance resident in LDS

@@ -15,6 +15,8 @@ CONFIGS = {
     "c2_1024x4_lognormal": dict(instances=1024, nodes=4, max_clock=1000),
     "c2_1024x4_uniform": dict(instances=1024, nodes=4, max_clock=1000, uniform=(5, 15)),
     "c3_65536x4": dict(instances=65536, nodes=4, max_clock=1000),
+    # what each of 8 GPUs runs when configuration 3 is read as ONE 65 536-instance batch sharded over the node (strong scaling)
+    "c3shard_8192x4": dict(instances=8192, nodes=4, max_clock=1000),
     "c4_16384x64_longtail_equivocators": dict(instances=16384, nodes=64, max_clock=300, variance=400.0, equivocate_every=5),
     "c5_8192x100_weighted_epochs": dict(instances=8192, nodes=100, max_clock=300, weights=[1 + (i % 4) for i in range(100)],
                                         commands_per_epoch=50),
@@ -36,6 +38,14 @@ CONFIGS = {
 }
 HBM_PEAK_GBS = 8000.0
 OPT_IN = ("c5b", "c4live", "c5live")
+# What pins each configuration's results (printed with every line): the reference itself only holds answers for 3- / 8-node
+# LogNormal(10, 4) runs; everything else is "device == oracle", the oracle being the specification.
+PARITY = {
+    "c2_1024x4_lognormal": "oracle == reference goldens (3/8 nodes, LogNormal(10,4)); 4 nodes: oracle-as-spec, same code path",
+    "c3_65536x4": "oracle == reference goldens (3/8 nodes, LogNormal(10,4)); 4 nodes: oracle-as-spec, same code path",
+    "c3shard_8192x4": "oracle == reference goldens (3/8 nodes, LogNormal(10,4)); 4 nodes: oracle-as-spec, same code path",
+}
+PARITY_DEFAULT = "oracle-as-spec (no reference answer: extension / size the reference never ran)"
 
 
 def kernel_name(layout):
@@ -48,8 +58,24 @@ def kernel_name(layout):
     return "lbft_k_run<%d>" % cls
 
 
-def roofline(layout, k, kernel_ms):
-    """SURVEY.md 8(d) per configuration, both ways (bench.py: all reference-equivalent events / rows the device moves)."""
+def measured_traffic(name):
+    """HBM bytes per launch of this configuration's run kernel from its own PMC passes (tools/gpu_configs_profile.sh writes
+    <dir>/<config>.pmc.json; LBFT_PMC_DIR points at that directory): 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes."""
+    d = os.environ.get("LBFT_PMC_DIR")
+    if not d:
+        return None
+    try:
+        with open(os.path.join(d, name + ".pmc.json")) as f:
+            t = json.load(f)
+        return {"gb_per_launch": (2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024 / 1e9, "fetch_kb_raw": t["FETCH_SIZE"], "write_kb_raw": t["WRITE_SIZE"]}
+    except Exception:
+        return None
+
+
+def roofline(layout, k, kernel_ms, name=None):
+    """SURVEY.md 8(d) per configuration, both ways (bench.py: all reference-equivalent events / rows the device moves).  The sizes are what
+    one event moves (lbft_batch_layout: node burst = fixed words + set extension words; hcbr words of large networks not counted), so the
+    algorithmic bytes are a lower bound of the traffic; `traffic` (per-configuration PMC pass) must not be below `executed`."""
     ev = sum(k["events"])
     s_node, s_evt, s_notif = layout["node_bytes"], layout["event_bytes"], layout["snapshot_bytes"]
     p = k["events_scheduled"] / max(ev, 1)
@@ -58,10 +84,18 @@ def roofline(layout, k, kernel_ms):
     pops = ev - k.get("timers_folded", 0)
     ex = pops * s_node + k.get("node_updates", pops) * s_node + 2 * pops * s_evt + 2 * k["events"][0] * s_notif
     sec = kernel_ms * 1e-3
-    return {"bound": "hbm", "kernel": kernel_name(layout), "kernel_ms": kernel_ms, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "algorithmic_bytes_per_event": bpe, "achieved": ev * bpe / sec / 1e9, "frac": ev * bpe / sec / 1e9 / HBM_PEAK_GBS,
-            "executed": {"gb_per_launch": ex / 1e9, "achieved": ex / sec / 1e9, "frac": ex / sec / 1e9 / HBM_PEAK_GBS, "queue_pops": pops,
-                         "node_updates": k.get("node_updates")}}
+    t = measured_traffic(name) if name else None
+    out = {"bound": "hbm", "kernel": kernel_name(layout), "kernel_ms": kernel_ms, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "algorithmic_bytes_per_event": bpe, "algorithmic_gb_per_launch": ev * bpe / 1e9, "achieved": ev * bpe / sec / 1e9,
+           "frac": ev * bpe / sec / 1e9 / HBM_PEAK_GBS,
+           "executed": {"gb_per_launch": ex / 1e9, "achieved": ex / sec / 1e9, "frac": ex / sec / 1e9 / HBM_PEAK_GBS, "queue_pops": pops,
+                        "node_updates": k.get("node_updates")},
+           "traffic": t["gb_per_launch"] if t else None, "traffic_unit": "GB per launch (2 x FETCH_SIZE + WRITE_SIZE)", "traffic_detail": t}
+    if t:
+        out["traffic_over_algorithmic"] = t["gb_per_launch"] / (ev * bpe / 1e9)
+        out["traffic_over_executed"] = t["gb_per_launch"] / (ex / 1e9)
+        out["traffic_frac_of_peak"] = t["gb_per_launch"] / sec / HBM_PEAK_GBS
+    return out
 
 
 def run(name, scale=1.0, reps=1, lpw=0):
@@ -86,7 +120,7 @@ def run(name, scale=1.0, reps=1, lpw=0):
     liveness = {"min_node_commits": {"min": int(worst.min()), "median": float(np.median(worst)), "max": int(worst.max())},
                 "instances_with_5_commits_at_every_node": float((worst >= 5).mean()),
                 "epochs_min_max": [int(res.epochs.min()), int(res.epochs.max())]}
-    out = {"config": name, "liveness": liveness, "roofline": roofline(sim.layout(), k, best), "instances": m, "nodes": c["nodes"], "max_clock": c["max_clock"], "kernel_ms": best,
+    out = {"config": name, "parity": PARITY.get(name, PARITY_DEFAULT), "liveness": liveness, "roofline": roofline(sim.layout(), k, best, name), "instances": m, "nodes": c["nodes"], "max_clock": c["max_clock"], "kernel_ms": best,
            "rounds_per_s": k["rounds"] / (best * 1e-3), "commits_per_s": k["commits"] / (best * 1e-3),
            "events_per_s": sum(k["events"]) / (best * 1e-3), "events": sum(k["events"]), "rounds": k["rounds"], "commits": k["commits"],
            "faulted_instances": k["faulted_instances"], "max_queue": k["max_queue"], "max_snapshots": k["max_snapshots"],

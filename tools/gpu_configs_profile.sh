@@ -9,7 +9,8 @@ PROF_CONFIGS=${2:-"c4_16384x64_longtail_equivocators c5_8192x100_weighted_epochs
 OUT=gpurun_out/configs_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 900 python tools/configs.py c2_1024x4_lognormal c2_1024x4_uniform c3_65536x4 c4_16384x64_longtail_equivocators c5_8192x100_weighted_epochs \
+# (first pass: timings; the lines are rewritten with each configuration's own PMC traffic at the end)
+timeout 900 python tools/configs.py c2_1024x4_lognormal c2_1024x4_uniform c3_65536x4 c3shard_8192x4 c4_16384x64_longtail_equivocators c5_8192x100_weighted_epochs \
   c4live_16384x64_longtail_equivocators_fixed c5live_8192x100_rotating_rights_epochs_fixed > $OUT/baseline_configs.jsonl 2> $OUT/configs.err
 python - "$OUT" <<'PY'
 import json, sys
@@ -30,3 +31,11 @@ for cfg in $PROF_CONFIGS; do
   rm -rf $OUT/$cfg.stats $OUT/$cfg.fetch $OUT/$cfg.write $OUT/$cfg.sq2 $OUT/$cfg.sq1
   head -3 $OUT/$cfg.kernel_stats.csv; head -30 $OUT/$cfg.pmc.json
 done
+# second pass of the lines, now with `roofline.traffic` from each configuration's own FETCH / WRITE passes
+LBFT_PMC_DIR=$OUT timeout 900 python tools/configs.py c2_1024x4_lognormal c2_1024x4_uniform c3_65536x4 c3shard_8192x4 $PROF_CONFIGS > $OUT/baseline_configs_with_traffic.jsonl 2>> $OUT/configs.err
+python - "$OUT" <<'PY'
+import json, sys
+for line in open(sys.argv[1] + "/baseline_configs_with_traffic.jsonl"):
+    d = json.loads(line); r = d["roofline"]
+    print(d["config"], "ms", round(d["kernel_ms"], 2), "frac", round(r["frac"], 4), "exec", round(r["executed"]["frac"], 4), "traffic GB", r["traffic"], "t/alg", r.get("traffic_over_algorithmic"), "t/exec", r.get("traffic_over_executed"))
+PY
