@@ -78,6 +78,8 @@ extern "C" {
     fn lbft_batch_create(cfg: *const LbftConfig, seeds: *const u64, n: usize, device: c_int, out: *mut *mut c_void) -> c_int;
     fn lbft_batch_run_until(b: *mut c_void, max_clock: i64) -> c_int;
     fn lbft_batch_save_node(b: *const c_void, inst: usize, node: u32, buf: *mut c_void, cap: usize, len: *mut usize) -> c_int;
+    /// past_record_stores (node.rs:43) kept in full on the device: save_node then also serves nodes that have changed epoch
+    pub fn lbft_batch_keep_retired_stores(b: *mut c_void, enable: c_int) -> c_int;
     fn lbft_batch_commit_counts(b: *const c_void, out: *mut u32) -> c_int;
     fn lbft_batch_committed_history(b: *const c_void, inst: usize, node: u32, out: *mut LbftCommit, cap: usize, len: *mut usize) -> c_int;
     fn lbft_batch_last_committed_state(b: *const c_void, inst: usize, node: u32, out: *mut u64) -> c_int;
@@ -207,6 +209,8 @@ impl NodeBatch {
         let mut handle = std::ptr::null_mut();
         check(unsafe { lbft_batch_create(&cfg, rng_seeds.as_ptr(), rng_seeds.len(), 0, &mut handle) })?;
         let batch = Batch { handle, num_nodes, num_instances: rng_seeds.len() };
+        // ConsensusNode::save_node serialises past_record_stores (node.rs:43): a node-level session keeps the retired stores in full
+        check(unsafe { lbft_batch_keep_retired_stores(batch.handle, 1) })?;
         check(unsafe { lbft_batch_manual_begin(batch.handle, max_clock) })?;
         Ok(Arc::new(NodeBatch { batch }))
     }
@@ -308,26 +312,28 @@ impl ConsensusNode<SimulatedContext> for GpuNode {
 
     /// node.rs:233-238: `bincode::serialize(&NodeState)` under the reference's key.  `lbft_batch_save_node` builds that image
     /// from the device state (HashMaps in ascending key order; the reference's `load_node` accepts any order), so a
-    /// reference node can be restored from what a GPU node saved.  A node that has changed epoch is not supported by
-    /// the device image (retired record stores are not kept in full): then only the save marker is stored -- the device
-    /// state itself stays durable for the lifetime of the batch (`lbft_batch_checkpoint_save` images the whole batch).
+    /// reference node can be restored from what a GPU node saved.  Nodes that have changed epoch need the batch to keep the
+    /// retired record stores (`lbft_batch_keep_retired_stores`, called by `GpuBatch::new` before the session starts); if the
+    /// image cannot be built the call FAILS -- a stale image of an earlier save is never left under the reference's key
+    /// (round-2 advisor) and the save marker does not advance.
     fn save_node<'a>(&'a mut self, context: &'a mut SimulatedContext) -> AsyncResult<'a, ()> {
         let marker = self.last_saved.0.to_le_bytes().to_vec();
         let handle = self.batch.batch.handle as *const c_void;
         let (inst, author) = (self.inst, self.author);
         let mut len = 0usize;
         let mut image = Vec::new();
-        let rc = unsafe { lbft_batch_save_node(handle, inst, author, std::ptr::null_mut(), 0, &mut len) };
-        if rc == 0 && len > 0 {
+        let mut rc = unsafe { lbft_batch_save_node(handle, inst, author, std::ptr::null_mut(), 0, &mut len) };
+        if rc == 0 {
             image.resize(len, 0u8);
-            if unsafe { lbft_batch_save_node(handle, inst, author, image.as_mut_ptr() as *mut c_void, len, &mut len) } != 0 {
-                image.clear();
-            }
+            rc = unsafe { lbft_batch_save_node(handle, inst, author, image.as_mut_ptr() as *mut c_void, len, &mut len) };
         }
         Box::pin(async move {
-            if !image.is_empty() {
-                context.store_value(NODE_IMAGE_KEY.to_string(), image).await?;
+            if rc != 0 {
+                // overwrite whatever an earlier save left: an empty value does not deserialise as a NodeState, so load_node fails loudly
+                context.store_value(NODE_IMAGE_KEY.to_string(), Vec::new()).await?;
+                return check(rc);
             }
+            context.store_value(NODE_IMAGE_KEY.to_string(), image).await?;
             context.store_value(SAVE_KEY.to_string(), marker).await
         })
     }

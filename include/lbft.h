@@ -166,9 +166,15 @@ int lbft_batch_last_committed_states(const lbft_batch* b, uint64_t* out);
 /* ConsensusNode::save_node (librabft-v2/src/node.rs:233-238): bincode::serialize(&NodeState) of one node -- record store with every Block /
  * QuorumCertificate / Vote / Timeout it holds (rebuilt with the reference's BCS + SipHash-1-3 hashes and signatures), pacemaker, tracker --
  * in bincode 1.3's default encoding with HashMaps in ascending key order (the reference's own order is per-process; its load_node,
- * node.rs:211-231, accepts any order).  *len = the image's length; copied when cap suffices.  Nodes that have changed epoch are not
- * supported (LBFT_ERR_UNSUPPORTED: retired record stores are not kept in full on the device). */
+ * node.rs:211-231, accepts any order).  *len = the image's length; buf == NULL: size query; a buffer smaller than the image is
+ * LBFT_ERR_INVALID (*len still holds the size needed).  A node that has changed epoch carries its retired record stores
+ * (past_record_stores, node.rs:43,338-340): the device keeps them in full only when lbft_batch_keep_retired_stores(b, 1) was called
+ * before the run; otherwise such a node is LBFT_ERR_UNSUPPORTED (nodes still in epoch 0 always work). */
 int lbft_batch_save_node(const lbft_batch* b, size_t inst, uint32_t node, void* buf, size_t cap, size_t* len);
+/* past_record_stores kept in full: at every epoch change the node's rows (record-store fields, timeouts, votes, election) are copied
+ * into an archive entry of the epoch being left -- num_nodes x epochs x one node's rows of device memory per instance.  Call before
+ * the batch runs.  Off by default: a run's results never depend on it. */
+int lbft_batch_keep_retired_stores(lbft_batch* b, int enable);
 /* ... and of one node: contexts[node].last_committed_state() as librabft-v2/tests/simulated_run.rs:57-65 reads it. */
 int lbft_batch_last_committed_state(const lbft_batch* b, size_t inst, uint32_t node, uint64_t* out);
 /* SimulatedNode::startup_time (simulator.rs:55,217): out[inst * num_nodes + node]. */

@@ -108,7 +108,7 @@ ABI_SYMBOLS = [
     "lbft_batch_device_bytes", "lbft_batch_set_max_steps", "lbft_batch_set_lanes_per_wavefront",
     "lbft_batch_set_lds_queue_slots", "lbft_batch_set_calendar_queue", "lbft_batch_phase_cycles", "lbft_batch_layout",
     "lbft_batch_run_steps", "lbft_batch_checkpoint_bytes", "lbft_batch_checkpoint_save", "lbft_batch_checkpoint_load",
-    "lbft_batch_enable_round_trace", "lbft_batch_round_switches", "lbft_batch_manual_begin", "lbft_batch_manual_finalize", "lbft_node_update", "lbft_node_create_notification",
+    "lbft_batch_enable_round_trace", "lbft_batch_keep_retired_stores", "lbft_batch_round_switches", "lbft_batch_manual_begin", "lbft_batch_manual_finalize", "lbft_node_update", "lbft_node_create_notification",
     "lbft_node_handle_notification", "lbft_node_release_notification", "lbft_node_create_request", "lbft_node_handle_request",
     "lbft_node_handle_response", "lbft_node_view_get", "lbft_device_leaders", "lbft_device_sample_delays",
     "lbft_device_exp_log", "lbft_last_error", "lbft_build_info",
@@ -178,6 +178,8 @@ def lib():
     L.lbft_batch_checkpoint_save.restype = C.c_int
     L.lbft_batch_checkpoint_load.argtypes = [vp, vp, C.c_size_t]
     L.lbft_batch_checkpoint_load.restype = C.c_int
+    L.lbft_batch_keep_retired_stores.argtypes = [vp, C.c_int]
+    L.lbft_batch_keep_retired_stores.restype = C.c_int
     L.lbft_batch_enable_round_trace.argtypes = [vp, C.c_uint32]
     L.lbft_batch_enable_round_trace.restype = C.c_int
     L.lbft_batch_round_switches.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

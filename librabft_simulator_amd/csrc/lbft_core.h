@@ -159,6 +159,7 @@ struct Params {
   u32 off_list;  // n > 16 only: receiver list scratch of process_node_actions
   u32 off_arch, ecap;   // quirks bit 0 (Q1 fixed): frozen record stores of past epochs, snapshot format, [n][ecap]
   u32 off_sync;         // quirks bit 0: scratch list of block ids (bcap words) for building a response's record order
+  u32 off_rarch, rarch_words;  // lbft_batch_keep_retired_stores: verbatim copy of a node's rows at each epoch change, [n][ecap][rarch_words] (0: off)
   u32 off_trace, rcap;  // round-switch trace (DataWriter, data_writer.rs): first_time[n][rcap] then max_round[n]; rcap == 0: off
   u32 off_ring, ring;   // cooperative large-network kernels: ring of pre-generated RNG draws (ring entries, a power of two; 2 rows each); 0 = none
   u32 ring_topup;       // draws every network's generator runs ahead per event-loop step (0 = only on demand)
@@ -674,7 +675,7 @@ struct SimT {
   LBFT_HD SimT(const Params& p, u32* state, u32 i) : SimT(p, reinterpret_cast<char*>(state) + tile_offset_bytes(p, i), (i & (p.tw - 1u)) * 4u, 0) {}
   LBFT_HD SimT(const Params& p, char* tile_base, u32 lane_byte_offset, int) : P(p), tile(tile_base), lane4(lane_byte_offset), qk(nullptr), qm(nullptr), qstr(0), qsh(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab),
         leader_lds(nullptr), dur_lds(nullptr), leader_lds_len(0), dur_lds_len(0), hc(nullptr), plist_lds(nullptr) {
-    coop_on = false; cur_xk = 0; wtab = p.weights;
+    coop_on = false; cur_xk = 0; wtab = p.weights; hcdirty = 0; sw_epoch = 0; sw_blk = 0;
     if (RING) { rng.rtile = tile; rng.rrsh = rsh(); rng.rbase = boff(P.off_ring); rng.rmask = P.ring ? P.ring - 1u : 0xffffffffu; rng.rhead = 0; rng.rcnt = 0; }
   }
   LBFT_HD void attach_queue(u64* keys, u32* metas, u32 stride, u32 slots) {
@@ -1824,6 +1825,34 @@ struct SimT {
       if (commit_block(node, y, ry.depth())) break;
     }
   }
+  // past_record_stores.insert(self.epoch_id, old_record_store) (node.rs:338-340), kept IN FULL when the batch asked for it
+  // (lbft_batch_keep_retired_stores: what save_node needs for a node that has changed epoch): the node's rows -- fixed words, hcbr
+  // buffers, set extension words -- copied verbatim into the archive entry of the epoch being left.  The blocks and certificates of
+  // the retired store need no copy: they are the block rows of that epoch whose KNOWN / QC bit the node holds (never set again later).
+  LBFT_HD void retire_store(u32 node) {
+#if defined(LBFT_NO_RETIRE)
+    return;
+#endif
+    if (!P.rarch_words) return;
+    u32 old_epoch = nf(node, NF_EPOCH);
+    if (old_epoch >= P.ecap) { fault |= F_EPOCH_OVERFLOW; return; }
+    u32 base = P.off_rarch + (node * P.ecap + old_epoch) * P.rarch_words;
+    // (the fixed words come from the register copy, everything behind them from the node's rows: the hcbr buffers -- LDS-resident for
+    // networks of <= 4 nodes in class 0 -- and the set extension words, which are flushed first)
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 f = 0; f < NF_FIXED_WORDS; f++) st(base + f, cw[f]);
+    ax_store(node);
+    axdirty = 0;
+    const u32 row = nfw(node, NF_FIXED_WORDS), tail = P.rarch_words - NF_FIXED_WORDS;
+    if (hc_lds()) {
+      for (u32 buf = 0; buf < 2; buf++)
+        for (u32 a = 0; a < P.n; a++) st(base + NF_FIXED_WORDS + buf * P.n + a, hc_get(node, buf, a));
+    } else {
+      for (u32 k = 0; k < tail; k++) st(base + NF_FIXED_WORDS + k, ld(row + k));
+    }
+  }
   // The tail of SimulatedContext::commit + the epoch switch of process_commits (node.rs:331-348) for one block whose
   // state is pending and extends the last commit.  Returns true when no further block may be committed in this call
   // (epoch change or full log).
@@ -1837,26 +1866,36 @@ struct SimT {
       // read_epoch_id (simulated_context.rs:199-207)
       // epoch = depth / commands_per_epoch; the (software) 64-bit division only runs when a boundary is crossed
       if ((u64)depth >= ((u64)nf(node, NF_EPOCH) + 1) * P.cpe) {
-        u64 new_epoch = (u64)depth / P.cpe;
-        // fresh RecordStoreState for the new epoch (node.rs:331-348, record_store.rs:169-198)
-        if (q1()) {  // the store being retired stays readable for peers that ask later (past_record_stores, node.rs:43,339)
-          u32 old_epoch = nf(node, NF_EPOCH);
-          if (old_epoch < P.ecap) write_store_snapshot(node, arch_base(node, old_epoch)); else fault |= F_EPOCH_OVERFLOW;
-        }
-        nfs(node, NF_PREV_EPOCH_HCC, nf(node, NF_HCC_BLK));  // ... and its commit certificate is what notifications forward (Q2 fixed)
-        nfs(node, NF_EPOCH, (u32)new_epoch);
-        nfs(node, NF_INIT_STATE_BLK, y);
-        nfs(node, NF_PROPOSED_BLK, 0);
-        nfs(node, NF_HQC_ROUND, 0); nfs(node, NF_HQC_BLK, 0); nfs(node, NF_HTC_ROUND, 0);
-        nfs(node, NF_CUR_ROUND, 1); nfs(node, NF_HC_ROUND, 0); nfs(node, NF_HCC_BLK, 0);
-        am_clear(node, NF_TC_MASK); am_clear(node, NF_TO_MASK); nfs(node, NF_TO_WEIGHT, 0);
-        nfs(node, NF_ELECTION, 0);
-        clear_ballot(node);
-        nfs(node, NF_LVR, 0); nfs(node, NF_LOCKED, 0);
+        // the epoch switch itself (node.rs:331-348) runs once process_commits has returned (update_node: epoch_switch) -- ONE site, and
+        // one with few live registers, instead of a copy inside each commit path
+        sw_epoch = (u32)((u64)depth / P.cpe) + 1u;
+        sw_blk = y;
         return true;
       }
     }
     return false;
+  }
+
+  // fresh RecordStoreState for the new epoch (node.rs:331-348, record_store.rs:169-198); the retired one is archived first
+  u32 sw_epoch, sw_blk;  // pending epoch switch of the current event's node: new epoch + 1 (0: none), the block whose commit ended the old one
+  LBFT_HD void epoch_switch(u32 node) {
+    const u32 new_epoch = sw_epoch - 1u, y = sw_blk;
+    sw_epoch = 0;
+    if (q1()) {  // the store being retired stays readable for peers that ask later (past_record_stores, node.rs:43,339)
+      u32 old_epoch = nf(node, NF_EPOCH);
+      if (old_epoch < P.ecap) write_store_snapshot(node, arch_base(node, old_epoch)); else fault |= F_EPOCH_OVERFLOW;
+    }
+    retire_store(node);
+    nfs(node, NF_PREV_EPOCH_HCC, nf(node, NF_HCC_BLK));  // ... and its commit certificate is what notifications forward (Q2 fixed)
+    nfs(node, NF_EPOCH, new_epoch);
+    nfs(node, NF_INIT_STATE_BLK, y);
+    nfs(node, NF_PROPOSED_BLK, 0);
+    nfs(node, NF_HQC_ROUND, 0); nfs(node, NF_HQC_BLK, 0); nfs(node, NF_HTC_ROUND, 0);
+    nfs(node, NF_CUR_ROUND, 1); nfs(node, NF_HC_ROUND, 0); nfs(node, NF_HCC_BLK, 0);
+    am_clear(node, NF_TC_MASK); am_clear(node, NF_TO_MASK); nfs(node, NF_TO_WEIGHT, 0);
+    nfs(node, NF_ELECTION, 0);
+    clear_ballot(node);
+    nfs(node, NF_LVR, 0); nfs(node, NF_LOCKED, 0);
   }
 
   // ---- NodeState::update_node (node.rs:240-304) ----
@@ -1907,6 +1946,7 @@ struct SimT {
     LBFT_UMARK(9);
     }
     process_commits(node);
+    if (sw_epoch) epoch_switch(node);
     LBFT_MARK(27);
     bool tq; i64 tnext;
     update_tracker(node, lqat, lclock, tq, tnext);
@@ -2847,6 +2887,7 @@ struct SimT {
       for (u32 k = 0; k < P.n; k++) st(P.off_trace + P.n * P.rcap + k, 0);
     }
     for (u32 s = 0; s < P.scap; s++) { st(P.off_snap_free + s, P.scap - 1 - s); st(P.off_snap_ref + s, 0); }
+    for (u32 k = 0; k < P.n * P.ecap * P.rarch_words; k++) st(P.off_rarch + k, 0);  // (an unused archive entry reads as "no store": current_round 0)
     rng.seed(seed);
     for (u32 node = 0; node < P.n; node++) {
       for (u32 f = 0; f < P.node_words; f++) nfms(node, f, 0);
@@ -3122,6 +3163,8 @@ inline u64 compute_layout(Params& p) {
   p.off_list = (u32)w; w += p.n > 16 ? p.n : 0;
   p.off_trace = (u32)w; w += p.rcap ? (u64)p.n * p.rcap + p.n : 0;
   p.off_arch = (u32)w; w += (p.quirks & 1u) ? (u64)p.n * p.ecap * p.snap_words : 0;
+  if (p.rarch_words) p.rarch_words = node_words_used(p);
+  p.off_rarch = (u32)w; w += (u64)p.n * p.ecap * p.rarch_words;
   p.off_sync = (u32)w; w += (p.quirks & 1u) ? p.bcap : 0;
   p.off_ring = (u32)w; w += 2ULL * p.ring;
   if (c0a) w = up(w, 32);

@@ -58,6 +58,8 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restr
 #define LBFT_RUN_WAVES 8
 #endif
 #define LBFT_RUN_BLOCK (64 * LBFT_RUN_WAVES)
+#define LBFT_RUN_WAVES_FULL 4  // the kernels that use the whole register file (lbft_k_run<1>, <2>): one wavefront per SIMD = 4 per workgroup
+                               // (a 512-thread launch bound would cap them at 256 registers)
 #define LBFT_LDS_HCBR_WORDS 32  // class 0, n <= 4: hcbr[node][2][4] per instance
 #ifndef LBFT_PACKED_QL_MAX
 #define LBFT_PACKED_QL_MAX 64  // LDS slots per instance of the packed (class 0) queue: the 4-node bench workload peaks at 53 pending events
@@ -71,14 +73,14 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restr
 // `slot_bytes`: 12 (key + meta) or 8 (packed one-word entries, kernel class 0)
 // (class 0 with a lane-major queue front, LBFT_C0_QLANE: LBFT_QLANE_PAD more words per lane)
 #define LBFT_QPAD(slot_bytes) ((slot_bytes) == 8 && LBFT_C0_QLANE ? LBFT_QLANE_PAD : 0u)
-static inline size_t run_lds_bytes(u32 ql, u32 lpw, u32 n, u32 slot_bytes) {
-  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * (ql + LBFT_QPAD(slot_bytes)) * lpw * slot_bytes + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8 + 8 +
-         (n > 16 ? (size_t)LBFT_RUN_WAVES * lpw * LBFT_MAX_NODES : 0) +
-         (n <= 4 && slot_bytes == 8 && !(LBFT_C0_IMAJOR && LBFT_C0_HCREG) ? (size_t)LBFT_RUN_WAVES * lpw * LBFT_LDS_HCBR_WORDS * 4 : 0);  // class 0, n <= 4: hcbr buffers
+static inline size_t run_lds_bytes(u32 ql, u32 lpw, u32 n, u32 slot_bytes, u32 nwaves) {
+  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)nwaves * (ql + LBFT_QPAD(slot_bytes)) * lpw * slot_bytes + (size_t)nwaves * LBFT_NPHASES * 8 + 8 +
+         (n > 16 ? (size_t)nwaves * lpw * LBFT_MAX_NODES : 0) +
+         (n <= 4 && slot_bytes == 8 && !(LBFT_C0_IMAJOR && LBFT_C0_HCREG) ? (size_t)nwaves * lpw * LBFT_LDS_HCBR_WORDS * 4 : 0);  // class 0, n <= 4: hcbr buffers
 }
 
-__device__ __forceinline__ size_t run_lds_bytes_dev(u32 ql, u32 lpw, u32 slot_bytes) {  // = run_lds_bytes(ql, lpw, 0, ..): where the receiver lists start
-  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)LBFT_RUN_WAVES * (ql + LBFT_QPAD(slot_bytes)) * lpw * slot_bytes + (size_t)LBFT_RUN_WAVES * LBFT_NPHASES * 8 + 8;
+__device__ __forceinline__ size_t run_lds_bytes_dev(u32 ql, u32 lpw, u32 slot_bytes, u32 nwaves) {  // = run_lds_bytes(ql, lpw, 0, ..): where the receiver lists start
+  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)nwaves * (ql + LBFT_QPAD(slot_bytes)) * lpw * slot_bytes + (size_t)nwaves * LBFT_NPHASES * 8 + 8;
 }
 #ifndef LBFT_RUN_WAVES_PER_SIMD
 #define LBFT_RUN_WAVES_PER_SIMD 2  // register budget of the class-0 run kernel: 512 / 2 = 256 VGPRs + AGPRs per lane (the
@@ -87,41 +89,42 @@ __device__ __forceinline__ size_t run_lds_bytes_dev(u32 ql, u32 lpw, u32 slot_by
 template <int CLS>
 __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ state, u32* __restrict__ unfinished) {
   extern __shared__ u64 lds[];
+  const u32 nwaves = blockDim.x >> 6;  // wavefronts per workgroup: 8 for the two-wavefronts-per-SIMD kernels, 4 for the full-register ones
   u64* t_zx = lds;
   u64* t_zf = lds + 257;
   u64* t_et = lds + 514;
-  for (u32 t = threadIdx.x; t < 257; t += LBFT_RUN_BLOCK) { t_zx[t] = p.zig_x[t]; t_zf[t] = p.zig_f[t]; }
-  for (u32 t = threadIdx.x; t < 256; t += LBFT_RUN_BLOCK) t_et[t] = p.exp_tab[t];
+  for (u32 t = threadIdx.x; t < 257; t += blockDim.x) { t_zx[t] = p.zig_x[t]; t_zf[t] = p.zig_f[t]; }
+  for (u32 t = threadIdx.x; t < 256; t += blockDim.x) t_et[t] = p.exp_tab[t];
   i64* t_dur = reinterpret_cast<i64*>(lds + 770);
   u8* t_leader = reinterpret_cast<u8*>(lds + 770 + LBFT_LDS_DURS);
   u32 n_dur = p.dur_len < LBFT_LDS_DURS ? p.dur_len : LBFT_LDS_DURS;
   u32 n_leader = p.leader_len < LBFT_LDS_LEADERS ? p.leader_len : LBFT_LDS_LEADERS;
-  for (u32 t = threadIdx.x; t < n_dur; t += LBFT_RUN_BLOCK) t_dur[t] = p.dur_tab[t];
-  for (u32 t = threadIdx.x; t < n_leader; t += LBFT_RUN_BLOCK) t_leader[t] = p.leader_tab[t];
+  for (u32 t = threadIdx.x; t < n_dur; t += blockDim.x) t_dur[t] = p.dur_tab[t];
+  for (u32 t = threadIdx.x; t < n_leader; t += blockDim.x) t_leader[t] = p.leader_tab[t];
   u32* t_weights = reinterpret_cast<u32*>(lds + 770 + LBFT_LDS_DURS + LBFT_LDS_LEADERS / 8);
-  for (u32 t = threadIdx.x; t < p.n; t += LBFT_RUN_BLOCK) t_weights[t] = p.weights[t];
+  for (u32 t = threadIdx.x; t < p.n; t += blockDim.x) t_weights[t] = p.weights[t];
   __syncthreads();
   u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const u32 qslots = p.ql + (SimT<CLS>::QLANE ? LBFT_QLANE_PAD : 0u);  // u64 words per instance in the key area
   u64* keys = SimT<CLS>::QLANE ? lds + LBFT_TABLE_U64 + ((size_t)wave * p.lpw + lane) * qslots : lds + LBFT_TABLE_U64 + (size_t)wave * p.ql * p.lpw + lane;
-  u32* metas = reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)LBFT_RUN_WAVES * qslots * p.lpw) + (size_t)wave * p.ql * p.lpw + lane;  // (CLS 0: unused, not allocated)
-  const u32 meta_words = CLS == 0 ? 0u : LBFT_RUN_WAVES * p.ql * p.lpw;
+  u32* metas = reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)nwaves * qslots * p.lpw) + (size_t)wave * p.ql * p.lpw + lane;  // (CLS 0: unused, not allocated)
+  const u32 meta_words = CLS == 0 ? 0u : nwaves * p.ql * p.lpw;
   // Only the first p.lpw lanes of a wavefront carry an instance (occupancy vs lane-utilisation knob).
-  u32 i = (blockIdx.x * LBFT_RUN_WAVES + wave) * p.lpw + lane;
+  u32 i = (blockIdx.x * nwaves + wave) * p.lpw + lane;
   bool active = lane < p.lpw && i < p.m;
   bool done = true;
   // lpw divides 64, so a wavefront's instances share one tile: its base is wavefront-uniform (SGPRs) and
   // every row access is saddr + 32-bit voffset
   // (tile width tw: 64 for the small-network classes -- two 32-lane wavefronts share a tile --, otherwise tw == lpw: one tile per wavefront)
   const u32 tw = SimT<CLS>::TILE64 ? 64u : SimT<CLS>::IMAJOR ? 1u : p.tw;
-  u32 tile_idx = __builtin_amdgcn_readfirstlane(((blockIdx.x * LBFT_RUN_WAVES + wave) * p.lpw) / tw);
+  u32 tile_idx = __builtin_amdgcn_readfirstlane(((blockIdx.x * nwaves + wave) * p.lpw) / tw);
   char* tile = reinterpret_cast<char*>(state) + (size_t)tile_idx * p.total_words * ((size_t)4 * tw);
   if constexpr (SimT<CLS>::COOP) {
     // Large networks: EVERY lane of the wavefront runs the event loop; the first lpw lanes carry a network each, all 64
     // cooperate on the bulk sends of those networks (SimT::run_coop / coop_bulk).
     // (tw may be narrower than the lanes that carry a network: lane j's instance then sits j / tw tiles behind the wavefront's
     // first tile -- folded into the lane's 32-bit column offset, the tile base stays wavefront-uniform)
-    const u32 li = active ? (i - ((blockIdx.x * LBFT_RUN_WAVES + wave) * p.lpw)) : (lane & (p.lpw - 1u));
+    const u32 li = active ? (i - ((blockIdx.x * nwaves + wave) * p.lpw)) : (lane & (p.lpw - 1u));
     SimT<CLS> s(p, tile, (li / tw) * (p.total_words * 4u * tw) + (li & (tw - 1u)) * 4u, 0);
     bool lead = false;
     if (active) lead = s.ld(I_DONE) == 0;
@@ -130,13 +133,13 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
     s.attach_round_tables(t_leader, n_leader, t_dur, n_dur);
     s.attach_weights(t_weights);
     if (lead) {
-      u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 12u);
+      u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 12u, nwaves);
       s.attach_peer_list(lists + ((size_t)wave * p.lpw + lane) * LBFT_MAX_NODES);
       s.load_scalars();
       s.queue_to_lds();
     }
 #if defined(LBFT_PHASE_TIMERS)
-    u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)LBFT_RUN_WAVES * qslots * p.lpw) +
+    u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)nwaves * qslots * p.lpw) +
                                         (size_t)meta_words + (meta_words & 1u)) + wave * LBFT_NPHASES;
     if (lane == 0) { for (int k = 0; k < LBFT_NPHASES; k++) wprof[k] = 0; wprof[31] = __builtin_readcyclecounter(); }
     s.wprof = wprof;
@@ -164,11 +167,11 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
       s.attach_round_tables(t_leader, n_leader, t_dur, n_dur);
       s.attach_weights(t_weights);
       if (p.n > 16) {  // receiver / sender lists of process_node_actions: LDS instead of HBM rows
-        u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, CLS == 0 ? 8u : 12u);
+        u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, CLS == 0 ? 8u : 12u, nwaves);
         s.attach_peer_list(lists + ((size_t)wave * p.lpw + lane) * LBFT_MAX_NODES);
       }
       if (CLS == 0 && p.n <= 4 && !SimT<CLS>::HCREG) {  // the nodes' hcbr buffers (same place as the receiver lists of large networks)
-        u32* hcb = reinterpret_cast<u32*>(reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 8u));
+        u32* hcb = reinterpret_cast<u32*>(reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 8u, nwaves));
         s.attach_hcbr(hcb + (size_t)wave * LBFT_LDS_HCBR_WORDS * p.lpw + lane);
       }
       s.load_scalars();
@@ -176,7 +179,7 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
       s.hcbr_to_lds();
 #if defined(LBFT_PHASE_TIMERS)
       // per-wavefront accumulators behind the queue columns (8-byte aligned: the meta area is a multiple of 8 words)
-      u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)LBFT_RUN_WAVES * qslots * p.lpw) +
+      u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)nwaves * qslots * p.lpw) +
                                           (size_t)meta_words + (meta_words & 1u)) + wave * LBFT_NPHASES;
       if (lane == 0) { for (int k = 0; k < LBFT_NPHASES; k++) wprof[k] = 0; wprof[31] = __builtin_readcyclecounter(); }
       s.wprof = wprof;
@@ -224,7 +227,7 @@ void lbft_k_run1l(Params p, u32* __restrict__ state, u32* __restrict__ unfinishe
                                    // 1.23 s instead of 1.01 s, 8192 x 100 nodes 7.0 s instead of 5.5 s)
 #endif
 template <int CLS>
-__global__ __launch_bounds__(LBFT_RUN_BLOCK)
+__global__ __launch_bounds__(64 * LBFT_RUN_WAVES_FULL)
 #if LBFT_BIG_WAVES_PER_SIMD > 1
 __attribute__((amdgpu_waves_per_eu(LBFT_BIG_WAVES_PER_SIMD, LBFT_BIG_WAVES_PER_SIMD)))
 #endif
@@ -478,8 +481,10 @@ struct lbft_batch {
   u32 lpw = 0;  // 0 = auto
   int ql = -1;  // LDS queue slots per instance; -1 = auto
   u32 rcap = 0; // round-switch trace capacity (rounds per node); 0 = off
+  bool keep_stores = false;  // lbft_batch_keep_retired_stores: the record store a node retires at an epoch change is archived in full
   unsigned long long* d_prof = nullptr;
   size_t lds_bytes = 0;
+  u32 run_waves = LBFT_RUN_WAVES;  // wavefronts per workgroup of the run kernel this batch uses (prepare_run)
   float init_ms = 0, run_ms = 0;
   lbft_counters counters;
   size_t table_bytes = 0;
@@ -787,6 +792,15 @@ int lbft_batch_enable_round_trace(lbft_batch* b, uint32_t max_rounds) {
   return LBFT_OK;
 }
 
+// past_record_stores (node.rs:43,338-340) kept in full on the device, so that lbft_batch_save_node also serves nodes that have changed
+// epoch.  Costs num_nodes x epochs x one node's rows of device memory per instance; off by default.
+int lbft_batch_keep_retired_stores(lbft_batch* b, int enable) {
+  if (!b) return LBFT_ERR_INVALID;
+  if (b->ran || b->manual || b->started) { g_err = "ask for the retired record stores before running the batch"; return LBFT_ERR_STATE; }
+  b->keep_stores = enable != 0;
+  return LBFT_OK;
+}
+
 // out[round * num_nodes + node] = GlobalTime at which `node` was first seen in `round` by the reference's DataWriter
 // (bft-lib/src/data_writer.rs:34-50), INT64_MIN = empty cell; rows for round < min(max_round, cap_rounds).
 int lbft_batch_round_switches(const lbft_batch* b, size_t inst, int64_t* out, size_t cap_rounds, uint64_t* max_round, uint64_t* messages) {
@@ -910,13 +924,14 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   bool class0 = n <= 16 && !qheap && !p.equiv && !b->rcap && !p.drop_ppm && !p.part_size && !(p.quirks & 1u);
   // epochs a node can go through are bounded by its commits: the archive of retired record stores (quirks bit 0) is exact
   u64 eauto = (u64)bcap / (c.commands_per_epoch ? c.commands_per_epoch : 1) + 2;
-  u32 ecap = (p.quirks & 1u) ? (u32)(eauto > 4096 ? 4096 : eauto) : 0;
+  u32 ecap = ((p.quirks & 1u) || b->keep_stores) ? (u32)(eauto > 4096 ? 4096 : eauto) : 0;
+  const u32 rarch = b->keep_stores ? 1u : 0u;  // (compute_layout turns the flag into the entry size)
   // (the calendar replaces the HEAP: a small network outside class 0 -- e.g. 4 nodes with an equivocator -- keeps the LDS-fronted
   // array; 65536 x 4 nodes with one equivocator each: 28.6 ms on the array, 43.6 ms on the HBM calendar)
   u32 qcal = (!class0 && big && !b->rcap && b->allow_calendar && max_clock <= LBFT_CAL_MAX_CLOCK) ? 1u : 0u;
   bool relayout = !(p.qcap == qcap && p.scap == scap && p.bcap == bcap && p.lcap == lcap && p.rcap == b->rcap && p.qcal == qcal && p.ecap == ecap &&
-                    p.max_clock == (i32)max_clock && b->d_state);
-  p.qcap = qcap; p.scap = scap; p.bcap = bcap; p.lcap = lcap; p.rcap = b->rcap; p.qcal = qcal; p.qheap = qheap; p.ecap = ecap;
+                    (p.rarch_words != 0) == (rarch != 0) && p.max_clock == (i32)max_clock && b->d_state);
+  p.qcap = qcap; p.scap = scap; p.bcap = bcap; p.lcap = lcap; p.rcap = b->rcap; p.qcal = qcal; p.qheap = qheap; p.ecap = ecap; p.rarch_words = rarch;
   p.max_clock = (i32)max_clock;
   p.max_steps = b->max_steps;
   // Cooperative large-network kernels (class 2 on the calendar queue): ring of pre-generated RNG draws per instance and how far
@@ -985,22 +1000,27 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
     p.rsh = 2;
     while ((4u << (p.rsh - 2)) < 4u * tw) p.rsh++;
   }
+  // wavefronts per workgroup of the kernel this batch runs on: 8 = both wavefront slots of a CU's four SIMDs for the kernels compiled
+  // for two wavefronts per SIMD, 4 for the full-register ones
+  const bool two_wave_kernel = sim_class(p) == 0 || (sim_lean(p) && lean2_allowed()) || (sim_lean1(p) && lean_allowed());
+  const u32 nwaves = two_wave_kernel ? LBFT_RUN_WAVES : LBFT_RUN_WAVES_FULL;
+  b->run_waves = nwaves;
   // LDS queue slots per instance: what one CU's LDS affords when it hosts 64/lpw workgroups
-  u32 wg_per_cu = (64 / lpw) * 4 / LBFT_RUN_WAVES;  // workgroups of LBFT_RUN_WAVES wavefronts that make up a CU's 256 instances
+  u32 wg_per_cu = (64 / lpw) * 4 / nwaves;  // workgroups that make up a CU's 256 instances
   if (wg_per_cu < 1) wg_per_cu = 1;
   if (wg_per_cu > 4) wg_per_cu = 4;
   size_t budget = (160u * 1024u) / wg_per_cu;
   // 2 KiB slack per workgroup: with less, two workgroups of 32-lane wavefronts do not become co-resident on a CU
   u32 slot_bytes = p.qpack ? 8u : 12u;  // kernel class 0 keeps one-word entries
-  u32 ql_auto = (u32)((budget - run_lds_bytes(0, lpw, n, slot_bytes) - 2048) / (slot_bytes * LBFT_RUN_WAVES * lpw));  // (run_lds_bytes(0, ..) includes the lane padding)
+  u32 ql_auto = (u32)((budget - run_lds_bytes(0, lpw, n, slot_bytes, nwaves) - 2048) / (slot_bytes * nwaves * lpw));  // (run_lds_bytes(0, ..) includes the lane padding)
   if (p.qpack && ql_auto > LBFT_PACKED_QL_MAX) ql_auto = LBFT_PACKED_QL_MAX;
   u32 ql = b->ql < 0 ? ql_auto : (u32)b->ql;
   if (ql > qcap) ql = qcap;
   if (p.qpack) ql &= ~(LBFT_POP_BATCH - 1u);  // scanned in batches of LBFT_POP_BATCH
   if (p.qcal) ql = 0;  // the calendar lives in HBM rows
-  if (run_lds_bytes(ql, lpw, n, slot_bytes) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
+  if (run_lds_bytes(ql, lpw, n, slot_bytes, nwaves) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
   p.ql = ql;
-  b->lds_bytes = run_lds_bytes(ql, lpw, n, slot_bytes);
+  b->lds_bytes = run_lds_bytes(ql, lpw, n, slot_bytes, nwaves);
   p.prof = b->d_prof;
   return LBFT_OK;
 }
@@ -1043,14 +1063,15 @@ static int launch_run(lbft_batch* b) {
   const void* run_fn = leanq ? reinterpret_cast<const void*>(lbft_k_run2q) : lean ? reinterpret_cast<const void*>(lbft_k_run2l) : lean1 ? reinterpret_cast<const void*>(lbft_k_run1l) : cls == 0 ? reinterpret_cast<const void*>(lbft_k_run0)
                      : cls == 1 ? reinterpret_cast<const void*>(lbft_k_run<1>) : reinterpret_cast<const void*>(lbft_k_run<2>);
   HIP_TRY(hipFuncSetAttribute(run_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
-  u32 grid_run = (u32)((b->m + (size_t)LBFT_RUN_WAVES * p.lpw - 1) / ((size_t)LBFT_RUN_WAVES * p.lpw));
+  const u32 nwaves = b->run_waves, block = 64u * nwaves;
+  u32 grid_run = (u32)((b->m + (size_t)nwaves * p.lpw - 1) / ((size_t)nwaves * p.lpw));
   HIP_TRY(hipMemsetAsync(b->d_unfinished, 0, sizeof(u32), b->stream));
-  if (leanq) lbft_k_run2q<<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
-  else if (lean) lbft_k_run2l<<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
-  else if (lean1) lbft_k_run1l<<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
-  else if (cls == 0) lbft_k_run0<<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
-  else if (cls == 1) lbft_k_run<1><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
-  else lbft_k_run<2><<<grid_run, LBFT_RUN_BLOCK, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  if (leanq) lbft_k_run2q<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  else if (lean) lbft_k_run2l<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  else if (lean1) lbft_k_run1l<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  else if (cls == 0) lbft_k_run0<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  else if (cls == 1) lbft_k_run<1><<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  else lbft_k_run<2><<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   HIP_TRY(hipGetLastError());
   return LBFT_OK;
 }
@@ -1323,14 +1344,18 @@ int lbft_batch_save_node(const lbft_batch* b, size_t inst, uint32_t node, void* 
   const Params& dp = b->p;
   // this instance's rows, contiguous on the host (a tile of width 1)
   std::vector<u32> hw(dp.total_words);
-  HIP_TRY(hipMemcpy2D(hw.data(), sizeof(u32), b->d_state + word_offset(dp, (u32)inst, 0), (size_t)4 * dp.tw, sizeof(u32), dp.total_words,
-                      hipMemcpyDeviceToHost));
+  if (dp.tw == 1)  // instance-major rows: one contiguous copy
+    HIP_TRY(hipMemcpy(hw.data(), b->d_state + word_offset(dp, (u32)inst, 0), (size_t)4 * dp.total_words, hipMemcpyDeviceToHost));
+  else
+    HIP_TRY(hipMemcpy2D(hw.data(), sizeof(u32), b->d_state + word_offset(dp, (u32)inst, 0), (size_t)4 * dp.tw, sizeof(u32), dp.total_words,
+                        hipMemcpyDeviceToHost));
   std::vector<uint8_t> image;
   std::string err;
   int rc = build_node_image(dp, hw.data(), node, b->weights.data(), b->cfg.delta, b->cfg.gamma, b->cfg.lambda, b->cfg.target_commit_interval, image, err);
   if (rc != 0) { g_err = err; return LBFT_ERR_UNSUPPORTED; }
   *len = image.size();
-  if (buf && cap >= image.size()) memcpy(buf, image.data(), image.size());
+  if (buf && cap < image.size()) { g_err = "save_node: the buffer is smaller than the image (*len holds the size needed)"; return LBFT_ERR_INVALID; }
+  if (buf) memcpy(buf, image.data(), image.size());
   return LBFT_OK;
 }
 

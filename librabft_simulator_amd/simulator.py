@@ -243,7 +243,7 @@ class BatchSimulator:
     def __init__(self, rng_seeds, num_nodes, network_delay, node_config=None, commands_per_epoch=30000,
                  voting_rights=None, device=0, queue_capacity=0, snapshot_capacity=0, block_capacity=0,
                  log_capacity=0, max_steps_per_launch=0, lanes_per_wavefront=0, lds_queue_slots=-1, equivocate_every=0, drop_per_million=0, partition=None,
-                 calendar_queue=True, quirks=0, rights_rotation=0):
+                 calendar_queue=True, quirks=0, rights_rotation=0, keep_retired_stores=False):
         seeds = np.ascontiguousarray(rng_seeds, dtype=np.uint64)
         self.seeds = seeds
         self.num_instances = int(seeds.shape[0])
@@ -263,6 +263,8 @@ class BatchSimulator:
             check(_lib.lib().lbft_batch_set_calendar_queue(self._h, 0))
         if lds_queue_slots != -1:
             check(_lib.lib().lbft_batch_set_lds_queue_slots(self._h, lds_queue_slots))
+        if keep_retired_stores:  # past_record_stores (node.rs:43) in full: save_node then also serves nodes that have changed epoch
+            check(_lib.lib().lbft_batch_keep_retired_stores(self._h, 1))
 
     @classmethod
     def new(cls, rng_seeds, num_nodes, network_delay, node_config=None, **kw):

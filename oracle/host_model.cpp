@@ -39,6 +39,7 @@ typedef struct lbft_hostmodel_caps {
   uint32_t ring;           // > 0 (class 2 + calendar): the cooperative event loop (run_coop / coop_bulk, 64 emulated lanes) with a ring of this many pre-generated draws
   uint32_t ring_topup;     // draws the generator runs ahead per step
   uint32_t tw;             // tile width of the state layout (0 = 64; the device uses the lanes per wavefront outside kernel class 0)
+  uint32_t keep_stores;    // lbft_batch_keep_retired_stores: the retired record stores are archived in full
 } lbft_hostmodel_caps;
 
 // Same outputs as lbft_oracle_run_batch, plus per-instance fault words and max queue/snapshot use.
@@ -70,6 +71,7 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
     if (p.ecap < 64) p.ecap = 64;
   }
   p.qcal = caps->qcal;
+  p.rarch_words = caps->keep_stores ? 1u : 0u;  // (compute_layout turns the flag into the entry size)
   p.ring = (caps->qcal && p.n > 32) ? caps->ring : 0; p.ring_topup = p.ring ? caps->ring_topup : 0;
   if (p.ring & (p.ring - 1)) return -12;
   if (p.qcal) { if (max_clock > LBFT_CAL_MAX_CLOCK || p.rcap) return -11; p.qheap = 1; p.ql = 0; }

@@ -364,7 +364,7 @@ def leader(num_nodes, rnd, weights=None):
 # Host build of the kernel logic (oracle/host_model.cpp) -- CPU-only differential testing.
 # ----------------------------------------------------------------------------------------------
 class HostModelCaps(C.Structure):
-    _fields_ = [("qcap", C.c_uint32), ("scap", C.c_uint32), ("bcap", C.c_uint32), ("lcap", C.c_uint32), ("ql", C.c_uint32), ("qheap", C.c_uint32), ("force_generic", C.c_uint32), ("rcap", C.c_uint32), ("qcal", C.c_uint32), ("ring", C.c_uint32), ("ring_topup", C.c_uint32), ("tw", C.c_uint32)]
+    _fields_ = [("qcap", C.c_uint32), ("scap", C.c_uint32), ("bcap", C.c_uint32), ("lcap", C.c_uint32), ("ql", C.c_uint32), ("qheap", C.c_uint32), ("force_generic", C.c_uint32), ("rcap", C.c_uint32), ("qcal", C.c_uint32), ("ring", C.c_uint32), ("ring_topup", C.c_uint32), ("tw", C.c_uint32), ("keep_stores", C.c_uint32)]
 
 
 _hm = None
@@ -408,10 +408,10 @@ def hostmodel_node_images(cfg, seed, max_clock, **caps):
 
 
 def hostmodel_run_batch(cfg, seeds, max_clock, threads=1, history_cap=0, qcap=256, scap=128, bcap=256, lcap=256, ql=0, qheap=0, force_generic=0, rcap=0, qcal=0,
-                        hash_cap=0, ring=0, ring_topup=0, tw=0):
+                        hash_cap=0, ring=0, ring_topup=0, tw=0, keep_stores=0):
     seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
     m, nn = len(seeds), cfg.num_nodes
-    caps = HostModelCaps(qcap, scap, bcap, lcap, ql, qheap, force_generic, rcap, qcal, ring, ring_topup, tw)
+    caps = HostModelCaps(qcap, scap, bcap, lcap, ql, qheap, force_generic, rcap, qcal, ring, ring_topup, tw, keep_stores)
     rs = np.zeros((m, max(rcap, 1), nn), dtype=np.int64)
     mr = np.zeros(m, dtype=np.uint32)
     commit_counts = np.zeros((m, nn), dtype=np.uint32)

@@ -97,3 +97,99 @@ def node_state(data):
     n["past_record_stores"] = r.seq(lambda: (r.u64(), record_store(r)))
     assert r.o == len(data), (r.o, len(data))
     return n
+
+
+# ---- the inverse: dict -> bytes (save -> load -> save round trip, librabft-v2/src/unit_tests/node_tests.rs:17-21) ----
+class Writer:
+    def __init__(self):
+        self.b = bytearray()
+
+    def u64(self, v):
+        self.b += struct.pack("<Q", v)
+
+    def i64(self, v):
+        self.b += struct.pack("<q", v)
+
+    def u32(self, v):
+        self.b += struct.pack("<I", v)
+
+    def f64(self, v):
+        self.b += struct.pack("<d", v)
+
+    def opt(self, v, f):
+        self.b.append(0 if v is None else 1)
+        if v is not None:
+            f(v)
+
+    def seq(self, items, f):
+        self.u64(len(items))
+        for it in items:
+            f(it)
+
+
+def _w_signature(w, s):
+    w.u64(s[0]); w.u64(s[1])
+
+
+def _w_block(w, b):
+    w.u64(b["command"][0]); w.u64(b["command"][1]); w.i64(b["time"]); w.u64(b["previous_quorum_certificate_hash"]); w.u64(b["round"]); w.u64(b["author"])
+    _w_signature(w, b["signature"])
+
+
+def _w_vote(w, v):
+    w.u64(v["epoch_id"]); w.u64(v["round"]); w.u64(v["certified_block_hash"]); w.u64(v["state"]); w.opt(v["committed_state"], w.u64); w.u64(v["author"])
+    _w_signature(w, v["signature"])
+
+
+def _w_qc(w, q):
+    w.u64(q["epoch_id"]); w.u64(q["round"]); w.u64(q["certified_block_hash"]); w.u64(q["state"]); w.opt(q["committed_state"], w.u64)
+    w.seq(q["votes"], lambda v: (w.u64(v[0]), _w_signature(w, v[1])))
+    w.u64(q["author"])
+    _w_signature(w, q["signature"])
+
+
+def _w_timeout(w, t):
+    w.u64(t["epoch_id"]); w.u64(t["round"]); w.u64(t["highest_certified_block_round"]); w.u64(t["author"])
+    _w_signature(w, t["signature"])
+
+
+def _w_record_store(w, s):
+    w.u64(s["epoch_id"])
+    c = s["configuration"]
+    w.seq(c["authors"], lambda p: (w.u64(p[0]), w.u64(p[1])))
+    w.seq(c["voting_rights"], lambda p: (w.u64(p[0]), w.u64(p[1])))
+    w.u64(c["total_votes"])
+    w.u64(s["initial_hash"]); w.u64(s["initial_state"])
+    w.seq(s["blocks"], lambda kv: (w.u64(kv[0]), _w_block(w, kv[1])))
+    w.seq(s["quorum_certificates"], lambda kv: (w.u64(kv[0]), _w_qc(w, kv[1])))
+    w.opt(s["current_proposed_block"], w.u64)
+    for k in ("highest_quorum_certificate_round", "highest_quorum_certificate_hash", "highest_timeout_certificate_round", "current_round",
+              "highest_committed_round"):
+        w.u64(s[k])
+    w.opt(s["highest_commit_certificate_hash"], w.u64)
+    w.opt(s["highest_timeout_certificate"], lambda tc: w.seq(tc, lambda t: _w_timeout(w, t)))
+    w.seq(s["current_timeouts"], lambda kv: (w.u64(kv[0]), _w_timeout(w, kv[1])))
+    w.seq(s["current_votes"], lambda kv: (w.u64(kv[0]), _w_vote(w, kv[1])))
+    w.u64(s["current_timeouts_weight"])
+    e = s["current_election"]
+    if e[0] == "Ongoing":
+        w.u32(0)
+        w.seq(e[1], lambda en: (w.u64(en[0][0]), w.u64(en[0][1]), w.u64(en[1])))
+    elif e[0] == "Won":
+        w.u32(1); w.u64(e[1]); w.u64(e[2])
+    else:
+        w.u32(2)
+
+
+def dump_node_state(n):
+    """dict (as node_state returns it) -> the bincode image."""
+    w = Writer()
+    _w_record_store(w, n["record_store"])
+    p = n["pacemaker"]
+    w.u64(p["active_epoch"]); w.u64(p["active_round"]); w.opt(p["active_leader"], w.u64); w.i64(p["active_round_start_time"])
+    w.i64(p["active_round_duration"]); w.i64(p["delta"]); w.f64(p["gamma"]); w.f64(p["lambda_"])
+    w.u64(n["epoch_id"]); w.u64(n["latest_voted_round"]); w.u64(n["locked_round"]); w.i64(n["latest_query_all_time"])
+    t = n["tracker"]
+    w.u64(t["epoch_id"]); w.u64(t["highest_committed_round"]); w.i64(t["latest_commit_time"]); w.i64(t["target_commit_interval"])
+    w.seq(n["past_record_stores"], lambda kv: (w.u64(kv[0]), _w_record_store(w, kv[1])))
+    return bytes(w.b)

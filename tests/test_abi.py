@@ -118,18 +118,22 @@ def test_run_kernels_keep_their_state_in_registers(hiplib):
     # (round 3, instance-major rows: the wide node / snapshot loads need register tuples, and ~46 loop-INVARIANT values -- kernel
     # arguments, LDS bases -- are parked in scratch before the loop and reloaded after it: 188 bytes, two reloads inside the loop on
     # the rare propose path; the whole per-lane state in scratch would be > 600 bytes)
-    assert run0[0]["private_segment_fixed_size"] <= 256 and run0[0]["vgpr_spill_count"] <= 64, run0
+    # (+ ~25 more since the retired record stores can be archived, SimT::retire_store: parked loop-invariants again -- measured
+    # 21.80 ms with it, 21.88 ms compiled out)
+    assert run0[0]["private_segment_fixed_size"] <= 384 and run0[0]["vgpr_spill_count"] <= 96, run0
     assert run0[0]["vgpr_count"] <= 256, run0
     big = [v for k, v in kernels.items() if "lbft_k_runILi" in k]
     assert len(big) == 2, sorted(kernels)
     for v in big:  # large-network classes: a handful of spilled registers at most, never the whole state
         assert v["private_segment_fixed_size"] <= 128, big
     lean = [v for k, v in kernels.items() if "lbft_k_run1l" in k]  # class 1 without record exchange / trace / loss: two wavefronts per SIMD as well
-    assert len(lean) == 1 and all(v["vgpr_count"] <= 256 and v["private_segment_fixed_size"] <= 128 for v in lean), lean
+    assert len(lean) == 1 and all(v["vgpr_count"] <= 256 and v["private_segment_fixed_size"] <= 160 for v in lean), lean
     # large networks, two wavefronts per SIMD: without (run2l) and with (run2q) the record exchange of quirks bit 0.  They only pay while the
     # trimmed loop keeps its state in registers: 4 / 24 spilled registers as built; 118 (staged sets) and 325 (a second inlined copy of
     # update_node's tail inside handle_response) were slower than one wavefront per SIMD
-    for name, cap in (("lbft_k_run2l", 16), ("lbft_k_run2q", 48)):
+    # (round 3: 38 / 70 with SimT::retire_store compiled in -- values parked around the loop: 362 vs 365 ms and 3.03 vs 2.98 s against the
+    # build without it)
+    for name, cap in (("lbft_k_run2l", 56), ("lbft_k_run2q", 96)):
         lean2 = [v for k, v in kernels.items() if name in k]
         assert len(lean2) == 1 and lean2[0]["vgpr_count"] <= 256 and lean2[0]["vgpr_spill_count"] <= cap, (name, lean2)
 

@@ -86,11 +86,78 @@ def test_device_image_equals_oracle_image(oracle, name):
             assert a == b, (name, t, node)
 
 
+# Nodes that have changed epoch carry their retired record stores (past_record_stores, node.rs:43,233-238,331-348): c5live-shaped runs.
+EPOCH_CASES = {
+    "n4_q3_cpe5": (dict(num_nodes=4, commands_per_epoch=5, quirks=3), 5, (400, 1000)),
+    "n4_reference_quirks_stall_cpe50": (dict(num_nodes=4, commands_per_epoch=50), 3, (3000,)),                    # epochs [1, 1, 0, 0] for ever
+    "n7_rotating_rights_q3_cpe3": (dict(num_nodes=7, voting_rights=[2, 1, 1, 3, 1, 2, 1], commands_per_epoch=3, quirks=3, rights_rotation=1), 11, (700,)),
+    "n1_cpe2": (dict(num_nodes=1, commands_per_epoch=2), 1, (0, 30, 200)),                                        # node_tests.rs:11-15's context
+    "n40_weighted_rotating_q3_cpe3": (dict(num_nodes=40, voting_rights=[1 + (i % 4) for i in range(40)], commands_per_epoch=3, quirks=3, rights_rotation=1), 7, (450,)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(EPOCH_CASES))
+def test_image_builder_serves_nodes_that_changed_epoch(oracle, name):
+    """Host model rows (retired stores archived: keep_stores) -> csrc/lbft_save_node.h == the oracle's image incl. every past record store."""
+    kw, seed, horizons = EPOCH_CASES[name]
+    cfg = oracle.make_config(math_mode=1, **kw)
+    n = kw["num_nodes"]
+    for t in horizons:
+        sim = oracle.OracleSim(cfg, seed).run_until(t)
+        caps = dict(qcap=max(4096, 8 * n * n), scap=(n * n + 8 * n + 64), bcap=1024, lcap=1024, ql=0, qheap=1 if n > 16 else 0, qcal=1 if n > 32 else 0,
+                    ring=256 if n > 32 else 0, tw=8 if n > 32 else 0, keep_stores=1)
+        images = oracle.hostmodel_node_images(cfg, seed, t, **caps)
+        epochs = []
+        for node in range(n):
+            a, b = sim.save_node(node), images[node]
+            assert b is not None
+            if a != b:
+                assert node_state(b) == node_state(a), (name, t, node)
+            assert a == b, (name, t, node)
+            ns = node_state(a)
+            assert [e for e, _ in ns["past_record_stores"]] == list(range(ns["epoch_id"]))  # one retired store per epoch left, ascending
+            epochs.append(ns["epoch_id"])
+        if t >= 400:
+            assert max(epochs) >= 1, (name, t, epochs)
+
+
 @pytest.mark.gpu
-def test_device_refuses_nodes_that_changed_epoch():
+@pytest.mark.parametrize("name", sorted(EPOCH_CASES))
+def test_device_image_of_nodes_that_changed_epoch_equals_oracle_image(oracle, name):
+    """lbft_batch_keep_retired_stores + lbft_batch_save_node == the oracle, byte for byte, after epoch changes (replaces round 2's
+    test_device_refuses_nodes_that_changed_epoch)."""
     import librabft_simulator_amd as amd
+    kw, seed, horizons = EPOCH_CASES[name]
+    cfg = oracle.make_config(math_mode=1, **kw)
+    kwd = dict(kw)
+    n = kwd.pop("num_nodes")
+    for t in horizons:
+        sim = oracle.OracleSim(cfg, seed).run_until(t)
+        res = amd.BatchSimulator.new(np.array([seed + 1, seed], dtype=np.uint64), n, amd.RandomDelay.new(10.0, 4.0), keep_retired_stores=True, **kwd).loop_until(t)
+        for node in range(n):
+            a, b = sim.save_node(node), res.save_node(1, node)
+            if a != b:
+                assert node_state(b) == node_state(a), (name, t, node)
+            assert a == b, (name, t, node)
+        # the archive changes nothing else: same logs as a batch without it
+        plain = amd.BatchSimulator.new(np.array([seed + 1, seed], dtype=np.uint64), n, amd.RandomDelay.new(10.0, 4.0), **kwd).loop_until(t)
+        assert (plain.commit_counts == res.commit_counts).all() and (plain.last_committed_states == res.last_committed_states).all()
+
+
+@pytest.mark.gpu
+def test_device_without_the_archive_refuses_nodes_that_changed_epoch():
+    """Off by default (it costs num_nodes x epochs x a node's rows of device memory per instance): then a node past its first epoch
+    change is refused with LBFT_ERR_UNSUPPORTED, never served a wrong image; a too small buffer is LBFT_ERR_INVALID (round-2 advisor)."""
+    import ctypes
+    import librabft_simulator_amd as amd
+    from librabft_simulator_amd import _lib
     res = amd.BatchSimulator.new(np.array([5], dtype=np.uint64), 4, amd.RandomDelay.new(10.0, 4.0), commands_per_epoch=5, quirks=3).loop_until(1000)
     assert res.epochs.min() >= 1
     with pytest.raises(amd.LbftError) as e:
         res.save_node(0, 0)
     assert e.value.code == -3
+    res0 = amd.BatchSimulator.new(np.array([5], dtype=np.uint64), 4, amd.RandomDelay.new(10.0, 4.0)).loop_until(300)
+    ln = ctypes.c_size_t(0)
+    small = np.zeros(16, dtype=np.uint8)
+    rc = _lib.lib().lbft_batch_save_node(res0._sim._h, 0, 0, small.ctypes.data, small.size, ctypes.byref(ln))
+    assert rc == -1 and ln.value > 16  # LBFT_ERR_INVALID, *len = the size needed
