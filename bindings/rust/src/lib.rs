@@ -70,6 +70,45 @@ pub struct LbftActions {
     pub should_query_all: u32,
 }
 
+/// `lbft_node_call` / `lbft_node_result` (include/lbft.h): one entry of a batch of trait calls
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct LbftNodeCall {
+    pub op: u32,
+    pub instance: u32,
+    pub node: u32,
+    pub peer: u32,
+    pub handle: u32,
+    pub reserved: u32,
+    pub node_time: i64,
+}
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct LbftNodeResult {
+    pub actions: LbftActions,
+    pub handle: u32,
+    pub should_sync: u32,
+    pub status: i32,
+    pub reserved: u32,
+}
+/// `lbft_counters` (include/lbft.h)
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct LbftCounters {
+    pub events: [u64; 4],
+    pub rng_draws: u64,
+    pub rounds: u64,
+    pub commits: u64,
+    pub events_scheduled: u64,
+    pub faulted_instances: u64,
+    pub max_queue: u64,
+    pub max_snapshots: u64,
+    pub max_blocks: u64,
+    pub launches: u64,
+    pub timers_folded: u64,
+    pub node_updates: u64,
+}
+
 pub const LBFT_OK: c_int = 0;
 pub const LBFT_ERR_FAULT: c_int = -5;
 
@@ -78,6 +117,10 @@ extern "C" {
     fn lbft_batch_create(cfg: *const LbftConfig, seeds: *const u64, n: usize, device: c_int, out: *mut *mut c_void) -> c_int;
     fn lbft_batch_run_until(b: *mut c_void, max_clock: i64) -> c_int;
     fn lbft_batch_save_node(b: *const c_void, inst: usize, node: u32, buf: *mut c_void, cap: usize, len: *mut usize) -> c_int;
+    /// many trait calls (each on another instance) in one launch + one synchronisation: see include/lbft.h `lbft_node_calls`
+    pub fn lbft_node_calls(b: *mut c_void, calls: *const LbftNodeCall, n: usize, results: *mut LbftNodeResult) -> c_int;
+    /// the run's one collective, natively: ncclAllReduce of the throughput counters on the caller's ncclComm_t
+    pub fn lbft_batch_counters_allreduce(b: *mut c_void, nccl_comm: *mut c_void, out: *mut LbftCounters) -> c_int;
     /// past_record_stores (node.rs:43) kept in full on the device: save_node then also serves nodes that have changed epoch
     pub fn lbft_batch_keep_retired_stores(b: *mut c_void, enable: c_int) -> c_int;
     fn lbft_batch_commit_counts(b: *const c_void, out: *mut u32) -> c_int;

@@ -171,6 +171,12 @@ int lbft_batch_last_committed_states(const lbft_batch* b, uint64_t* out);
  * (past_record_stores, node.rs:43,338-340): the device keeps them in full only when lbft_batch_keep_retired_stores(b, 1) was called
  * before the run; otherwise such a node is LBFT_ERR_UNSUPPORTED (nodes still in epoch 0 always work). */
 int lbft_batch_save_node(const lbft_batch* b, size_t inst, uint32_t node, void* buf, size_t cap, size_t* len);
+/* Multi-GPU: instances shard over the GPUs with no data-path collective; the run's ONE collective aggregates the
+ * throughput counters of all ranks: a RCCL ncclAllReduce(ncclSum) over xGMI of the eleven additive counters of lbft_batch_counters
+ * (followed by a three-word ncclMax for the high-water marks).  `nccl_comm` is the caller's ncclComm_t for this batch's device (any
+ * host language: the library loads librccl itself, on first use); the collective runs on the batch's stream.  `out` receives the
+ * aggregate; launches is this rank's.  Every rank of the communicator must call it. */
+int lbft_batch_counters_allreduce(lbft_batch* b, void* nccl_comm, lbft_counters* out);
 /* past_record_stores kept in full: at every epoch change the node's rows (record-store fields, timeouts, votes, election) are copied
  * into an archive entry of the epoch being left -- num_nodes x epochs x one node's rows of device memory per instance.  Call before
  * the batch runs.  Off by default: a run's results never depend on it. */
@@ -280,6 +286,37 @@ int lbft_node_create_request(lbft_batch* b, size_t inst, uint32_t node, uint32_t
 int lbft_node_handle_request(lbft_batch* b, size_t inst, uint32_t node, uint32_t request, uint32_t* response);
 int lbft_node_handle_response(lbft_batch* b, size_t inst, uint32_t node, uint32_t peer, uint32_t response, int64_t node_time);
 int lbft_node_view_get(lbft_batch* b, size_t inst, uint32_t node, lbft_node_view* out);
+
+/* The same trait calls for many instances at once: ONE kernel launch and ONE synchronisation for the whole array instead of one per
+ * call (a host driving thousands of simulators through ConsensusNode / DataSyncNode is otherwise launch-bound).  Every call of a
+ * batch must address a different instance -- calls on one instance are ordered by the protocol and belong in successive batches
+ * (LBFT_ERR_INVALID otherwise).  results[k] belongs to calls[k]; a call that found no free snapshot slot has results[k].status =
+ * LBFT_ERR_FAULT (and the function returns LBFT_ERR_FAULT; the other results are valid).  Request / response calls need the
+ * record-exchange layout (quirks bit 0): in reference mode they are host-side tokens (see above), use the single calls. */
+#define LBFT_CALL_UPDATE_NODE 0          /* ConsensusNode::update_node(node_time) on `node`                    -> actions */
+#define LBFT_CALL_CREATE_NOTIFICATION 1  /* DataSyncNode::create_notification on `node`                        -> handle */
+#define LBFT_CALL_HANDLE_NOTIFICATION 2  /* handle_notification(handle) from `peer` on `node`                  -> should_sync */
+#define LBFT_CALL_RELEASE_NOTIFICATION 3 /* drop one reference of `handle` (notification, request or response) */
+#define LBFT_CALL_CREATE_REQUEST 4       /* DataSyncNode::create_request on `node`                              -> handle */
+#define LBFT_CALL_HANDLE_REQUEST 5       /* handle_request(handle) on `node` (the peer that answers)            -> handle (the response) */
+#define LBFT_CALL_HANDLE_RESPONSE 6      /* handle_response(handle, node_time) from `peer` on `node` */
+typedef struct lbft_node_call {
+  uint32_t op;       /* LBFT_CALL_* */
+  uint32_t instance; /* at most one call per instance and batch */
+  uint32_t node;
+  uint32_t peer;
+  uint32_t handle;
+  uint32_t reserved;
+  int64_t node_time;
+} lbft_node_call;
+typedef struct lbft_node_result {
+  lbft_actions actions; /* LBFT_CALL_UPDATE_NODE */
+  uint32_t handle;      /* create_notification / create_request / handle_request */
+  uint32_t should_sync; /* handle_notification */
+  int32_t status;       /* LBFT_OK or LBFT_ERR_FAULT */
+  uint32_t reserved;
+} lbft_node_result;
+int lbft_node_calls(lbft_batch* b, const lbft_node_call* calls, size_t n, lbft_node_result* results);
 
 /* Stand-alone device checks of the third-party arithmetic (tests): each runs a tiny kernel.
  *   leaders: out[r] = PacemakerState::leader(round r) (pacemaker.rs:100-109) for r < n_rounds

@@ -85,6 +85,19 @@ class LbftActions(C.Structure):
                 "should_broadcast": bool(self.should_broadcast), "should_query_all": bool(self.should_query_all)}
 
 
+class LbftNodeCall(C.Structure):
+    """lbft_node_call: one trait call of a batch of calls (lbft_node_calls)."""
+    _fields_ = [("op", C.c_uint32), ("instance", C.c_uint32), ("node", C.c_uint32), ("peer", C.c_uint32), ("handle", C.c_uint32),
+                ("reserved", C.c_uint32), ("node_time", C.c_int64)]
+
+
+class LbftNodeResult(C.Structure):
+    _fields_ = [("actions", LbftActions), ("handle", C.c_uint32), ("should_sync", C.c_uint32), ("status", C.c_int32), ("reserved", C.c_uint32)]
+
+
+CALL_UPDATE_NODE, CALL_CREATE_NOTIFICATION, CALL_HANDLE_NOTIFICATION, CALL_RELEASE_NOTIFICATION, CALL_CREATE_REQUEST, CALL_HANDLE_REQUEST, CALL_HANDLE_RESPONSE = range(7)
+
+
 class LbftNodeView(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("epoch_id", "current_round", "highest_quorum_certificate_round",
                                            "highest_timeout_certificate_round", "highest_committed_round", "active_round",
@@ -108,7 +121,7 @@ ABI_SYMBOLS = [
     "lbft_batch_device_bytes", "lbft_batch_set_max_steps", "lbft_batch_set_lanes_per_wavefront",
     "lbft_batch_set_lds_queue_slots", "lbft_batch_set_calendar_queue", "lbft_batch_phase_cycles", "lbft_batch_layout",
     "lbft_batch_run_steps", "lbft_batch_checkpoint_bytes", "lbft_batch_checkpoint_save", "lbft_batch_checkpoint_load",
-    "lbft_batch_enable_round_trace", "lbft_batch_keep_retired_stores", "lbft_batch_round_switches", "lbft_batch_manual_begin", "lbft_batch_manual_finalize", "lbft_node_update", "lbft_node_create_notification",
+    "lbft_batch_enable_round_trace", "lbft_batch_keep_retired_stores", "lbft_batch_counters_allreduce", "lbft_node_calls", "lbft_batch_round_switches", "lbft_batch_manual_begin", "lbft_batch_manual_finalize", "lbft_node_update", "lbft_node_create_notification",
     "lbft_node_handle_notification", "lbft_node_release_notification", "lbft_node_create_request", "lbft_node_handle_request",
     "lbft_node_handle_response", "lbft_node_view_get", "lbft_device_leaders", "lbft_device_sample_delays",
     "lbft_device_exp_log", "lbft_last_error", "lbft_build_info",
@@ -178,6 +191,10 @@ def lib():
     L.lbft_batch_checkpoint_save.restype = C.c_int
     L.lbft_batch_checkpoint_load.argtypes = [vp, vp, C.c_size_t]
     L.lbft_batch_checkpoint_load.restype = C.c_int
+    L.lbft_node_calls.argtypes = [vp, C.POINTER(LbftNodeCall), C.c_size_t, C.POINTER(LbftNodeResult)]
+    L.lbft_node_calls.restype = C.c_int
+    L.lbft_batch_counters_allreduce.argtypes = [vp, vp, C.POINTER(LbftCounters)]
+    L.lbft_batch_counters_allreduce.restype = C.c_int
     L.lbft_batch_keep_retired_stores.argtypes = [vp, C.c_int]
     L.lbft_batch_keep_retired_stores.restype = C.c_int
     L.lbft_batch_enable_round_trace.argtypes = [vp, C.c_uint32]

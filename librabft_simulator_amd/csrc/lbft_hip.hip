@@ -7,6 +7,8 @@
 // No CPU fallback exists: every entry point fails with LBFT_ERR_HIP if the device is unusable.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -333,9 +335,8 @@ __global__ void lbft_k_export_histories(Params p, const u32* __restrict__ state,
 // Node-level interface (include/lbft.h lbft_node_*): one lane applies one trait call to one node.
 enum NodeOp : u32 { OP_UPDATE = 0, OP_CREATE_NOTIFICATION, OP_HANDLE_NOTIFICATION, OP_RELEASE_NOTIFICATION, OP_VIEW,
                     OP_CREATE_REQUEST, OP_HANDLE_REQUEST, OP_HANDLE_RESPONSE };
-__global__ void lbft_k_node_op(Params p, u32* __restrict__ state, u32 op, u32 inst, u32 node, u32 arg0, u32 arg1, i64 node_time,
-                               unsigned long long* __restrict__ out) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+__device__ __forceinline__ void node_op_body(const Params& p, u32* __restrict__ state, u32 op, u32 inst, u32 node, u32 arg0, u32 arg1, i64 node_time,
+                                             unsigned long long* __restrict__ out) {
   Sim s(p, state, inst);
   s.load_scalars();
   if (op == OP_UPDATE) {
@@ -399,6 +400,20 @@ __global__ void lbft_k_node_op(Params p, u32* __restrict__ state, u32 op, u32 in
     out[14] = s.nf(node, NF_HTC_ROUND) ? 1 : 0;
   }
   s.store_scalars(s.ld(I_DONE) != 0);
+}
+__global__ void lbft_k_node_op(Params p, u32* __restrict__ state, u32 op, u32 inst, u32 node, u32 arg0, u32 arg1, i64 node_time,
+                               unsigned long long* __restrict__ out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  node_op_body(p, state, op, inst, node, arg0, arg1, node_time, out);
+}
+// The same trait calls for MANY instances in one launch (lbft_node_calls): lane t applies calls[t] -- each on another instance, so the
+// calls are independent -- and leaves its 16 result words at out + 16 t.
+__global__ __launch_bounds__(64) void lbft_k_node_ops(Params p, u32* __restrict__ state, const lbft_node_call* __restrict__ calls, u32 n,
+                                                       unsigned long long* __restrict__ out) {
+  u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  lbft_node_call c = calls[t];
+  node_op_body(p, state, c.op, c.instance, c.node, c.peer, c.handle, c.node_time, out + (size_t)16 * t);
 }
 
 // out[shift * len + r] = PacemakerState::leader(r) under the voting rights shifted by `shift` (blockIdx.y; one table when the
@@ -470,6 +485,9 @@ struct lbft_batch {
   u64* d_states_out = nullptr;
   unsigned long long* d_counters = nullptr;
   u32* d_scratch = nullptr;  // m * n words for gathers
+  lbft_node_call* d_calls = nullptr;  // lbft_node_calls: the calls of one batch and their result words
+  unsigned long long* d_call_out = nullptr;
+  size_t calls_cap = 0;
   Params p;
   bool ran = false;
   bool manual = false;  // node-level interface active (lbft_batch_manual_begin)
@@ -553,7 +571,7 @@ static void free_batch(lbft_batch* b) {
   if (!b) return;
   (void)hipSetDevice(b->device);
   hipFree(b->d_seeds); hipFree(b->d_state); hipFree(b->d_zx); hipFree(b->d_zf); hipFree(b->d_et); hipFree(b->d_dur);
-  hipFree(b->d_leaders); hipFree(b->d_weights); hipFree(b->d_prof); hipFree(b->d_unfinished); hipFree(b->d_states_out); hipFree(b->d_counters); hipFree(b->d_scratch);
+  hipFree(b->d_leaders); hipFree(b->d_weights); hipFree(b->d_prof); hipFree(b->d_unfinished); hipFree(b->d_states_out); hipFree(b->d_counters); hipFree(b->d_scratch); hipFree(b->d_calls); hipFree(b->d_call_out);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   if (b->ev2) hipEventDestroy(b->ev2);
@@ -684,6 +702,78 @@ static int node_op(lbft_batch* b, u32 op, size_t inst, u32 node, u32 arg0, u32 a
   if (n_out) HIP_TRY(hipMemcpyAsync(host_out, d_out, n_out * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
   return LBFT_OK;
+}
+
+static bool exchange_layout(const lbft_batch* b);
+// Many trait calls in ONE launch and ONE synchronisation (a host that drives thousands of simulators -- the Rust `Simulator<GpuNode, ..>`
+// of bindings/rust -- is otherwise bound by ~10-20 us of launch + sync per call).  Every call of a batch must address another
+// instance (calls on one instance are ordered by the protocol; they go into successive batches).
+int lbft_node_calls(lbft_batch* b, const lbft_node_call* calls, size_t n, lbft_node_result* results) {
+  if (!b || (n && (!calls || !results))) return LBFT_ERR_INVALID;
+  if (!b->manual) { g_err = "lbft_batch_manual_begin first"; return LBFT_ERR_STATE; }
+  if (n == 0) return LBFT_OK;
+  if (n > b->m) { g_err = "more calls than instances: two calls of a batch would address one instance"; return LBFT_ERR_INVALID; }
+  const bool exchange = exchange_layout(b);
+  std::vector<uint8_t> seen(b->m, 0);
+  std::vector<lbft_node_call> dev(calls, calls + n);
+  for (size_t k = 0; k < n; k++) {
+    const lbft_node_call& c = calls[k];
+    if (c.instance >= b->m || c.node >= b->p.n) { g_err = "call addresses no such instance / node"; return LBFT_ERR_INVALID; }
+    if (seen[c.instance]) { g_err = "two calls of one batch address the same instance"; return LBFT_ERR_INVALID; }
+    seen[c.instance] = 1;
+    u32 op;
+    switch (c.op) {
+      case LBFT_CALL_UPDATE_NODE: op = OP_UPDATE; break;
+      case LBFT_CALL_CREATE_NOTIFICATION: op = OP_CREATE_NOTIFICATION; break;
+      case LBFT_CALL_HANDLE_NOTIFICATION: op = OP_HANDLE_NOTIFICATION; if (c.peer >= b->p.n || c.handle >= b->p.scap) return LBFT_ERR_INVALID; break;
+      case LBFT_CALL_RELEASE_NOTIFICATION: op = OP_RELEASE_NOTIFICATION; if (c.handle >= b->p.scap) return LBFT_ERR_INVALID; break;
+      case LBFT_CALL_CREATE_REQUEST: op = OP_CREATE_REQUEST; break;
+      case LBFT_CALL_HANDLE_REQUEST: op = OP_HANDLE_REQUEST; if (c.handle >= b->p.scap) return LBFT_ERR_INVALID; break;
+      case LBFT_CALL_HANDLE_RESPONSE: op = OP_HANDLE_RESPONSE; if (c.peer >= b->p.n || c.handle >= b->p.scap) return LBFT_ERR_INVALID; break;
+      default: g_err = "unknown call"; return LBFT_ERR_INVALID;
+    }
+    if (!exchange && (op == OP_CREATE_REQUEST || op == OP_HANDLE_REQUEST || op == OP_HANDLE_RESPONSE)) {
+      g_err = "request / response calls of a batch need the record-exchange layout (quirks bit 0); in reference mode use the single calls (payload-free tokens)";
+      return LBFT_ERR_UNSUPPORTED;
+    }
+    dev[k].op = op;
+  }
+  HIP_TRY(hipSetDevice(b->device));
+  const size_t call_bytes = n * sizeof(lbft_node_call), out_bytes = n * 16 * sizeof(unsigned long long);
+  if (b->calls_cap < n) {
+    if (b->d_calls) { hipFree(b->d_calls); b->d_calls = nullptr; }
+    if (b->d_call_out) { hipFree(b->d_call_out); b->d_call_out = nullptr; }
+    b->calls_cap = 0;
+    size_t cap = n < 1024 ? 1024 : n;
+    HIP_TRY(hipMalloc(&b->d_calls, cap * sizeof(lbft_node_call)));
+    HIP_TRY(hipMalloc(&b->d_call_out, cap * 16 * sizeof(unsigned long long)));
+    b->calls_cap = cap;
+  }
+  HIP_TRY(hipMemcpyAsync(b->d_calls, dev.data(), call_bytes, hipMemcpyHostToDevice, b->stream));
+  lbft_k_node_ops<<<(u32)((n + 63) / 64), 64, 0, b->stream>>>(b->p, b->d_state, b->d_calls, (u32)n, b->d_call_out);
+  HIP_TRY(hipGetLastError());
+  std::vector<unsigned long long> h(n * 16);
+  HIP_TRY(hipMemcpyAsync(h.data(), b->d_call_out, out_bytes, hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  int rc = LBFT_OK;
+  for (size_t k = 0; k < n; k++) {
+    const unsigned long long* o = &h[k * 16];
+    lbft_node_result& r = results[k];
+    memset(&r, 0, sizeof(r));
+    switch (dev[k].op) {
+      case OP_UPDATE:
+        r.actions.next_scheduled_update = (int64_t)o[0]; r.actions.should_send[0] = o[1]; r.actions.should_send[1] = o[2];
+        r.actions.should_broadcast = (uint32_t)o[3]; r.actions.should_query_all = (uint32_t)o[4];
+        break;
+      case OP_HANDLE_NOTIFICATION: r.should_sync = (uint32_t)o[0]; break;
+      case OP_CREATE_NOTIFICATION: case OP_CREATE_REQUEST: case OP_HANDLE_REQUEST:
+        if ((long long)o[0] < 0) { r.status = LBFT_ERR_FAULT; rc = LBFT_ERR_FAULT; g_err = "no free snapshot slot (snapshot_capacity) in at least one call"; }
+        else r.handle = (uint32_t)o[0];
+        break;
+      default: break;
+    }
+  }
+  return rc;
 }
 
 int lbft_node_update(lbft_batch* b, size_t inst, uint32_t node, int64_t node_time, lbft_actions* out) {
@@ -1363,6 +1453,42 @@ int lbft_batch_counters(const lbft_batch* b, lbft_counters* out) {
   if (!b || !out) return LBFT_ERR_INVALID;
   if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
   *out = b->counters;
+  return LBFT_OK;
+}
+
+// ---- the run's ONE collective, natively: RCCL all-reduce of the throughput counters over xGMI ----
+// librccl is not linked: it is loaded when the first all-reduce is asked for (a single-GPU user never maps it).
+namespace {
+typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, void* /*ncclComm_t*/, hipStream_t);
+nccl_allreduce_fn g_nccl_allreduce = nullptr;
+const int kNcclUint64 = 5, kNcclSum = 0, kNcclMax = 2;  // rccl.h: ncclUint64 = 5; ncclSum = 0, ncclProd = 1, ncclMax = 2
+}
+int lbft_batch_counters_allreduce(lbft_batch* b, void* nccl_comm, lbft_counters* out) {
+  if (!b || !nccl_comm || !out) return LBFT_ERR_INVALID;
+  if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
+  if (!g_nccl_allreduce) {
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) { g_err = std::string("librccl not found: ") + dlerror(); return LBFT_ERR_HIP; }
+    g_nccl_allreduce = reinterpret_cast<nccl_allreduce_fn>(dlsym(h, "ncclAllReduce"));
+    if (!g_nccl_allreduce) { g_err = "ncclAllReduce not found in librccl"; return LBFT_ERR_HIP; }
+  }
+  HIP_TRY(hipSetDevice(b->device));
+  const lbft_counters& c = b->counters;
+  // [0, 11): sums -- ONE ncclAllReduce(ncclSum); [11, 14): high-water marks -- a second, three-word one with ncclMax
+  unsigned long long h[14] = {c.events[0], c.events[1], c.events[2], c.events[3], c.rng_draws, c.rounds, c.commits, c.events_scheduled,
+                              c.faulted_instances, c.timers_folded, c.node_updates, c.max_queue, c.max_snapshots, c.max_blocks};
+  unsigned long long* d = reinterpret_cast<unsigned long long*>(b->d_scratch);  // (>= 256 bytes)
+  HIP_TRY(hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, b->stream));
+  int rc = g_nccl_allreduce(d, d, 11, kNcclUint64, kNcclSum, nccl_comm, b->stream);
+  if (rc == 0) rc = g_nccl_allreduce(d + 11, d + 11, 3, kNcclUint64, kNcclMax, nccl_comm, b->stream);
+  if (rc != 0) { g_err = "ncclAllReduce failed with ncclResult_t " + std::to_string(rc); return LBFT_ERR_HIP; }
+  HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  *out = c;
+  out->events[0] = h[0]; out->events[1] = h[1]; out->events[2] = h[2]; out->events[3] = h[3];
+  out->rng_draws = h[4]; out->rounds = h[5]; out->commits = h[6]; out->events_scheduled = h[7]; out->faulted_instances = h[8];
+  out->timers_folded = h[9]; out->node_updates = h[10]; out->max_queue = h[11]; out->max_snapshots = h[12]; out->max_blocks = h[13];
   return LBFT_OK;
 }
 

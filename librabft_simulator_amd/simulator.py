@@ -136,6 +136,13 @@ class BatchResult:
             return c.as_dict()
         return self._get("counters", f)
 
+    def counters_allreduce(self, nccl_comm):
+        """The run's one collective, natively: RCCL ncclAllReduce of the throughput counters over the caller's communicator (an
+        ncclComm_t as an integer / ctypes pointer; every rank calls it).  Returns the aggregate as a dict."""
+        c = LbftCounters()
+        check(_lib.lib().lbft_batch_counters_allreduce(self._sim._h, C.c_void_p(int(nccl_comm)), C.byref(c)))
+        return c.as_dict()
+
     def _node_array(self, name, dtype):
         def f():
             out = np.zeros((self._sim.num_instances, self._sim.num_nodes), dtype=dtype)
@@ -310,6 +317,17 @@ class BatchSimulator:
         ``nodes[instance][author]`` -> NodeHandle."""
         check(_lib.lib().lbft_batch_manual_begin(self._h, int(max_clock)))
         return [[NodeHandle(self, i, n) for n in range(self.num_nodes)] for i in range(self.num_instances)]
+
+    def node_calls(self, calls):
+        """Many trait calls in ONE launch (lbft_node_calls): `calls` = iterable of (op, instance, node, peer, handle, node_time) with op
+        one of _lib.CALL_*; every call on another instance.  Returns a list of dicts (actions / handle / should_sync per call)."""
+        calls = list(calls)
+        arr = (_lib.LbftNodeCall * len(calls))()
+        for k, (op, inst, node, peer, handle, t) in enumerate(calls):
+            arr[k] = _lib.LbftNodeCall(int(op), int(inst), int(node), int(peer), int(handle), 0, int(t))
+        res = (_lib.LbftNodeResult * len(calls))()
+        check(_lib.lib().lbft_node_calls(self._h, arr, len(calls), res))
+        return [{"actions": r.actions.as_dict(), "handle": int(r.handle), "should_sync": bool(r.should_sync), "status": int(r.status)} for r in res]
 
     def release_notification(self, instance, notification):
         check(_lib.lib().lbft_node_release_notification(self._h, int(instance), notification[1]))

@@ -185,6 +185,33 @@ def test_bench_two_ranks_on_one_device():
     assert round(d["events_per_s"] * d["ms_per_step"]) == round(w["events_per_s"] * w["ms_per_step"])
 
 
+def test_bench_two_ranks_nccl():
+    """bench.py --gpus 2 over RCCL (backend "nccl", one device per rank): what the driver's scaling run launches.  Needs two GPUs; the
+    one-GPU boxes of the test tier skip it (the native RCCL path is still executed there: tests/test_node_level.py::
+    test_counters_allreduce_through_rccl)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (found %d)" % torch.cuda.device_count())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    for extra, scaling in ((["--instances", "4096"], "weak"), (["--total-instances", "8192"], "strong")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["faulted_instances"] == 0 and d["parity"]["mismatches"] == 0
+        assert d["config"]["total_instances"] == 8192
+
+
 def test_multi_launch_equals_single_launch(amd, oracle):
     kw, seeds = dict(num_nodes=4), np.arange(1, 257, dtype=np.uint64)
     _, res = run_gpu(amd, kw, seeds, 1000, max_steps_per_launch=97)

@@ -300,3 +300,99 @@ def test_device_request_response_in_reference_mode_are_self_answered_and_insert_
     with pytest.raises(amd.LbftError) as e:    # a peer's answer needs the payloads of quirks bit 0
         dev.respond(0, req)
     assert e.value.code == -3
+
+
+@pytest.mark.gpu
+def test_batched_node_calls_equal_single_calls():
+    """lbft_node_calls: the trait calls of MANY instances in one launch == the same calls made one by one (one launch + sync each).
+    Scenario per instance: every node's first update (the leader of round 1 proposes), the proposer's notification delivered to the
+    others, their updates (votes) -- with a different proposer-visible time per instance so that the instances differ."""
+    import time
+    import librabft_simulator_amd as amd
+    from librabft_simulator_amd import _lib
+    m, n = 512, 4
+
+    def drive(batched):
+        sim = amd.BatchSimulator.new(np.arange(1, m + 1, dtype=np.uint64), n, amd.RandomDelay.new(10.0, 4.0))
+        nodes = sim.manual(100000)
+        trace, dt = [], 0.0
+
+        def many(calls):
+            nonlocal dt
+            t0 = time.perf_counter()
+            if batched:
+                r = sim.node_calls(calls)
+            else:
+                r = []
+                for op, inst, node, peer, handle, t in calls:
+                    h = nodes[inst][node]
+                    if op == _lib.CALL_UPDATE_NODE:
+                        r.append({"actions": h.update_node(t), "handle": 0, "should_sync": False})
+                    elif op == _lib.CALL_CREATE_NOTIFICATION:
+                        r.append({"actions": None, "handle": h.create_notification()[1], "should_sync": False})
+                    elif op == _lib.CALL_HANDLE_NOTIFICATION:
+                        r.append({"actions": None, "handle": 0, "should_sync": h.handle_notification((peer, handle))})
+            dt += time.perf_counter() - t0
+            return r
+        for node in range(n):  # first update of every node, instance-specific clocks
+            res = many([(_lib.CALL_UPDATE_NODE, i, node, 0, 0, 1 + i % 7) for i in range(m)])
+            trace.append([(r["actions"]["next_scheduled_update"], tuple(r["actions"]["should_send"]), r["actions"]["should_broadcast"]) for r in res])
+        leader = [next((k for k in range(n) if trace[k][i][2]), 0) for i in range(m)]  # who broadcast (the proposer), per instance
+        notes = many([(_lib.CALL_CREATE_NOTIFICATION, i, leader[i], 0, 0, 0) for i in range(m)])
+        for d in range(1, n):
+            res = many([(_lib.CALL_HANDLE_NOTIFICATION, i, (leader[i] + d) % n, leader[i], notes[i]["handle"], 0) for i in range(m)])
+            trace.append([r["should_sync"] for r in res])
+            res = many([(_lib.CALL_UPDATE_NODE, i, (leader[i] + d) % n, 0, 0, 9 + i % 5) for i in range(m)])
+            trace.append([(r["actions"]["next_scheduled_update"], tuple(r["actions"]["should_send"]), r["actions"]["should_broadcast"]) for r in res])
+        views = [[nodes[i][k].view() for k in range(n)] for i in range(0, m, 37)]
+        return trace, views, dt
+
+    t_b, v_b, dt_b = drive(True)
+    t_s, v_s, dt_s = drive(False)
+    assert t_b == t_s and v_b == v_s
+    assert any(x[2] for x in t_b[0] + t_b[1] + t_b[2] + t_b[3])            # somebody proposed
+    assert any(len(x[1]) for row in t_b[4:] for x in row if isinstance(x, tuple))  # votes were sent to the proposer
+    print("node-level calls: %d instances, batched %.1f ms, one by one %.1f ms" % (m, dt_b * 1e3, dt_s * 1e3))
+    assert dt_b < dt_s  # ~16 launches against ~16 * 512
+
+
+@pytest.mark.gpu
+def test_batched_node_calls_reject_two_calls_on_one_instance():
+    import librabft_simulator_amd as amd
+    from librabft_simulator_amd import _lib
+    sim = amd.BatchSimulator.new(np.arange(1, 5, dtype=np.uint64), 4, amd.RandomDelay.new(10.0, 4.0))
+    sim.manual(1000)
+    with pytest.raises(amd.LbftError) as e:
+        sim.node_calls([(_lib.CALL_UPDATE_NODE, 1, 0, 0, 0, 1), (_lib.CALL_UPDATE_NODE, 1, 2, 0, 0, 1)])
+    assert e.value.code == -1
+
+
+@pytest.mark.gpu
+def test_counters_allreduce_through_rccl():
+    """lbft_batch_counters_allreduce: the run's one collective, natively (ncclAllReduce on the batch's stream).  One GPU here, so the
+    communicator has one rank: the call goes through librccl and must return the batch's own counters."""
+    import ctypes
+    import librabft_simulator_amd as amd
+    try:
+        rccl = ctypes.CDLL("librccl.so.1")
+    except OSError:
+        pytest.skip("librccl not available")
+    uid = (ctypes.c_char * 128)()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    u = UniqueId()
+    ctypes.memmove(ctypes.byref(u), uid, 128)
+    res = amd.BatchSimulator.new(np.arange(1, 513, dtype=np.uint64), 4, amd.RandomDelay.new(10.0, 4.0)).loop_until(500)
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, u, 0) == 0
+    try:
+        agg = res.counters_allreduce(comm.value)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        rccl.ncclCommDestroy(comm)
+    own = res.counters
+    for k in ("events", "rounds", "commits", "rng_draws", "events_scheduled", "faulted_instances", "timers_folded", "node_updates", "max_queue", "max_snapshots", "max_blocks"):
+        assert agg[k] == own[k], k
