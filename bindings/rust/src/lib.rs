@@ -62,7 +62,7 @@ pub struct LbftCommit {
 }
 
 #[repr(C)]
-#[derive(Default)]
+#[derive(Clone, Copy, Default)]
 pub struct LbftActions {
     pub next_scheduled_update: i64,
     pub should_send: [u64; 2],
