@@ -1,4 +1,4 @@
 set -u
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r03calls
-timeout 900 python -m pytest tests/test_node_level.py -x -q -m gpu -s > gpurun_out/r03calls/pytest.log 2>&1; echo rc=$?; grep "node-level calls" gpurun_out/r03calls/pytest.log; tail -8 gpurun_out/r03calls/pytest.log
+mkdir -p gpurun_out/r03log
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "third_party or golden or gpu_equals_oracle or full_batch" > gpurun_out/r03log/pytest.log 2>&1; echo rc=$?; tail -4 gpurun_out/r03log/pytest.log
