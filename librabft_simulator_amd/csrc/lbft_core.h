@@ -88,6 +88,13 @@ typedef int64_t i64;
 #ifndef LBFT_FAST_TRUNC_EXP
 #define LBFT_FAST_TRUNC_EXP 1  // the delay sampler decides trunc(exp(y)) from a single-precision estimate when that is safe (SimT::trunc_exp)
 #endif
+#ifndef LBFT_C0_POPC
+#define LBFT_C0_POPC 1   // small batches of class-0 networks run lbft_k_run0s (SimT<8>): the pop's scan by all 64 lanes of the wavefront
+#endif
+#ifndef LBFT_POPC_MAX_LPW
+#define LBFT_POPC_MAX_LPW 8u  // networks per wavefront up to which lbft_k_run0s is used (measured: 1 024 x 4: 6.3 against 7.5 ms, 8 192: 10.9 against 12.1,
+                              // 16 384 (8 per wavefront): 14.8 against 15.9; 32 per wavefront: the lane-private scan stops at the queue's length and wins)
+#endif
 #ifndef LBFT_C0_QLANE
 #define LBFT_C0_QLANE 0
 #endif
@@ -315,6 +322,16 @@ enum SnapField : u32 { S_EPOCH = 0, S_CERTS /* hcc | hqc << 16 */, S_PROP_VOTE /
 #define LBFT_NO_LEADER 0xffu
 #define LBFT_NEVER INT64_MAX
 
+// Branch hints: without them the compiler lays blocks out in source order, i.e. fault handling, capacity spills and once-per-epoch code
+// sit in the middle of the event loop; with them they move behind it and the loop's instruction-cache footprint shrinks.
+#if defined(LBFT_NO_HINTS)
+#define LBFT_UNLIKELY(x) (x)
+#define LBFT_LIKELY(x) (x)
+#else
+#define LBFT_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#define LBFT_LIKELY(x) __builtin_expect(!!(x), 1)
+#endif
+LBFT_RARE u64 udiv64(u64 a, u64 b) { return a / b; }  // (a software division of ~200 instructions on the device; only epoch changes need it)
 LBFT_HD u64 rotl64(u64 x, int b) { return (x << b) | (x >> (64 - b)); }
 
 LBFT_HD u64 mulhi64(u64 a, u64 b) {
@@ -349,7 +366,7 @@ LBFT_HD int ctz32(u32 x) {
 
 // Rust `f64 as i64` (saturating; NaN -> 0).
 LBFT_HD i64 f64_to_i64_sat(double v) {
-  if (v >= 0.0 && v < 2147483648.0) return (i64)(i32)v;  // every sane delay: one hardware conversion (truncates toward zero)
+  if (__builtin_expect(v >= 0.0 && v < 2147483648.0, 1)) return (i64)(i32)v;  // every sane delay: one hardware conversion (truncates toward zero)
   if (v != v) return 0;
   if (v >= 9223372036854775808.0) return INT64_MAX;
   if (v <= -9223372036854775808.0) return INT64_MIN;
@@ -532,7 +549,7 @@ LBFT_HD u64 record_hash_timeout(u64 epoch, u64 round, u64 hcbr, u64 author) {
 
 // EpochConfiguration::pick_author(SipHash13(round)) (configuration.rs:65-75, pacemaker.rs:100-109)
 // `shift`: author a holds weights[(a + shift) % n] (rotating voting rights; 0 in the reference)
-LBFT_HD u32 compute_leader(const u32* weights, u32 n, u32 total_votes, u64 round, u32 shift = 0) {
+LBFT_RARE u32 compute_leader(const u32* weights, u32 n, u32 total_votes, u64 round, u32 shift = 0) {
   Rng r;
   r.seed(siphash13_u64(round));
   u64 target = r.gen_range_u64(total_votes);
@@ -614,8 +631,14 @@ struct SimT {
   // batch's state (the generic class 3 reads back / steps any batch) honours its ring of pre-generated draws.
   // 64-wide tiles addressed at compile time for the small-network classes (many lanes per wavefront); the large-network
   // classes address tiles of P.tw = lanes per wavefront (lbft_core.h "HBM layout")
-  static constexpr bool C0I = CLS == 0 && LBFT_C0_IMAJOR != 0;
-  static constexpr bool TILE64 = (CLS == 0 && !C0I) || CLS == 1 || CLS == 6;
+  // 8 = class 0 for SMALL batches (at most LBFT_POPC_MAX_LPW networks per wavefront, lbft_k_run0s): the same step, but the pop's scan of the
+  // LDS queue front is done by all 64 lanes of the wavefront (coop_find, run_popc) -- a kernel of its own so that neither carries the
+  // other's scan (with both, lbft_k_run0 grew from 57.8 to 61.4 KB and the 65 536-network batch from 22.4 to 24.0 ms: the 64 KB
+  // instruction cache again)
+  static constexpr bool POPC = CLS == 8;
+  static constexpr bool C0 = CLS == 0 || CLS == 8;
+  static constexpr bool C0I = C0 && LBFT_C0_IMAJOR != 0;
+  static constexpr bool TILE64 = (C0 && !C0I) || CLS == 1 || CLS == 6;
   static constexpr bool HCREG = C0I && LBFT_C0_HCREG != 0;
   static constexpr bool IMAJOR = BIG || C0I;  // tile width 1 = every instance's words contiguous (P.tw == 1), addressed at compile time
   static constexpr bool F_AX = LEAN2 ? (LBFT_LEAN_AX != 0) : (LBFT_AX != 0);      // (tuning switches above)
@@ -626,12 +649,12 @@ struct SimT {
   bool coop_on;  // set by run_coop: the event loop is being run by a whole wavefront
   LBFT_HD bool coop() const { return COOP && coop_on && P.qcal != 0 && P.ring != 0 && !lossy(); }
   LBFT_HD bool wide() const { return BIG ? true : (CLS == 3 ? P.n > 32 : false); }
-  LBFT_HD bool heap() const { return CLS == 0 ? false : (BIG ? true : P.qheap != 0); }
-  LBFT_HD bool tracing() const { return CLS != 0 && !LEAN && P.rcap != 0; }  // round-switch trace (DataWriter); class 0 never traces
-  LBFT_HD bool q1() const { return CLS != 0 && (!LEAN || CLS == 7) && (P.quirks & 1u) != 0; }  // requests are answered by the peer with real payloads
-  LBFT_HD bool cal() const { return CLS != 0 && P.qcal != 0; }
-  LBFT_HD bool packed() const { return CLS == 0 ? true : (BIG ? false : P.n <= 16); }
-  LBFT_HD bool qpacked() const { return CLS == 0 ? true : (CLS == 3 ? P.qpack != 0 : false); }  // one-word queue entries
+  LBFT_HD bool heap() const { return C0 ? false : (BIG ? true : P.qheap != 0); }
+  LBFT_HD bool tracing() const { return !C0 && !LEAN && P.rcap != 0; }  // round-switch trace (DataWriter); class 0 never traces
+  LBFT_HD bool q1() const { return !C0 && (!LEAN || CLS == 7) && (P.quirks & 1u) != 0; }  // requests are answered by the peer with real payloads
+  LBFT_HD bool cal() const { return !C0 && P.qcal != 0; }
+  LBFT_HD bool packed() const { return C0 ? true : (BIG ? false : P.n <= 16); }
+  LBFT_HD bool qpacked() const { return C0 ? true : (CLS == 3 ? P.qpack != 0 : false); }  // one-word queue entries
   const Params& P;
   char* tile;
   u32 lane4;
@@ -661,7 +684,7 @@ struct SimT {
   // LBFT_C0_QLANE (kernel class 0): the LDS queue front is lane-major instead -- a lane's slots are consecutive words (slot offsets are
   // instruction immediates, two keys per ds_read_b128), lanes LBFT_QLANE_PAD words apart beyond the slots so that the lanes of a
   // wavefront reading the same slot fall into different banks
-  static constexpr bool QLANE = CLS == 0 && LBFT_C0_QLANE != 0;
+  static constexpr bool QLANE = C0 && LBFT_C0_QLANE != 0;
   LBFT_HD u32 qx(u32 k) const { return QLANE ? k : k << qsh; }
   // read-only tables (LDS copies on the device)
   const u64 *zig_x, *zig_f, *exp_tab;
@@ -1046,8 +1069,8 @@ struct SimT {
       double xi = lbft_asdouble(zig_x[i]);
       double x = u * xi;
       double ax = x < 0.0 ? -x : x;
-      if (ax < lbft_asdouble(zig_x[i + 1])) return x;
-      if (i == 0) {
+      if (LBFT_LIKELY(ax < lbft_asdouble(zig_x[i + 1]))) return x;
+      if (LBFT_UNLIKELY(i == 0)) {
         double xx = 1.0, yy = 0.0;
         while (-2.0 * yy < xx * xx) {
           double a = lbft_asdouble((1023ULL << 52) | (rng.next_u64() >> 12)) - (1.0 - 0x1p-53);
@@ -1071,14 +1094,14 @@ struct SimT {
   LBFT_HD i64 trunc_exp(double y) const {
 #if LBFT_FAST_TRUNC_EXP
     float t = (float)(y * 1.4426950408889634);
-    if (t > -20.0f && t < 20.0f) {
+    if (LBFT_LIKELY(t > -20.0f && t < 20.0f)) {
 #if defined(__HIP_DEVICE_COMPILE__)
       float a = __builtin_amdgcn_exp2f(t);
 #else
       float a = exp2f(t);
 #endif
       float fl = __builtin_floorf(a), fr = a - fl, m = a * 2e-6f;
-      if (fr > m && fr < 1.0f - m) return (i64)(i32)fl;
+      if (LBFT_LIKELY(fr > m && fr < 1.0f - m)) return (i64)(i32)fl;
     }
 #endif
     return f64_to_i64_sat(lbft_exp(y, exp_tab));
@@ -1102,7 +1125,7 @@ struct SimT {
 #define LBFT_QP_STAMP_BITS 25
   LBFT_HD void q_set(u32 k, u64 key, u32 meta) const {
     if (qpacked()) {
-      if (k < ql) qk[qx(k)] = key;
+      if (LBFT_LIKELY(k < ql)) qk[qx(k)] = key;
       else { st(P.off_qhi + k, (u32)(key >> 32)); st(P.off_qlo + k, (u32)key); }
       return;
     }
@@ -1112,7 +1135,7 @@ struct SimT {
   LBFT_HD void q_get(u32 k, u64& key, u32& meta) const {
     if (qpacked()) {
       meta = 0;
-      if (k < ql) key = qk[qx(k)];
+      if (LBFT_LIKELY(k < ql)) key = qk[qx(k)];
       else key = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k);
       return;
     }
@@ -1140,9 +1163,9 @@ struct SimT {
   LBFT_HD bool push_event(i64 time, u32 kind, u32 node, u32 sender, u32 slot, u32 reuse_stamp = ~0u) {
     u32 my_stamp = reuse_stamp;
     if (reuse_stamp == ~0u) my_stamp = stamp++;
-    if (time > (i64)P.max_clock) return false;
-    if (my_stamp >= (qpacked() ? (1u << LBFT_QP_STAMP_BITS) : (1u << 30))) { fault |= F_STAMP_OVERFLOW; return false; }
-    if (qlen >= P.qcap) { fault |= F_QUEUE_OVERFLOW; return false; }
+    if (LBFT_UNLIKELY(time > (i64)P.max_clock)) return false;
+    if (LBFT_UNLIKELY(my_stamp >= (qpacked() ? (1u << LBFT_QP_STAMP_BITS) : (1u << 30)))) { fault |= F_STAMP_OVERFLOW; return false; }
+    if (LBFT_UNLIKELY(qlen >= P.qcap)) { fault |= F_QUEUE_OVERFLOW; return false; }
     u64 key = ((u64)(u32)time << 32) | ((3u - kind) << 30) | my_stamp;
     u32 meta = node | (sender << 8) | (slot << 16);
     if (qpacked())
@@ -1195,6 +1218,57 @@ struct SimT {
       bool lt = mb < ma;
       m = lt ? mb : ma; i = lt ? ib : ia;
     }
+  }
+  // Packed queue: (bkey, best) = the smallest key among the LDS slots and its slot.  Completes the pop: the spilled tail (slots >= ql
+  // live in the HBM rows; rare when ql covers the high-water mark) is compared, the event decoded, and the last entry moved into the hole.
+  LBFT_HD void pop_take(u64 bkey, u32 best, i32& time, u32& kind, u32& meta) {
+    if (LBFT_UNLIKELY(qlen > ql))
+      for (u32 k = ql; k < qlen; k++) {
+        u64 key = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k);
+        if (key < bkey) { bkey = key; best = k; }
+      }
+    time = (i32)(u32)(bkey >> 43);
+    kind = 3u - ((u32)(bkey >> 41) & 3u);
+    ev_stamp = (u32)(bkey >> 16) & ((1u << LBFT_QP_STAMP_BITS) - 1u);
+    u32 lo = (u32)bkey;
+    meta = ((lo >> 12) & 15u) | (((lo >> 8) & 15u) << 8) | ((lo & 0xffu) << 16);
+    qlen--;
+    u64 lk = ~0ULL; u32 lm = 0;
+    if (best != qlen) { q_get(qlen, lk, lm); q_set(best, lk, 0); }
+    if (qlen < ql) qk[qx(qlen)] = ~0ULL;  // the vacated last slot becomes a sentinel again
+  }
+  // ---- the pop's scan by ALL 64 lanes of the wavefront (kernel class 0, SimT::run_popc; the north star's "next-event-time reductions
+  // done with wavefront shuffle primitives").  A wavefront carries lpw networks in its first lanes; their LDS queue columns are one
+  // array keys[slot][lpw] (unused slots hold the sentinel ~0), so lane l reads the words l, l + 64, l + 128, ... of that array -- slot
+  // (l + 64 j) / lpw of network l % lpw: every network's slots spread over 64 / lpw lanes, the idle lanes of a small-batch wavefront (63
+  // of 64 at one network per wavefront) and the upper half of a 32-network wavefront included.  Each lane keeps the smallest of its
+  // ql lpw / 64 keys, a butterfly of wavefront shuffles over the lanes of equal l % lpw leaves every network's minimum in all of its
+  // lanes, and -- keys are unique (creation stamps) -- the lane holding it names the slot.  `kw`: the wavefront's key array.
+  LBFT_HD void coop_find(const u64* kw, u64& bkey, u32& best) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 lane = lbft_lane_id();
+    const u32 words = ql << qsh;  // ql * lpw
+    u64 m = ~0ULL; u32 mi = 0;
+    for (u32 w0 = 0; w0 < words; w0 += 256u) {  // four independent loads per round trip
+      u64 v0 = w0 + lane < words ? kw[w0 + lane] : ~0ULL, v1 = w0 + 64u + lane < words ? kw[w0 + 64u + lane] : ~0ULL;
+      u64 v2 = w0 + 128u + lane < words ? kw[w0 + 128u + lane] : ~0ULL, v3 = w0 + 192u + lane < words ? kw[w0 + 192u + lane] : ~0ULL;
+      bool a = v1 < v0, b = v3 < v2;
+      u64 m01 = a ? v1 : v0, m23 = b ? v3 : v2;
+      u32 i01 = a ? w0 + 64u + lane : w0 + lane, i23 = b ? w0 + 192u + lane : w0 + 128u + lane;
+      bool c = m23 < m01;
+      u64 mm = c ? m23 : m01; u32 ii = c ? i23 : i01;
+      if (mm < m) { m = mm; mi = ii; }
+    }
+    for (u32 d = qstr; d < 64u; d <<= 1) {  // lanes l ^ d share l % lpw
+      u32 olo = (u32)__shfl_xor((int)(u32)m, (int)d, 64), ohi = (u32)__shfl_xor((int)(u32)(m >> 32), (int)d, 64), oi = (u32)__shfl_xor((int)mi, (int)d, 64);
+      u64 o = ((u64)ohi << 32) | olo;
+      bool lt = o < m;
+      m = lt ? o : m; mi = lt ? oi : mi;
+    }
+    bkey = m; best = mi >> qsh;
+#else
+    (void)kw; bkey = ~0ULL; best = 0;
+#endif
   }
   // Removes the minimum; returns false when the queue is empty.
   LBFT_HD bool pop_event(i32& time, u32& kind, u32& meta) {
@@ -1271,8 +1345,8 @@ struct SimT {
     u64 bkey = ~0ULL;
     u32 nl = qlen < ql ? qlen : ql;
     if (qpacked()) {
-      // ql is a multiple of 8 and slots >= qlen hold the sentinel: eight independent loads in flight per batch, then a
-      // tree of compare-selects (a sequential min pays one LDS round trip per slot)
+      // ql is a multiple of the batch and slots >= qlen hold the sentinel: LBFT_POP_BATCH independent loads in flight per batch,
+      // then a tree of compare-selects (a sequential min pays one LDS round trip per slot)
       for (u32 k0 = 0; k0 < nl; k0 += LBFT_POP_BATCH) {
         u64 kk[LBFT_POP_BATCH];
 #if defined(__HIPCC__)
@@ -1283,19 +1357,7 @@ struct SimT {
         qmin<0, LBFT_POP_BATCH>(kk, bm, bi);
         if (bm < bkey) { bkey = bm; best = k0 + bi; }
       }
-      for (u32 k = ql; k < qlen; k++) {  // spilled tail (rare when ql covers the high-water mark)
-        u64 key = ((u64)ld(P.off_qhi + k) << 32) | ld(P.off_qlo + k);
-        if (key < bkey) { bkey = key; best = k; }
-      }
-      time = (i32)(u32)(bkey >> 43);
-      kind = 3u - ((u32)(bkey >> 41) & 3u);
-      ev_stamp = (u32)(bkey >> 16) & ((1u << LBFT_QP_STAMP_BITS) - 1u);
-      u32 lo = (u32)bkey;
-      meta = ((lo >> 12) & 15u) | (((lo >> 8) & 15u) << 8) | ((lo & 0xffu) << 16);
-      qlen--;
-      u64 lk = ~0ULL; u32 lm = 0;
-      if (best != qlen) { q_get(qlen, lk, lm); q_set(best, lk, 0); }
-      if (qlen < ql) qk[qx(qlen)] = ~0ULL;  // the vacated last slot becomes a sentinel again
+      pop_take(bkey, best, time, kind, meta);
       return true;
     }
 #if defined(__HIPCC__)
@@ -1340,7 +1402,7 @@ struct SimT {
   }
   LBFT_HD i32 snap_alloc() {
     if (mask_slots()) {
-      if (snap_mask == 0) { fault |= F_SNAP_OVERFLOW; return -1; }
+      if (LBFT_UNLIKELY(snap_mask == 0)) { fault |= F_SNAP_OVERFLOW; return -1; }
       u32 slot = ctz64(snap_mask);
       snap_mask &= snap_mask - 1;
       u32 live = P.scap - popc64(snap_mask);
@@ -1361,7 +1423,7 @@ struct SimT {
   }
 
   // extension "lossy network": called right after a message's delay draw; true = the message is lost
-  LBFT_HD bool lossy() const { return CLS != 0 && !LEAN && (P.drop_ppm | P.part_size) != 0; }
+  LBFT_HD bool lossy() const { return !C0 && !LEAN && (P.drop_ppm | P.part_size) != 0; }
   LBFT_HD bool net_lost(u32 a, u32 b) {
     if (!lossy()) return false;
     bool lost = false;
@@ -1369,7 +1431,7 @@ struct SimT {
     if (P.part_size && clock >= P.part_start && clock < P.part_end && ((a < P.part_size) != (b < P.part_size))) lost = true;
     return lost;
   }
-  LBFT_HD bool is_equivocator(u32 node) const { return CLS != 0 && P.equiv != 0 && node % P.equiv == 0; }  // class 0: all honest
+  LBFT_HD bool is_equivocator(u32 node) const { return !C0 && P.equiv != 0 && node % P.equiv == 0; }  // class 0: all honest
   // EpochConfiguration of the node's current epoch (extension "rotating voting rights": shifted by epoch * rot)
   // (32-bit arithmetic: epochs are bounded by the block capacity 65534 and rot < n <= 128; a 64-bit modulo is a ~200-instruction
   // software division inlined at every use)
@@ -1387,7 +1449,7 @@ struct SimT {
     // when the two pointer members happen to sit at the same offset of their structs, the optimiser merges the two
     // branches into one load through a phi of `this` and `&P`, after which neither struct is promoted to registers any
     // more (the whole simulator state silently moves to scratch memory; tests/test_abi.py guards the symptom).
-    if (round < P.leader_len) {
+    if (LBFT_LIKELY(round < P.leader_len)) {
       const u8* tab = (round < leader_lds_len && shift == 0) ? leader_lds : P.leader_tab + (size_t)shift * P.leader_len;
       return tab[round];
     }
@@ -1410,7 +1472,7 @@ struct SimT {
   LBFT_HD bool state_pending(u32 node, u32 blk, const Blk& r) const {
     if (!bm_test(blk, r, B_PEND, node)) return false;
     u32 d = r.depth();
-    if (d > nf(node, NF_NCOMMITS)) return true;
+    if (LBFT_LIKELY(d > nf(node, NF_NCOMMITS))) return true;
     return ld(P.off_log + node * P.lcap + d - 1) != blk;
   }
   // RecordStoreState::compute_state (record_store.rs:426-454) + CommandExecutor::compute.
@@ -1588,7 +1650,7 @@ struct SimT {
         if (w >= P.quorum) nfs(node, NF_ELECTION, 1u | (b << 8));
       }
     } else {
-      fault |= F_BALLOT_OVERFLOW;
+      fault |= F_BALLOT_OVERFLOW;  // (never with honest voters: two ballot entries hold any round's votes)
     }
   }
   // Timeout (record_store.rs:390-415,527-538).  Caller checked the epoch.
@@ -1648,7 +1710,7 @@ struct SimT {
   LBFT_HD void propose_block(u32 node, u32 prev_blk, i64 local_clock) {
     u32 cmd = nf(node, NF_NEXT_CMD);
     nfs(node, NF_NEXT_CMD, cmd + 1);
-    if (nblocks >= P.bcap || nblocks >= 0xfffeu) { fault |= F_BLOCK_OVERFLOW; return; }
+    if (LBFT_UNLIKELY(nblocks >= P.bcap || nblocks >= 0xfffeu)) { fault |= F_BLOCK_OVERFLOW; return; }
     u32 b = ++nblocks;
     u32 base = prev_blk ? prev_blk : nf(node, NF_INIT_STATE_BLK);
     Blk rb;
@@ -1704,9 +1766,9 @@ struct SimT {
   LBFT_HD i64 duration(u32 node, u32 round) {
     u32 hc = nf(node, NF_HC_ROUND);
     u32 hccr = hc > 0 ? hc + 2 : 0;
-    if (round <= hccr) { fault |= F_INTERNAL; return 0; }
+    if (LBFT_UNLIKELY(round <= hccr)) { fault |= F_INTERNAL; return 0; }
     u32 k = round - hccr;
-    if (k >= P.dur_len) { fault |= F_DURATION_TABLE; k = P.dur_len - 1; }
+    if (LBFT_UNLIKELY(k >= P.dur_len)) { fault |= F_DURATION_TABLE; k = P.dur_len - 1; }
     const i64* tab = k < dur_lds_len ? dur_lds : P.dur_tab;  // (a selected pointer: see leader())
     return tab[k];
   }
@@ -1818,10 +1880,10 @@ struct SimT {
       for (u32 s = 0; s < j; s++) y = blk_get(y).prev();
       Blk ry = j == 0 ? r0 : blk_get(y);
       // SimulatedContext::commit (simulated_context.rs:160-185)
-      if (!state_pending(node, y, ry)) { fault |= F_COMMIT_UNKNOWN_STATE; return; }
+      if (LBFT_UNLIKELY(!state_pending(node, y, ry))) { fault |= F_COMMIT_UNKNOWN_STATE; return; }
       u32 prev = ry.prev();
       u32 base = prev ? prev : nf(node, NF_INIT_STATE_BLK);
-      if (base != nf(node, NF_LAST_COMMITTED_BLK)) { fault |= F_COMMIT_NOT_SUCCESSOR; return; }
+      if (LBFT_UNLIKELY(base != nf(node, NF_LAST_COMMITTED_BLK))) { fault |= F_COMMIT_NOT_SUCCESSOR; return; }
       if (commit_block(node, y, ry.depth())) break;
     }
   }
@@ -1860,15 +1922,15 @@ struct SimT {
     {
       nfs(node, NF_LAST_COMMITTED_BLK, y);
       u32 nc = nf(node, NF_NCOMMITS);
-      if (nc >= P.lcap) { fault |= F_LOG_OVERFLOW; return true; }
+      if (LBFT_UNLIKELY(nc >= P.lcap)) { fault |= F_LOG_OVERFLOW; return true; }
       st(P.off_log + node * P.lcap + nc, y);
       nfs(node, NF_NCOMMITS, nc + 1);
       // read_epoch_id (simulated_context.rs:199-207)
       // epoch = depth / commands_per_epoch; the (software) 64-bit division only runs when a boundary is crossed
-      if ((u64)depth >= ((u64)nf(node, NF_EPOCH) + 1) * P.cpe) {
+      if (LBFT_UNLIKELY((u64)depth >= ((u64)nf(node, NF_EPOCH) + 1) * P.cpe)) {
         // the epoch switch itself (node.rs:331-348) runs once process_commits has returned (update_node: epoch_switch) -- ONE site, and
         // one with few live registers, instead of a copy inside each commit path
-        sw_epoch = (u32)((u64)depth / P.cpe) + 1u;
+        sw_epoch = (u32)udiv64((u64)depth, P.cpe) + 1u;
         sw_blk = y;
         return true;
       }
@@ -1946,7 +2008,7 @@ struct SimT {
     LBFT_UMARK(9);
     }
     process_commits(node);
-    if (sw_epoch) epoch_switch(node);
+    if (LBFT_UNLIKELY(sw_epoch != 0)) epoch_switch(node);
     LBFT_MARK(27);
     bool tq; i64 tnext;
     update_tracker(node, lqat, lclock, tq, tnext);
@@ -2236,7 +2298,7 @@ struct SimT {
   // fixed words, the slot's reference count and (networks of <= 4 nodes) the highest_certified_block_round of the
   // sender's current timeouts -- every later dependent fetch would be a memory round trip of its own, serialised
   // with those of the lanes on other paths.
-  LBFT_HD bool small_sets() const { return CLS == 0 && P.n <= 4; }
+  LBFT_HD bool small_sets() const { return C0 && P.n <= 4; }
   LBFT_HD Snap load_snapshot(u32 slot) const {
     Snap sn;
     u32 sb = boff(P.off_snap + slot * P.snap_words);
@@ -2340,7 +2402,7 @@ struct SimT {
   u64 plist;
   u32 plist8;     // n <= 8 in kernel class 0: eight 4-bit entries (64-bit variable shifts cost three instructions each)
   u8* plist_lds;  // n > 16: this instance's 128-byte list in LDS (device); nullptr = the HBM row region
-  LBFT_HD bool packed8() const { return CLS == 0 && P.n <= 8; }
+  LBFT_HD bool packed8() const { return C0 && P.n <= 8; }
   LBFT_HD u32 peer(u32 i) const {
     if (packed8()) return (plist8 >> (4 * i)) & 15u;
     if (packed()) return (u32)(plist >> (4 * i)) & 15u;
@@ -2570,7 +2632,7 @@ struct SimT {
     double u = lbft_asdouble((1024ULL << 52) | (bits >> 12)) - 3.0;
     double x = u * lbft_asdouble(zig_x[i]);
     double ax = x < 0.0 ? -x : x;
-    d = f64_to_i64_sat(lbft_exp(P.mu + P.sigma * x, exp_tab));
+    d = trunc_exp(P.mu + P.sigma * x);
     return ax < lbft_asdouble(zig_x[i + 1]);
   }
   LBFT_HD u32 horizon_time(i32 clk, i64 d) const {  // clock + delay, 0xffffffff = past max_clock (never queued)
@@ -2925,7 +2987,8 @@ struct SimT {
   // One event = step_begin (pop, the node's rows, the event's handler, update_node, process_node_actions, the messages the
   // scalar send loop handles) + step_end (write-back); the cooperative kernels run coop_bulk between the two.
   struct StepCtx { u32 node, sender, kind; i32 t_event; bool do_update; };
-  LBFT_HD bool step_begin(StepCtx& c) {  // false: the queue is empty
+  // (fkey, fbest): class 8 only -- the pop's scan was done by the whole wavefront (run_popc / coop_find): smallest LDS-resident key, its slot
+  LBFT_HD bool step_begin(StepCtx& c, u64 fkey = 0, u32 fbest = 0) {  // false: the queue is empty
     {
       i32 t; u32 kind, meta;
       // A response that spans several epochs (quirks bit 0) is one event but several steps: between two epochs the reference runs
@@ -2935,7 +2998,10 @@ struct SimT {
       const bool resumed = q1() && cont != 0;
       if (resumed) { t = clock; kind = 2; meta = ld(I_CONT_META); }
       else {
-        if (!pop_event(t, kind, meta)) return false;
+        if (POPC) {  // (the scan was done by the whole wavefront: run_popc)
+          if (qlen == 0) return false;
+          pop_take(fkey, fbest, t, kind, meta);
+        } else if (!pop_event(t, kind, meta)) return false;
         LBFT_MARK(0);
         LBFT_COUNT(30);
         if (tracing()) trace_round_switch(last_node, t);
@@ -3065,6 +3131,34 @@ struct SimT {
       step_end(c);
       LBFT_STEP_DONE();
     }
+  }
+  // Kernel class 0: EVERY lane of the wavefront runs the loop and takes part in the scan of the event queues (coop_find); the lanes
+  // that carry a network (`leader`) then execute its event.  `kw`: the wavefront's LDS key array.
+  LBFT_HD bool run_popc(bool leader, const u64* kw) {
+    u32 steps = 0;
+    u32 max_steps = P.max_steps ? P.max_steps : 0xffffffffu;
+    LBFT_PIN_VGPR(max_steps);
+    bool go = leader, drained = true;
+    bulk = 0;
+    for (;;) {
+      if (go && steps >= max_steps) { go = false; drained = false; }
+      if (go && qlen == 0) go = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (__ballot(go) == 0) break;
+#else
+      if (!go) break;
+#endif
+      u64 fkey; u32 fbest;
+      coop_find(kw, fkey, fbest);
+      if (go) {
+        StepCtx c;
+        step_begin(c, fkey, fbest);
+        steps++;
+        step_end(c);
+        LBFT_STEP_DONE();
+      }
+    }
+    return drained;
   }
   // The same loop for the kernels whose lanes cooperate (COOP): EVERY lane of the wavefront runs it; `leader` lanes carry a
   // network and execute the events, the other lanes only take part in the bulk sends of the leaders' networks.

@@ -110,7 +110,7 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
   const u32 qslots = p.ql + (SimT<CLS>::QLANE ? LBFT_QLANE_PAD : 0u);  // u64 words per instance in the key area
   u64* keys = SimT<CLS>::QLANE ? lds + LBFT_TABLE_U64 + ((size_t)wave * p.lpw + lane) * qslots : lds + LBFT_TABLE_U64 + (size_t)wave * p.ql * p.lpw + lane;
   u32* metas = reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)nwaves * qslots * p.lpw) + (size_t)wave * p.ql * p.lpw + lane;  // (CLS 0: unused, not allocated)
-  const u32 meta_words = CLS == 0 ? 0u : nwaves * p.ql * p.lpw;
+  const u32 meta_words = SimT<CLS>::C0 ? 0u : nwaves * p.ql * p.lpw;
   // Only the first p.lpw lanes of a wavefront carry an instance (occupancy vs lane-utilisation knob).
   u32 i = (blockIdx.x * nwaves + wave) * p.lpw + lane;
   bool active = lane < p.lpw && i < p.m;
@@ -159,6 +159,46 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
       atomicAdd(&p.prof[31], (unsigned long long)(__builtin_readcyclecounter() - t_begin));
     }
 #endif
+  } else if constexpr (SimT<CLS>::POPC) {
+    // Class 0 with the wavefront-wide pop (SimT::run_popc): every lane runs the event loop and scans the wavefront's queue columns;
+    // the lanes that carry a network execute its events.
+    SimT<CLS> s(p, tile, SimT<CLS>::IMAJOR ? lane * (p.total_words * 4u) : (i & (tw - 1u)) * 4u, 0);
+    bool lead = false;
+    if (active) lead = s.ld(I_DONE) == 0;
+    s.attach_queue(keys, metas, p.lpw, p.ql);
+    s.attach_tables(t_zx, t_zf, t_et);
+    s.attach_round_tables(t_leader, n_leader, t_dur, n_dur);
+    s.attach_weights(t_weights);
+    if (p.n <= 4 && !SimT<CLS>::HCREG) {  // the nodes' hcbr buffers
+      u32* hcb = reinterpret_cast<u32*>(reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 8u, nwaves));
+      s.attach_hcbr(hcb + (size_t)wave * LBFT_LDS_HCBR_WORDS * p.lpw + lane);
+    }
+    s.qlen = 0;
+    if (lead) {
+      s.load_scalars();
+      s.queue_to_lds();
+      s.hcbr_to_lds();
+    }
+#if defined(LBFT_PHASE_TIMERS)
+    u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)nwaves * qslots * p.lpw) +
+                                        (size_t)meta_words + (meta_words & 1u)) + wave * LBFT_NPHASES;
+    if (lane == 0) { for (int k = 0; k < LBFT_NPHASES; k++) wprof[k] = 0; wprof[31] = __builtin_readcyclecounter(); }
+    s.wprof = wprof;
+    u64 t_begin = __builtin_readcyclecounter();
+#endif
+    bool drained = s.run_popc(lead, keys - lane);
+    if (lead) {
+      done = drained;
+      s.queue_from_lds();
+      s.hcbr_from_lds();
+      s.store_scalars(done);
+    }
+#if defined(LBFT_PHASE_TIMERS)
+    if (p.prof && lane == 0) {
+      for (int k = 0; k < 31; k++) atomicAdd(&p.prof[k], (unsigned long long)s.wprof[k]);
+      atomicAdd(&p.prof[31], (unsigned long long)(__builtin_readcyclecounter() - t_begin));
+    }
+#endif
   } else
   if (active) {
     // (instance-major classes: lane j's instance sits j instances behind the wavefront's first one -- folded into the lane's 32-bit column offset)
@@ -169,10 +209,10 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
       s.attach_round_tables(t_leader, n_leader, t_dur, n_dur);
       s.attach_weights(t_weights);
       if (p.n > 16) {  // receiver / sender lists of process_node_actions: LDS instead of HBM rows
-        u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, CLS == 0 ? 8u : 12u, nwaves);
+        u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, SimT<CLS>::C0 ? 8u : 12u, nwaves);
         s.attach_peer_list(lists + ((size_t)wave * p.lpw + lane) * LBFT_MAX_NODES);
       }
-      if (CLS == 0 && p.n <= 4 && !SimT<CLS>::HCREG) {  // the nodes' hcbr buffers (same place as the receiver lists of large networks)
+      if (SimT<CLS>::C0 && p.n <= 4 && !SimT<CLS>::HCREG) {  // the nodes' hcbr buffers (same place as the receiver lists of large networks)
         u32* hcb = reinterpret_cast<u32*>(reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 8u, nwaves));
         s.attach_hcbr(hcb + (size_t)wave * LBFT_LDS_HCBR_WORDS * p.lpw + lane);
       }
@@ -214,6 +254,9 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
 // wavefront per SIMD and may use the whole register file (VGPRs + AGPRs).
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run0(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(0) run_body<0>(p, state, unfinished); }
+// ... and for small batches (at most LBFT_POPC_MAX_LPW networks per wavefront): the pop's scan by all 64 lanes (SimT<8>)
+__global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
+void lbft_k_run0s(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(8) run_body<8>(p, state, unfinished); }
 // Large networks without record exchange / trace / lossy network (sim_lean()): also two wavefronts per SIMD (4 spilled registers)
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run2l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(5) run_body<5>(p, state, unfinished); }
@@ -446,6 +489,11 @@ static thread_local std::string g_err;
 // wavefronts overlap each other's dependent round trips, and at 256 registers every staged word is a spilled one (16 384 x 64 nodes:
 // 451 ms; with the staging 476-511 ms; the full-register kernel with twice the lanes 503 ms; 8 192 x 100 nodes: 2.49 / 2.75-2.85 / 2.85 s).
 // Tuning knobs: LBFT_NO_LEAN=1 = always the full-register kernels; LBFT_LEAN2=0 = the full-register kernel for large networks.
+// class-0 batches with few networks per wavefront run lbft_k_run0s (wavefront-wide pop); LBFT_NO_POPC=1: lbft_k_run0 for every batch size
+static bool small_batch_kernel(const Params& p) {
+  const char* e = getenv("LBFT_NO_POPC");
+  return LBFT_C0_POPC && !LBFT_C0_QLANE && sim_class(p) == 0 && p.lpw <= LBFT_POPC_MAX_LPW && p.ql > 0 && !(e && atoi(e));
+}
 static bool lean_allowed() { const char* e = getenv("LBFT_NO_LEAN"); return !(e && atoi(e)); }
 static bool lean2_allowed() { const char* e = getenv("LBFT_LEAN2"); return lean_allowed() && !(e && !atoi(e)); }
 
@@ -960,7 +1008,7 @@ int lbft_batch_layout(const lbft_batch* b, uint32_t* out) {
   out[5] = p.ql;              // event-queue slots per instance resident in LDS
   out[6] = p.lpw;             // lanes per wavefront carrying an instance
   out[7] = (uint32_t)sim_class(p) | (p.qheap << 8) | (p.qcal << 9) | ((((sim_lean(p) && lean2_allowed()) || (sim_lean1(p) && lean_allowed())) ? 1u : 0u) << 10) | ((p.ring ? 1u : 0u) << 11) |
-           (((sim_lean_q1(p) && lean2_allowed()) ? 1u : 0u) << 12);
+           (((sim_lean_q1(p) && lean2_allowed()) ? 1u : 0u) << 12) | ((small_batch_kernel(p) ? 1u : 0u) << 13);
   return LBFT_OK;
 }
 
@@ -1150,7 +1198,8 @@ static int launch_run(lbft_batch* b) {
   int cls = sim_class(p);
   bool lean = sim_lean(p) && lean2_allowed(), lean1 = sim_lean1(p) && lean_allowed();
   const bool leanq = lean && sim_lean_q1(p);
-  const void* run_fn = leanq ? reinterpret_cast<const void*>(lbft_k_run2q) : lean ? reinterpret_cast<const void*>(lbft_k_run2l) : lean1 ? reinterpret_cast<const void*>(lbft_k_run1l) : cls == 0 ? reinterpret_cast<const void*>(lbft_k_run0)
+  const bool small0 = small_batch_kernel(p);
+  const void* run_fn = leanq ? reinterpret_cast<const void*>(lbft_k_run2q) : lean ? reinterpret_cast<const void*>(lbft_k_run2l) : lean1 ? reinterpret_cast<const void*>(lbft_k_run1l) : (cls == 0 && small0) ? reinterpret_cast<const void*>(lbft_k_run0s) : cls == 0 ? reinterpret_cast<const void*>(lbft_k_run0)
                      : cls == 1 ? reinterpret_cast<const void*>(lbft_k_run<1>) : reinterpret_cast<const void*>(lbft_k_run<2>);
   HIP_TRY(hipFuncSetAttribute(run_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
   const u32 nwaves = b->run_waves, block = 64u * nwaves;
@@ -1159,6 +1208,7 @@ static int launch_run(lbft_batch* b) {
   if (leanq) lbft_k_run2q<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (lean) lbft_k_run2l<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (lean1) lbft_k_run1l<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  else if (cls == 0 && small0) lbft_k_run0s<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (cls == 0) lbft_k_run0<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (cls == 1) lbft_k_run<1><<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else lbft_k_run<2><<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
