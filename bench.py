@@ -159,7 +159,7 @@ def run_kernel_name(kc):
     """The run kernel a batch executes, from lbft_batch_layout's flag word (include/lbft.h)."""
     cls = kc & 255
     if cls == 0:
-        return "lbft_k_run0s" if kc & 8192 else "lbft_k_run0"
+        return "lbft_k_run0s" if kc & 8192 else "lbft_k_run0q" if kc & 16384 else "lbft_k_run0"
     if kc & 1024:  # the two-wavefronts-per-SIMD kernels
         return ("lbft_k_run2q" if kc & 4096 else "lbft_k_run2l") if cls == 2 else "lbft_k_run1l"
     return "lbft_k_run<%d>" % cls

@@ -91,6 +91,9 @@ typedef int64_t i64;
 #ifndef LBFT_C0_POPC
 #define LBFT_C0_POPC 1   // small batches of class-0 networks run lbft_k_run0s (SimT<8>): the pop's scan by all 64 lanes of the wavefront
 #endif
+#ifndef LBFT_C0_QUAD
+#define LBFT_C0_QUAD 1   // large class-0 batches of 4-node networks with unit rights and log-normal delays run lbft_k_run0q (SimT<9>)
+#endif
 #ifndef LBFT_POPC_MAX_LPW
 #define LBFT_POPC_MAX_LPW 8u  // networks per wavefront up to which lbft_k_run0s is used (measured: 1 024 x 4: 6.3 against 7.5 ms, 8 192: 10.9 against 12.1,
                               // 16 384 (8 per wavefront): 14.8 against 15.9; 32 per wavefront: the lane-private scan stops at the queue's length and wins)
@@ -636,7 +639,20 @@ struct SimT {
   // other's scan (with both, lbft_k_run0 grew from 57.8 to 61.4 KB and the 65 536-network batch from 22.4 to 24.0 ms: the 64 KB
   // instruction cache again)
   static constexpr bool POPC = CLS == 8;
-  static constexpr bool C0 = CLS == 0 || CLS == 8;
+  // 9 = class 0 with the headline network fixed at compile time (lbft_k_run0q): 4 nodes, unit voting rights, log-normal delays, <= 64
+  // snapshot slots, no layout padding -- loop bounds, the quorum, record sizes and the first row offsets become immediates (sim_quad())
+  static constexpr bool QUAD = CLS == 9;  // (the small-batch kernel gains nothing from it: 1 024 x 4 6.2 against 5.8 ms, 8 192 x 4 10.0 against 9.9 -- latency-bound)
+  static constexpr bool C0 = CLS == 0 || CLS == 8 || CLS == 9;
+  LBFT_HD u32 NN() const { return QUAD ? 4u : P.n; }
+  LBFT_HD u32 MW() const { return QUAD ? 1u : P.mw; }
+  LBFT_HD u32 NWORDS() const { return QUAD ? NF_FIXED_WORDS + 8u : P.node_words; }
+  LBFT_HD u32 SWORDS() const { return QUAD ? S_FIXED_WORDS + 8u : P.snap_words; }
+  LBFT_HD u32 BWORDS() const { return QUAD ? (u32)B_WORDS : P.blk_words; }
+  LBFT_HD u32 OFFNODE() const { return QUAD ? (u32)I_WORDS : P.off_node; }
+  LBFT_HD u32 UNITW() const { return QUAD ? 1u : P.unit_weights; }
+  LBFT_HD u32 DMODEL() const { return QUAD ? 0u : P.delay_model; }
+  LBFT_HD u32 QUORUM() const { return QUAD ? 3u : P.quorum; }
+  LBFT_HD u32 ROT() const { return QUAD ? 0u : P.rot; }
   static constexpr bool C0I = C0 && LBFT_C0_IMAJOR != 0;
   static constexpr bool TILE64 = (C0 && !C0I) || CLS == 1 || CLS == 6;
   static constexpr bool HCREG = C0I && LBFT_C0_HCREG != 0;
@@ -648,12 +664,12 @@ struct SimT {
   static constexpr bool RING = BIG || CLS == 3;
   bool coop_on;  // set by run_coop: the event loop is being run by a whole wavefront
   LBFT_HD bool coop() const { return COOP && coop_on && P.qcal != 0 && P.ring != 0 && !lossy(); }
-  LBFT_HD bool wide() const { return BIG ? true : (CLS == 3 ? P.n > 32 : false); }
+  LBFT_HD bool wide() const { return BIG ? true : (CLS == 3 ? NN() > 32 : false); }
   LBFT_HD bool heap() const { return C0 ? false : (BIG ? true : P.qheap != 0); }
   LBFT_HD bool tracing() const { return !C0 && !LEAN && P.rcap != 0; }  // round-switch trace (DataWriter); class 0 never traces
   LBFT_HD bool q1() const { return !C0 && (!LEAN || CLS == 7) && (P.quirks & 1u) != 0; }  // requests are answered by the peer with real payloads
   LBFT_HD bool cal() const { return !C0 && P.qcal != 0; }
-  LBFT_HD bool packed() const { return C0 ? true : (BIG ? false : P.n <= 16); }
+  LBFT_HD bool packed() const { return C0 ? true : (BIG ? false : NN() <= 16); }
   LBFT_HD bool qpacked() const { return C0 ? true : (CLS == 3 ? P.qpack != 0 : false); }  // one-word queue entries
   const Params& P;
   char* tile;
@@ -720,11 +736,11 @@ struct SimT {
   // node burst (every hcbr access is for the node of the current event); indices stay compile-time (value selects).
   mutable u32 hcw[8];
   mutable u32 hcdirty;
-  LBFT_HD bool hc_reg() const { return HCREG && P.n <= 4; }
+  LBFT_HD bool hc_reg() const { return HCREG && NN() <= 4; }
   LBFT_HD void hc_load(u32 nb) const {
     if (!hc_reg()) return;
     hcdirty = 0;
-    if (P.n == 4) {
+    if (NN() == 4) {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -733,12 +749,12 @@ struct SimT {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (u32 k = 0; k < 8; k++) hcw[k] = (k & 3u) < P.n ? ldf(nb, NF_FIXED_WORDS + (k >> 2) * P.n + (k & 3u)) : 0u;
+      for (u32 k = 0; k < 8; k++) hcw[k] = (k & 3u) < NN() ? ldf(nb, NF_FIXED_WORDS + (k >> 2) * NN() + (k & 3u)) : 0u;
     }
   }
   LBFT_HD void hc_store(u32 nb) const {
     if (!hc_reg() || !hcdirty) return;
-    if (P.n == 4) {
+    if (NN() == 4) {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -747,7 +763,7 @@ struct SimT {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (u32 k = 0; k < 8; k++) if ((k & 3u) < P.n) stf(nb, NF_FIXED_WORDS + (k >> 2) * P.n + (k & 3u), hcw[k]);
+      for (u32 k = 0; k < 8; k++) if ((k & 3u) < NN()) stf(nb, NF_FIXED_WORDS + (k >> 2) * NN() + (k & 3u), hcw[k]);
     }
   }
   LBFT_HD u32 hc_get(u32 node, u32 buf, u32 a) const {
@@ -758,7 +774,7 @@ struct SimT {
       return (idx & 4u) ? v47 : v03;
     }
     if (hc_lds()) return hc[(node * 8u + buf * 4u + a) << hsh];
-    return nfm(node, NF_FIXED_WORDS + buf * P.n + a);
+    return nfm(node, NF_FIXED_WORDS + buf * NN() + a);
   }
   LBFT_HD void hc_set(u32 node, u32 buf, u32 a, u32 v) const {
     if (hc_reg()) {
@@ -771,17 +787,17 @@ struct SimT {
       return;
     }
     if (hc_lds()) hc[(node * 8u + buf * 4u + a) << hsh] = v;
-    else nfms(node, NF_FIXED_WORDS + buf * P.n + a, v);
+    else nfms(node, NF_FIXED_WORDS + buf * NN() + a, v);
   }
   LBFT_HD void hcbr_to_lds() const {
     if (!hc_lds()) return;
-    for (u32 node = 0; node < P.n; node++)
-      for (u32 k = 0; k < 2 * P.n; k++) hc[(node * 8u + (k / P.n) * 4u + k % P.n) << hsh] = nfm(node, NF_FIXED_WORDS + k);
+    for (u32 node = 0; node < NN(); node++)
+      for (u32 k = 0; k < 2 * NN(); k++) hc[(node * 8u + (k / NN()) * 4u + k % NN()) << hsh] = nfm(node, NF_FIXED_WORDS + k);
   }
   LBFT_HD void hcbr_from_lds() const {
     if (!hc_lds()) return;
-    for (u32 node = 0; node < P.n; node++)
-      for (u32 k = 0; k < 2 * P.n; k++) nfms(node, NF_FIXED_WORDS + k, hc[(node * 8u + (k / P.n) * 4u + k % P.n) << hsh]);
+    for (u32 node = 0; node < NN(); node++)
+      for (u32 k = 0; k < 2 * NN(); k++) nfms(node, NF_FIXED_WORDS + k, hc[(node * 8u + (k / NN()) * 4u + k % NN()) << hsh]);
   }
   LBFT_HD void attach_tables(const u64* zx, const u64* zf, const u64* et) { zig_x = zx; zig_f = zf; exp_tab = et; }
   LBFT_HD void attach_peer_list(u8* list) { plist_lds = list; }
@@ -810,7 +826,7 @@ struct SimT {
   }
 
   // ---- field accessors ----
-  LBFT_HD u32 nfw(u32 node, u32 f) const { return P.off_node + node * P.node_words + f; }
+  LBFT_HD u32 nfw(u32 node, u32 f) const { return OFFNODE() + node * NWORDS() + f; }
   // direct (memory) access to any node's rows
   LBFT_HD u32 nfm(u32 node, u32 f) const { return ld(nfw(node, f)); }
   LBFT_HD void nfms(u32 node, u32 f, u32 v) const { st(nfw(node, f), v); }
@@ -819,15 +835,33 @@ struct SimT {
   // reorder row loads across row stores) and the modified ones are written back by end_node().
   // `f` is a compile-time constant at every call site, so cw[] lives in VGPRs.
   mutable u32 cw[NF_FIXED_WORDS];
-  mutable u64 cdirty;
+  // rows are written back by groups of fields that change together: 6 tests instead of 41 (A/B on the 65536 x 4 batch in one GPU call:
+  // 24.6 ms vs 25.1 ms per row; writing all rows unconditionally had measured 9 % slower).  cdirty holds one bit per GROUP.
+  static constexpr u32 NGROUPS = 6;
+  static constexpr u64 group_mask(u32 g) {
+    return g == 0 ? (1ULL << NF_IGNORE_UNTIL) | (1ULL << NF_LAST_TIMER_T) | (1ULL << NF_TIMER_DUPS) | (1ULL << NF_DUP_STAMP)
+         : g == 1 ? (1ULL << NF_PROPOSED_BLK) | (1ULL << NF_CUR_ROUND) | (1ULL << NF_TO_MASK) | (1ULL << NF_TO_WEIGHT) | (1ULL << NF_ELECTION) |
+                    (1ULL << NF_BAL0_BLK) | (1ULL << NF_BAL0_WEIGHT) | (1ULL << NF_BAL0_AUTHORS) | (1ULL << NF_BAL1_BLK) | (1ULL << NF_BAL1_WEIGHT) | (1ULL << NF_BAL1_AUTHORS)
+         : g == 2 ? (1ULL << NF_HQC_ROUND) | (1ULL << NF_HQC_BLK) | (1ULL << NF_HTC_ROUND) | (1ULL << NF_HC_ROUND) | (1ULL << NF_HCC_BLK) | (1ULL << NF_TC_MASK) | (1ULL << NF_TC_SEL)
+         : g == 3 ? (1ULL << NF_PM_EPOCH) | (1ULL << NF_PM_ROUND) | (1ULL << NF_PM_LEADER) | (1ULL << NF_PM_START) | (1ULL << NF_PM_DUR_LO) | (1ULL << NF_PM_DUR_HI)
+         : g == 4 ? (1ULL << NF_LVR) | (1ULL << NF_LOCKED) | (1ULL << NF_LQAT) | (1ULL << NF_TR_EPOCH) | (1ULL << NF_TR_HCR) | (1ULL << NF_TR_LCT) |
+                    (1ULL << NF_NEXT_CMD) | (1ULL << NF_LAST_COMMITTED_BLK) | (1ULL << NF_NCOMMITS)
+                  : (1ULL << NF_STARTUP) | (1ULL << NF_EPOCH) | (1ULL << NF_INIT_STATE_BLK) | (1ULL << NF_PREV_EPOCH_HCC);
+  }
+  static constexpr u32 group_of(u32 f) {
+    return (group_mask(0) >> f) & 1 ? 0u : (group_mask(1) >> f) & 1 ? 1u : (group_mask(2) >> f) & 1 ? 2u : (group_mask(3) >> f) & 1 ? 3u : (group_mask(4) >> f) & 1 ? 4u : 5u;
+  }
+  static_assert(NF_FIXED_WORDS == 41 && (group_mask(0) | group_mask(1) | group_mask(2) | group_mask(3) | group_mask(4) | group_mask(5)) == (1ULL << 41) - 1,
+                "every fixed word belongs to a write-back group");
+  mutable u32 cdirty;
   LBFT_HD u32 nf(u32 node, u32 f) const { return f < NF_FIXED_WORDS ? cw[f] : ld(nfw(node, f)); }
   LBFT_HD void nfs(u32 node, u32 f, u32 v) const {
-    if (f < NF_FIXED_WORDS) { cw[f] = v; cdirty |= 1ULL << f; }
+    if (f < NF_FIXED_WORDS) { cw[f] = v; cdirty |= 1u << group_of(f); }
     else st(nfw(node, f), v);
   }
   LBFT_HD void begin_node(u32 node) const {
     // one base pointer, then constant row offsets: the 38 loads become one burst with immediate offsets
-    u32 nb = boff(P.off_node + node * P.node_words);
+    u32 nb = boff(OFFNODE() + node * NWORDS());
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -838,41 +872,21 @@ struct SimT {
   }
   LBFT_HD void end_node(u32 node) const {
     ax_store(node);
-    u32 nb = boff(P.off_node + node * P.node_words);
+    u32 nb = boff(OFFNODE() + node * NWORDS());
     hc_store(nb);
-#if !defined(LBFT_END_NODE_PER_ROW)
-    // rows are written back by groups of fields that change together: 6 tests instead of 41 (A/B on the 65536 x 4 batch in
-    // one GPU call: 24.6 ms vs 25.1 ms per-row; writing all rows unconditionally had measured 9 % slower)
-    const u64 G[6] = {
-      (1ULL << NF_IGNORE_UNTIL) | (1ULL << NF_LAST_TIMER_T) | (1ULL << NF_TIMER_DUPS) | (1ULL << NF_DUP_STAMP),
-      (1ULL << NF_PROPOSED_BLK) | (1ULL << NF_CUR_ROUND) | (1ULL << NF_TO_MASK) | (1ULL << NF_TO_WEIGHT) | (1ULL << NF_ELECTION) |
-          (1ULL << NF_BAL0_BLK) | (1ULL << NF_BAL0_WEIGHT) | (1ULL << NF_BAL0_AUTHORS) | (1ULL << NF_BAL1_BLK) | (1ULL << NF_BAL1_WEIGHT) | (1ULL << NF_BAL1_AUTHORS),
-      (1ULL << NF_HQC_ROUND) | (1ULL << NF_HQC_BLK) | (1ULL << NF_HTC_ROUND) | (1ULL << NF_HC_ROUND) | (1ULL << NF_HCC_BLK) | (1ULL << NF_TC_MASK) | (1ULL << NF_TC_SEL),
-      (1ULL << NF_PM_EPOCH) | (1ULL << NF_PM_ROUND) | (1ULL << NF_PM_LEADER) | (1ULL << NF_PM_START) | (1ULL << NF_PM_DUR_LO) | (1ULL << NF_PM_DUR_HI),
-      (1ULL << NF_LVR) | (1ULL << NF_LOCKED) | (1ULL << NF_LQAT) | (1ULL << NF_TR_EPOCH) | (1ULL << NF_TR_HCR) | (1ULL << NF_TR_LCT) |
-          (1ULL << NF_NEXT_CMD) | (1ULL << NF_LAST_COMMITTED_BLK) | (1ULL << NF_NCOMMITS),
-      (1ULL << NF_STARTUP) | (1ULL << NF_EPOCH) | (1ULL << NF_INIT_STATE_BLK) | (1ULL << NF_PREV_EPOCH_HCC)};
-    static_assert(NF_FIXED_WORDS == 41, "field groups of end_node need updating");
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (u32 g = 0; g < 6; g++)
-      if (cdirty & G[g]) {
+    for (u32 g = 0; g < NGROUPS; g++)
+      if ((cdirty >> g) & 1u) {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
         for (u32 f = 0; f < NF_FIXED_WORDS; f++)
-          if ((G[g] >> f) & 1ULL) stf(nb, f, cw[f]);
+          if ((group_mask(g) >> f) & 1ULL) stf(nb, f, cw[f]);
       }
-#else
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (u32 f = 0; f < NF_FIXED_WORDS; f++)
-      if ((cdirty >> f) & 1ULL) stf(nb, f, cw[f]);
-#endif
   }
-  LBFT_HD u32 bfw(u32 b, u32 f) const { return P.off_blk + (b - 1) * P.blk_words + f; }
+  LBFT_HD u32 bfw(u32 b, u32 f) const { return P.off_blk + (b - 1) * BWORDS() + f; }
   LBFT_HD u32 bf(u32 b, u32 f) const { return ld(bfw(b, f)); }   // cold fields (B_TIME, B_CMD) and read-back
   LBFT_HD void bfs(u32 b, u32 f, u32 v) const { st(bfw(b, f), v); }
   LBFT_HD u32 blk_author(u32 b) const { return bf(b, B_LINK) >> 16; }
@@ -973,7 +987,7 @@ struct SimT {
   }
   // Node sets of a block (B_KNOWN / B_QC / B_PEND): nodes 0..31 live in the hot record, nodes >= 32 (n > 32
   // only) in extension rows behind the cold fields.
-  LBFT_HD u32 bxw(u32 b, u32 f, u32 k) const { return bfw(b, B_WORDS + (f - B_KNOWN) * (P.mw - 1) + k - 1); }
+  LBFT_HD u32 bxw(u32 b, u32 f, u32 k) const { return bfw(b, B_WORDS + (f - B_KNOWN) * (MW() - 1) + k - 1); }
   // (one round trip for the three words of this record copy instead of one per test / update)
   LBFT_HD void bx_fetch(u32 b, const Blk& rb, u32 k) const {
     if (rb.xk == k) return;
@@ -1017,9 +1031,9 @@ struct SimT {
       else bc_w[e][B_PEND] = hit ? v : bc_w[e][B_PEND];
     }
   }
-  LBFT_HD u32 sfw(u32 slot, u32 f) const { return P.off_snap + slot * P.snap_words + f; }
+  LBFT_HD u32 sfw(u32 slot, u32 f) const { return P.off_snap + slot * SWORDS() + f; }
   // extension word k >= 1 of a snapshot's TC (which = 0) / current-timeout (which = 1) author set
-  LBFT_HD u32 sxw(u32 slot, u32 which, u32 k) const { return sfw(slot, S_FIXED_WORDS + 2 * P.n + which * (P.mw - 1) + k - 1); }
+  LBFT_HD u32 sxw(u32 slot, u32 which, u32 k) const { return sfw(slot, S_FIXED_WORDS + 2 * NN() + which * (MW() - 1) + k - 1); }
 
   LBFT_HD void load_scalars() {
     clock = (i32)ld(I_CLOCK); stamp = ld(I_STAMP);
@@ -1107,7 +1121,7 @@ struct SimT {
     return f64_to_i64_sat(lbft_exp(y, exp_tab));
   }
   LBFT_HD i64 sample_delay() {
-    if (P.delay_model == 1) return P.uni_lo + (i64)rng.gen_range_u64(P.uni_span);
+    if (DMODEL() == 1) return P.uni_lo + (i64)rng.gen_range_u64(P.uni_span);
     double nrm = standard_normal();
     return trunc_exp(P.mu + P.sigma * nrm);
   }
@@ -1395,7 +1409,7 @@ struct SimT {
   }
   // (the register-resident free mask serves batches of <= 64 slots; the two-wavefront large-network kernel never has that few and
   // keeps the mask out of its registers)
-  LBFT_HD bool mask_slots() const { return LEAN2 ? false : P.scap <= 64; }
+  LBFT_HD bool mask_slots() const { return QUAD ? true : LEAN2 ? false : P.scap <= 64; }
   LBFT_HD void snap_free_slot(u32 slot) {
     if (mask_slots()) snap_mask |= 1ULL << slot;
     else { st(P.off_snap_free + snap_free, slot); snap_free++; }
@@ -1435,11 +1449,11 @@ struct SimT {
   // EpochConfiguration of the node's current epoch (extension "rotating voting rights": shifted by epoch * rot)
   // (32-bit arithmetic: epochs are bounded by the block capacity 65534 and rot < n <= 128; a 64-bit modulo is a ~200-instruction
   // software division inlined at every use)
-  LBFT_HD u32 rights_shift(u32 node) const { return P.rot ? (nf(node, NF_EPOCH) * P.rot) % P.n : 0u; }
+  LBFT_HD u32 rights_shift(u32 node) const { return ROT() ? (nf(node, NF_EPOCH) * ROT()) % NN() : 0u; }
   LBFT_HD u32 weight(u32 node, u32 author) const {  // vector load from a small table
-    if (P.unit_weights) return 1u;
+    if (UNITW()) return 1u;
     u32 i = author + rights_shift(node);
-    return wtab[i >= P.n ? i - P.n : i];
+    return wtab[i >= NN() ? i - NN() : i];
   }
 
   // ---- leader / duration ----
@@ -1453,7 +1467,7 @@ struct SimT {
       const u8* tab = (round < leader_lds_len && shift == 0) ? leader_lds : P.leader_tab + (size_t)shift * P.leader_len;
       return tab[round];
     }
-    return compute_leader(P.weights, P.n, P.total_votes, round, shift);
+    return compute_leader(P.weights, NN(), P.total_votes, round, shift);
   }
 
   // ---- SimulatedContext (simulated_context.rs:102-158): is the ledger state `blk` available? ----
@@ -1488,7 +1502,7 @@ struct SimT {
   // ---- author sets of a node (NF_TC_MASK, NF_TO_MASK, NF_BAL0_AUTHORS, NF_BAL1_AUTHORS): authors 0..31 in
   // the cached fixed rows, authors >= 32 (n > 32 only) in extension rows behind the hcbr buffers ----
   LBFT_HD u32 am_idx(u32 f) const { return f == NF_TC_MASK ? 0u : f == NF_TO_MASK ? 1u : f == NF_BAL0_AUTHORS ? 2u : 3u; }
-  LBFT_HD u32 amxw(u32 node, u32 f, u32 k) const { return nfw(node, NF_FIXED_WORDS + 2 * P.n + am_idx(f) * (P.mw - 1) + k - 1); }
+  LBFT_HD u32 amxw(u32 node, u32 f, u32 k) const { return nfw(node, NF_FIXED_WORDS + 2 * NN() + am_idx(f) * (MW() - 1) + k - 1); }
   // Words 1..3 of the four sets are staged in registers with the fixed rows (begin_node / end_node): a read-modify-write of
   // an extension row would otherwise be one dependent memory round trip per author >= 32 in every vote / timeout insertion
   // (64-node networks: half of all authors).  Indices are kept compile-time after unrolling (value selects, not dynamically
@@ -1498,7 +1512,7 @@ struct SimT {
   LBFT_HD void ax_load(u32 node) const {
     axdirty = 0;
     if (!F_AX || !wide()) return;
-    u32 base = nfw(node, NF_FIXED_WORDS + 2 * P.n);
+    u32 base = nfw(node, NF_FIXED_WORDS + 2 * NN());
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -1507,9 +1521,9 @@ struct SimT {
 #pragma unroll
 #endif
       for (u32 k = 0; k < 3; k++) {  // (unconditional loads of a clamped row, then a select: one burst with the fixed rows)
-        u32 kk = k + 1 < P.mw ? k : 0;
-        u32 v = ld(base + i * (P.mw - 1) + kk);
-        ax[i][k] = k + 1 < P.mw ? v : 0u;
+        u32 kk = k + 1 < MW() ? k : 0;
+        u32 v = ld(base + i * (MW() - 1) + kk);
+        ax[i][k] = k + 1 < MW() ? v : 0u;
       }
     }
   }
@@ -1523,7 +1537,7 @@ struct SimT {
 #pragma unroll
 #endif
       for (u32 k = 0; k < 3; k++)
-        if ((axdirty >> (i * 3 + k)) & 1u) st(nfw(node, NF_FIXED_WORDS + 2 * P.n + i * (P.mw - 1) + k), ax[i][k]);
+        if ((axdirty >> (i * 3 + k)) & 1u) st(nfw(node, NF_FIXED_WORDS + 2 * NN() + i * (MW() - 1) + k), ax[i][k]);
     }
   }
   LBFT_HD u32 ax_get(u32 i, u32 k) const {  // k = 1..3
@@ -1563,11 +1577,11 @@ struct SimT {
   }
   LBFT_HD void am_clear(u32 node, u32 f) const {
     nfs(node, f, 0);
-    for (u32 k = 1; wide() && k < P.mw; k++) am_set_word(node, f, k, 0);
+    for (u32 k = 1; wide() && k < MW(); k++) am_set_word(node, f, k, 0);
   }
   LBFT_HD void am_copy(u32 node, u32 dst, u32 src) const {
     nfs(node, dst, nf(node, src));
-    for (u32 k = 1; wide() && k < P.mw; k++) am_set_word(node, dst, k, am_word(node, src, k));
+    for (u32 k = 1; wide() && k < MW(); k++) am_set_word(node, dst, k, am_word(node, src, k));
   }
 
   // ---- RecordStoreState ----
@@ -1639,7 +1653,7 @@ struct SimT {
       if (ongoing) {
         u32 w = nf(node, NF_BAL0_WEIGHT) + weight(node, author);
         nfs(node, NF_BAL0_WEIGHT, w);
-        if (w >= P.quorum) nfs(node, NF_ELECTION, 1u | (b << 8));
+        if (w >= QUORUM()) nfs(node, NF_ELECTION, 1u | (b << 8));
       }
     } else if (b1 == b || b1 == 0) {
       nfs(node, NF_BAL1_BLK, b);
@@ -1647,7 +1661,7 @@ struct SimT {
       if (ongoing) {
         u32 w = nf(node, NF_BAL1_WEIGHT) + weight(node, author);
         nfs(node, NF_BAL1_WEIGHT, w);
-        if (w >= P.quorum) nfs(node, NF_ELECTION, 1u | (b << 8));
+        if (w >= QUORUM()) nfs(node, NF_ELECTION, 1u | (b << 8));
       }
     } else {
       fault |= F_BALLOT_OVERFLOW;  // (never with honest voters: two ballot entries hold any round's votes)
@@ -1664,7 +1678,7 @@ struct SimT {
     hc_set(node, 1u - tc_sel, author, hcbr);
     u32 w = nf(node, NF_TO_WEIGHT) + weight(node, author);
     nfs(node, NF_TO_WEIGHT, w);
-    if (w >= P.quorum) {
+    if (w >= QUORUM()) {
       // the current timeouts become the timeout certificate (record_store.rs:532-534): swap the buffers
       // instead of copying n words; the other buffer's stale entries are masked by the now-empty TO mask
       am_copy(node, NF_TC_MASK, NF_TO_MASK);
@@ -1732,7 +1746,7 @@ struct SimT {
     bfs(b, B_TIME, (u32)(i32)local_clock);
     bfs(b, B_CMD, cmd);
     bfs(b, B_VOTERS, 0);
-    for (u32 k = 0; wide() && k < 4 * (P.mw - 1); k++) bfs(b, B_WORDS + k, 0);
+    for (u32 k = 0; wide() && k < 4 * (MW() - 1); k++) bfs(b, B_WORDS + k, 0);
     blk_cache_insert(b, rb);
     insert_block(node, b, rb);
   }
@@ -1752,9 +1766,9 @@ struct SimT {
     nfs(node, NF_ELECTION, 2);
     // the QC's votes = the current votes for the winning (block, state) (record_store.rs:716-727): the ballot entry of b
     bool first = nf(node, NF_BAL0_BLK) == b;  // (field indices stay compile-time constants: the node cache lives in registers)
-    for (u32 k = 0; k < P.mw; k++) {
+    for (u32 k = 0; k < MW(); k++) {
       u32 v = first ? am_word(node, NF_BAL0_AUTHORS, k) : am_word(node, NF_BAL1_AUTHORS, k);
-      st(k == 0 ? bfw(b, B_VOTERS) : bfw(b, B_WORDS + 3 * (P.mw - 1) + k - 1), v);
+      st(k == 0 ? bfw(b, B_VOTERS) : bfw(b, B_WORDS + 3 * (MW() - 1) + k - 1), v);
     }
     insert_qc(node, b, rb);
     return true;
@@ -1910,7 +1924,7 @@ struct SimT {
     const u32 row = nfw(node, NF_FIXED_WORDS), tail = P.rarch_words - NF_FIXED_WORDS;
     if (hc_lds()) {
       for (u32 buf = 0; buf < 2; buf++)
-        for (u32 a = 0; a < P.n; a++) st(base + NF_FIXED_WORDS + buf * P.n + a, hc_get(node, buf, a));
+        for (u32 a = 0; a < NN(); a++) st(base + NF_FIXED_WORDS + buf * NN() + a, hc_get(node, buf, a));
     } else {
       for (u32 k = 0; k < tail; k++) st(base + NF_FIXED_WORDS + k, ld(row + k));
     }
@@ -2047,7 +2061,7 @@ struct SimT {
   // instead of simulator.rs:446) with the records the requester lacks (data_sync.rs:183-207, record_store.rs:766-831).
   // All records are immutable and live in the instance's block pool, so a response is described by the certificates
   // heading the peer's chains plus its timeouts and proposed block -- the same words as a notification snapshot. ----
-  LBFT_HD u32 sqw(u32 base, u32 k) const { return base + S_FIXED_WORDS + 2 * P.n + 2 * (P.mw - 1) + k; }
+  LBFT_HD u32 sqw(u32 base, u32 k) const { return base + S_FIXED_WORDS + 2 * NN() + 2 * (MW() - 1) + k; }
   // RecordStoreState as seen by unknown_records: written into `base` (a snapshot slot or an epoch-archive entry)
   // `skip_hcbr`: the caller has the timeouts' hcbr words copied by all lanes of the wavefront (coop_copy_hcbr_to)
   LBFT_HD void write_store_snapshot(u32 node, u32 base, bool skip_hcbr = false) const {
@@ -2058,18 +2072,18 @@ struct SimT {
     st(base + S_TC_ROUND, htc);
     st(base + S_TO_ROUND, nf(node, NF_CUR_ROUND));
     u32 tc_sel = nf(node, NF_TC_SEL);
-    for (u32 k = 0; k < P.mw; k++) {
+    for (u32 k = 0; k < MW(); k++) {
       u32 tk = htc ? am_word(node, NF_TC_MASK, k) : 0, ok = am_word(node, NF_TO_MASK, k);
-      st(k == 0 ? base + S_TC_MASK : base + S_FIXED_WORDS + 2 * P.n + (k - 1), tk);
-      st(k == 0 ? base + S_TO_MASK : base + S_FIXED_WORDS + 2 * P.n + (P.mw - 1) + (k - 1), ok);
+      st(k == 0 ? base + S_TC_MASK : base + S_FIXED_WORDS + 2 * NN() + (k - 1), tk);
+      st(k == 0 ? base + S_TO_MASK : base + S_FIXED_WORDS + 2 * NN() + (MW() - 1) + (k - 1), ok);
       // (several loads in flight per round trip: a load-store-load-store chain is one memory round trip per author)
       if (!skip_hcbr) {
         copy_hcbr_to(node, base + S_FIXED_WORDS, tk, 32 * k, tc_sel);
-        copy_hcbr_to(node, base + S_FIXED_WORDS + P.n, ok, 32 * k, 1u - tc_sel);
+        copy_hcbr_to(node, base + S_FIXED_WORDS + NN(), ok, 32 * k, 1u - tc_sel);
       }
     }
   }
-  LBFT_HD u32 arch_base(u32 node, u32 epoch) const { return P.off_arch + (node * P.ecap + epoch) * P.snap_words; }
+  LBFT_HD u32 arch_base(u32 node, u32 epoch) const { return P.off_arch + (node * P.ecap + epoch) * SWORDS(); }
   // known_quorum_certificate_rounds (record_store.rs:766-799) of the requester: the rounds at positions 0, 1, 3, 7, 15, ... of
   // the chains below its highest quorum certificate and its highest commit certificate.  unknown_records asks "is round R
   // known?" for the rounds of the peer's chains, which only ever DEScend along a chain -- so each (peer chain, requester
@@ -2149,15 +2163,15 @@ struct SimT {
     // moves forward while a set is inserted (see handle_notification): a set of another round is skipped as a whole, the
     // authors the node already holds are not fetched, the others several per round trip.
     u32 tc_round = ld(base + S_TC_ROUND), to_round = ld(base + S_TO_ROUND);
-    for (u32 k = 0; k < P.mw; k++) {
+    for (u32 k = 0; k < MW(); k++) {
       if (tc_round != nf(node, NF_CUR_ROUND)) break;
-      u32 tk = ld(k == 0 ? base + S_TC_MASK : base + S_FIXED_WORDS + 2 * P.n + (k - 1));
+      u32 tk = ld(k == 0 ? base + S_TC_MASK : base + S_FIXED_WORDS + 2 * NN() + (k - 1));
       insert_timeouts_at(node, base + S_FIXED_WORDS, tk, tc_round, 32 * k);
     }
-    for (u32 k = 0; k < P.mw; k++) {
+    for (u32 k = 0; k < MW(); k++) {
       if (to_round != nf(node, NF_CUR_ROUND)) break;
-      u32 ok = ld(k == 0 ? base + S_TO_MASK : base + S_FIXED_WORDS + 2 * P.n + (P.mw - 1) + (k - 1));
-      insert_timeouts_at(node, base + S_FIXED_WORDS + P.n, ok, to_round, 32 * k);
+      u32 ok = ld(k == 0 ? base + S_TO_MASK : base + S_FIXED_WORDS + 2 * NN() + (MW() - 1) + (k - 1));
+      insert_timeouts_at(node, base + S_FIXED_WORDS + NN(), ok, to_round, 32 * k);
     }
     // the proposed block, unless the burst above found it known to the node already (a bit that is only ever set)
     if (pb && !((pbk >> (node & 31u)) & 1u)) insert_block(node, pb);
@@ -2186,7 +2200,7 @@ struct SimT {
   // request it answers (epoch, certificates), in one burst.
   LBFT_HD Resp load_response(u32 slot) const {
     Resp rp;
-    u32 sb = boff(P.off_snap + slot * P.snap_words);
+    u32 sb = boff(P.off_snap + slot * SWORDS());
     rp.epoch = ldf(sb, S_EPOCH); rp.certs = ldf(sb, S_CERTS); rp.prop = ldf(sb, S_PROP_VOTE);
     u32 qb = sqw(sfw(slot, 0), 0);
     rp.req_epoch = ld(qb); rp.req_certs = ld(qb + 1);
@@ -2233,23 +2247,23 @@ struct SimT {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (u32 a = 0; a < 4; a++) if (a < P.n) st(sb + a, tc_sel ? hcw[4 + a] : hcw[a]);
+      for (u32 a = 0; a < 4; a++) if (a < NN()) st(sb + a, tc_sel ? hcw[4 + a] : hcw[a]);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (u32 a = 0; a < 4; a++) if (a < P.n) st(sb + P.n + a, tc_sel ? hcw[a] : hcw[4 + a]);
+      for (u32 a = 0; a < 4; a++) if (a < NN()) st(sb + NN() + a, tc_sel ? hcw[a] : hcw[4 + a]);
     } else
     if (!skip_hcbr) {
       copy_hcbr(node, slot, tcm, 0, tc_sel, S_FIXED_WORDS);
-      copy_hcbr(node, slot, tom, 0, 1u - tc_sel, S_FIXED_WORDS + P.n);
+      copy_hcbr(node, slot, tom, 0, 1u - tc_sel, S_FIXED_WORDS + NN());
     }
-    for (u32 k = 1; wide() && k < P.mw; k++) {  // authors >= 32 (n > 32 only): extension words of the two sets + their hcbr entries
+    for (u32 k = 1; wide() && k < MW(); k++) {  // authors >= 32 (n > 32 only): extension words of the two sets + their hcbr entries
       u32 tk = htc ? am_word(node, NF_TC_MASK, k) : 0, ok = am_word(node, NF_TO_MASK, k);
       st(sxw(slot, 0, k), tk);
       st(sxw(slot, 1, k), ok);
       if (!skip_hcbr) {
         copy_hcbr(node, slot, tk, 32 * k, tc_sel, S_FIXED_WORDS);
-        copy_hcbr(node, slot, ok, 32 * k, 1u - tc_sel, S_FIXED_WORDS + P.n);
+        copy_hcbr(node, slot, ok, 32 * k, 1u - tc_sel, S_FIXED_WORDS + NN());
       }
     }
   }
@@ -2266,7 +2280,7 @@ struct SimT {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (u32 q = 0; q < 4; q++) { tw_[q] = (q < P.mw && htc) ? am_word(node, NF_TC_MASK, q) : 0u; ow_[q] = q < P.mw ? am_word(node, NF_TO_MASK, q) : 0u; }
+      for (u32 q = 0; q < 4; q++) { tw_[q] = (q < MW() && htc) ? am_word(node, NF_TC_MASK, q) : 0u; ow_[q] = q < MW() ? am_word(node, NF_TO_MASK, q) : 0u; }
     }
     const u32 tc_sel = LBFT_UNI(sel_k, k);
     u32 tcw[4], tow[4];
@@ -2274,15 +2288,15 @@ struct SimT {
 #pragma unroll
 #endif
     for (u32 q = 0; q < 4; q++) { tcw[q] = LBFT_UNI(tw_[q], k); tow[q] = LBFT_UNI(ow_[q], k); }
-    const u32 src_tc = nfw(node, NF_FIXED_WORDS + tc_sel * P.n), src_to = nfw(node, NF_FIXED_WORDS + (1u - tc_sel) * P.n);
-    const u32 dst_tc = base + S_FIXED_WORDS, dst_to = base + S_FIXED_WORDS + P.n;
-    for (u32 a0 = 0; a0 < P.n; a0 += 64u) {
+    const u32 src_tc = nfw(node, NF_FIXED_WORDS + tc_sel * NN()), src_to = nfw(node, NF_FIXED_WORDS + (1u - tc_sel) * NN());
+    const u32 dst_tc = base + S_FIXED_WORDS, dst_to = base + S_FIXED_WORDS + NN();
+    for (u32 a0 = 0; a0 < NN(); a0 += 64u) {
       const u32 q0 = a0 >> 5;
       PL<u32> vt, vo, ht, ho;
       LBFT_FOR_LANES(l) {
         u32 wt = l < 32u ? tcw[q0] : tcw[q0 + 1], wo = l < 32u ? tow[q0] : tow[q0 + 1];
-        vt[l] = (a0 + l < P.n) ? (wt >> (l & 31u)) & 1u : 0u;
-        vo[l] = (a0 + l < P.n) ? (wo >> (l & 31u)) & 1u : 0u;
+        vt[l] = (a0 + l < NN()) ? (wt >> (l & 31u)) & 1u : 0u;
+        vo[l] = (a0 + l < NN()) ? (wo >> (l & 31u)) & 1u : 0u;
         ht[l] = vt[l] ? ldc(l4, src_tc + a0 + l) : 0u;
         ho[l] = vo[l] ? ldc(l4, src_to + a0 + l) : 0u;
       }
@@ -2298,10 +2312,10 @@ struct SimT {
   // fixed words, the slot's reference count and (networks of <= 4 nodes) the highest_certified_block_round of the
   // sender's current timeouts -- every later dependent fetch would be a memory round trip of its own, serialised
   // with those of the lanes on other paths.
-  LBFT_HD bool small_sets() const { return C0 && P.n <= 4; }
+  LBFT_HD bool small_sets() const { return C0 && NN() <= 4; }
   LBFT_HD Snap load_snapshot(u32 slot) const {
     Snap sn;
-    u32 sb = boff(P.off_snap + slot * P.snap_words);
+    u32 sb = boff(P.off_snap + slot * SWORDS());
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -2312,11 +2326,11 @@ struct SimT {
 #endif
     for (u32 a = 0; a < 4; a++) sn.to_hcbr[a] = 0;
     if (small_sets()) {
-      u32 hb = boff(P.off_snap + slot * P.snap_words + S_FIXED_WORDS + P.n);
+      u32 hb = boff(P.off_snap + slot * SWORDS() + S_FIXED_WORDS + NN());
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (u32 a = 0; a < 4; a++) sn.to_hcbr[a] = ldf(hb, a < P.n ? a : 0);
+      for (u32 a = 0; a < 4; a++) sn.to_hcbr[a] = ldf(hb, a < NN() ? a : 0);
     }
     return sn;
   }
@@ -2364,7 +2378,7 @@ struct SimT {
       if (tc_round == nf(node, NF_CUR_ROUND)) {
         LBFT_STAT(35);
         insert_timeouts(node, slot, S_FIXED_WORDS, sn.w[S_TC_MASK], tc_round);
-        for (u32 k = 1; wide() && k < P.mw; k++) insert_timeouts(node, slot, S_FIXED_WORDS, ld(sxw(slot, 0, k)), tc_round, 32 * k);
+        for (u32 k = 1; wide() && k < MW(); k++) insert_timeouts(node, slot, S_FIXED_WORDS, ld(sxw(slot, 0, k)), tc_round, 32 * k);
       }
       if (to_round == nf(node, NF_CUR_ROUND)) {
         if (sn.w[S_TO_MASK]) LBFT_STAT(36);
@@ -2375,8 +2389,8 @@ struct SimT {
             insert_timeout(node, a, to_round, h);
           }
         } else
-        insert_timeouts(node, slot, S_FIXED_WORDS + P.n, sn.w[S_TO_MASK], to_round);
-        for (u32 k = 1; wide() && k < P.mw; k++) insert_timeouts(node, slot, S_FIXED_WORDS + P.n, ld(sxw(slot, 1, k)), to_round, 32 * k);
+        insert_timeouts(node, slot, S_FIXED_WORDS + NN(), sn.w[S_TO_MASK], to_round);
+        for (u32 k = 1; wide() && k < MW(); k++) insert_timeouts(node, slot, S_FIXED_WORDS + NN(), ld(sxw(slot, 1, k)), to_round, 32 * k);
       }
       LBFT_MARK(23);
       if (vote) { LBFT_STAT(37); insert_vote(node, sender, vote, blk_get(vote)); }
@@ -2402,7 +2416,7 @@ struct SimT {
   u64 plist;
   u32 plist8;     // n <= 8 in kernel class 0: eight 4-bit entries (64-bit variable shifts cost three instructions each)
   u8* plist_lds;  // n > 16: this instance's 128-byte list in LDS (device); nullptr = the HBM row region
-  LBFT_HD bool packed8() const { return C0 && P.n <= 8; }
+  LBFT_HD bool packed8() const { return C0 && NN() <= 8; }
   LBFT_HD u32 peer(u32 i) const {
     if (packed8()) return (plist8 >> (4 * i)) & 15u;
     if (packed()) return (u32)(plist >> (4 * i)) & 15u;
@@ -2426,12 +2440,12 @@ struct SimT {
       plist = low | high;
     } else if (plist_lds) {
       u32 c = 0;
-      for (u32 i = 0; i < P.n; i++) if (i != node) plist_lds[c++] = (u8)i;
+      for (u32 i = 0; i < NN(); i++) if (i != node) plist_lds[c++] = (u8)i;
     } else {
       u32 c = 0;
-      for (u32 i = 0; i < P.n; i++) if (i != node) st(P.off_list + c++, i);
+      for (u32 i = 0; i < NN(); i++) if (i != node) st(P.off_list + c++, i);
     }
-    return P.n - 1;
+    return NN() - 1;
   }
   LBFT_HD void peers_shuffle(u32 cnt) {  // rand 0.8 SliceRandom::shuffle (no draws when cnt < 2)
     for (u32 i = cnt; i-- > 1;) {
@@ -2512,9 +2526,9 @@ struct SimT {
   LBFT_HD void send_loop(u32 node, u32 sender, const SendPlan& sp, const Actions& act) {
     u32 n_a = 0, n_b = 0;
     if (sp.have_actions) {
-      if (act.broadcast) n_a = P.n - 1;
+      if (act.broadcast) n_a = NN() - 1;
       else if (act.send_to >= 0 && (u32)act.send_to != node) n_a = 1;
-      if (act.query_all) n_b = P.n - 1;
+      if (act.query_all) n_b = NN() - 1;
     }
     u32 first_a = sp.response + sp.sync, first_b = first_a + n_a, total = first_b + n_b;
     // Cooperative kernels: a list of n - 1 messages (broadcast / query-all) is left to coop_bulk, which run_coop executes with
@@ -2623,7 +2637,7 @@ struct SimT {
   LBFT_HD void stc(u32 l4, u32 w, u32 v) const { *reinterpret_cast<u32*>(tile + (size_t)((IMAJOR ? (w << 2) : mul24(w, rowb())) + l4)) = v; }
   // the first try of sample_delay() on the draw `bits`: true = accepted (then d is the delay sample_delay() returns)
   LBFT_HD bool fast_delay(u64 bits, i64& d) const {
-    if (P.delay_model == 1) {
+    if (DMODEL() == 1) {
       u64 zone = (P.uni_span << clz64(P.uni_span)) - 1;
       d = P.uni_lo + (i64)mulhi64(bits, P.uni_span);
       return bits * P.uni_span <= zone;
@@ -2644,7 +2658,7 @@ struct SimT {
     const u32 l4 = LBFT_UNI(lane4, k);
     const u32 node = LBFT_UNI(bulk_node, k);
     const i32 clk = (i32)LBFT_UNI((u32)clock, k);
-    const u32 cnt = P.n - 1;
+    const u32 cnt = NN() - 1;
     const u32 kc = which ? 2u : 3u;  // 3 - Event kind (DataSyncNotify = 0, DataSyncRequest = 1): the bucket within a time
     const u32 ring_row = P.off_ring, ring_mask = P.ring - 1u;
     // leader: what the scalar loop decides at the start of a list
@@ -2917,10 +2931,10 @@ struct SimT {
       for (u32 i = 0; i < sizeof(name) - 1; i++) hq.byte((u32)name[i]);
       hq.u64le(epoch); hq.u64le(round); hq.u64le(bh); hq.u64le(state); hq.option(has_cs, cs);
       u32 votes = 0;
-      for (u32 w = 0; w < P.mw; w++) votes += popc64(ld(w == 0 ? bfw(y, B_VOTERS) : bfw(y, B_WORDS + 3 * (P.mw - 1) + w - 1)));
+      for (u32 w = 0; w < MW(); w++) votes += popc64(ld(w == 0 ? bfw(y, B_VOTERS) : bfw(y, B_WORDS + 3 * (MW() - 1) + w - 1)));
       hq.uleb(votes);
-      for (u32 w = 0; w < P.mw; w++)
-        for (u32 m = ld(w == 0 ? bfw(y, B_VOTERS) : bfw(y, B_WORDS + 3 * (P.mw - 1) + w - 1)); m; m &= m - 1) {
+      for (u32 w = 0; w < MW(); w++)
+        for (u32 m = ld(w == 0 ? bfw(y, B_VOTERS) : bfw(y, B_WORDS + 3 * (MW() - 1) + w - 1)); m; m &= m - 1) {
           u64 a = 32 * w + ctz32(m);  // (Author, Signature{author, hash of the vote}) (simulated_context.rs:22-23,259-261)
           hq.u64le(a); hq.u64le(a); hq.u64le(record_hash_vote(epoch, round, bh, state, has_cs, cs, a));
         }
@@ -2945,14 +2959,14 @@ struct SimT {
     last_node = 0; vd_time = 0xffffffffu; vd_stamp = 0;
     cal_cursor = 0; cal_free = 0; cal_bump = 0;  // (the calendar's head / tail / bitmap rows are zeroed by the host)
     if (P.rcap) {
-      for (u32 k = 0; k < P.n * P.rcap; k++) st(P.off_trace + k, 0xffffffffu);
-      for (u32 k = 0; k < P.n; k++) st(P.off_trace + P.n * P.rcap + k, 0);
+      for (u32 k = 0; k < NN() * P.rcap; k++) st(P.off_trace + k, 0xffffffffu);
+      for (u32 k = 0; k < NN(); k++) st(P.off_trace + NN() * P.rcap + k, 0);
     }
     for (u32 s = 0; s < P.scap; s++) { st(P.off_snap_free + s, P.scap - 1 - s); st(P.off_snap_ref + s, 0); }
-    for (u32 k = 0; k < P.n * P.ecap * P.rarch_words; k++) st(P.off_rarch + k, 0);  // (an unused archive entry reads as "no store": current_round 0)
+    for (u32 k = 0; k < NN() * P.ecap * P.rarch_words; k++) st(P.off_rarch + k, 0);  // (an unused archive entry reads as "no store": current_round 0)
     rng.seed(seed);
-    for (u32 node = 0; node < P.n; node++) {
-      for (u32 f = 0; f < P.node_words; f++) nfms(node, f, 0);
+    for (u32 node = 0; node < NN(); node++) {
+      for (u32 f = 0; f < NWORDS(); f++) nfms(node, f, 0);
       nfms(node, NF_CUR_ROUND, 1);
       nfms(node, NF_PM_LEADER, LBFT_NO_LEADER);
       nfms(node, NF_LAST_TIMER_T, 0xffffffffu);
@@ -2974,7 +2988,7 @@ struct SimT {
   // a new round since the last call, so one node is examined instead of all. ----
   LBFT_HD void trace_round_switch(u32 node, i32 event_time) {
     u32 ar = nfm(node, NF_PM_ROUND);
-    u32 mw = P.off_trace + P.n * P.rcap + node;
+    u32 mw = P.off_trace + NN() * P.rcap + node;
     if (ar > ld(mw)) {
       st(mw, ar);
       // (the reference writes rounds 0..max_round exclusive, data_writer.rs:74-75: a node AT round rcap loses nothing)
@@ -3215,6 +3229,11 @@ inline int sim_class(const Params& p) {
   return small && fits_packed_queue ? 0 : 1;
 }
 
+// Does a class-0 batch qualify for the kernel with the headline network fixed at compile time (SimT<9>)?
+inline bool sim_quad(const Params& p) {
+  return sim_class(p) == 0 && p.n == 4 && p.unit_weights && p.delay_model == 0 && p.scap <= 64 && p.rot == 0 && !(LBFT_C0_IMAJOR && LBFT_C0_ALIGN) &&
+         p.off_node == I_WORDS && p.node_words == NF_FIXED_WORDS + 8u && p.snap_words == S_FIXED_WORDS + 8u && p.blk_words == B_WORDS;
+}
 // Does a class-2 / class-1 batch qualify for the lean kernel of its class (SimT<5> / SimT<6>)?
 inline bool sim_lean_features(const Params& p) { return (!(p.quirks & 1u) || (LBFT_LEAN_Q1 && p.n > 32)) && !p.rcap && !p.drop_ppm && !p.part_size; }
 inline bool sim_lean(const Params& p) { return sim_class(p) == 2 && sim_lean_features(p); }

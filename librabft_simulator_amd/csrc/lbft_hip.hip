@@ -254,6 +254,9 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
 // wavefront per SIMD and may use the whole register file (VGPRs + AGPRs).
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run0(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(0) run_body<0>(p, state, unfinished); }
+// ... the same kernel with the headline network fixed at compile time (4 nodes, unit voting rights, log-normal delays: SimT<9>, sim_quad())
+__global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
+void lbft_k_run0q(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(9) run_body<9>(p, state, unfinished); }
 // ... and for small batches (at most LBFT_POPC_MAX_LPW networks per wavefront): the pop's scan by all 64 lanes (SimT<8>)
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run0s(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(8) run_body<8>(p, state, unfinished); }
@@ -493,6 +496,11 @@ static thread_local std::string g_err;
 static bool small_batch_kernel(const Params& p) {
   const char* e = getenv("LBFT_NO_POPC");
   return LBFT_C0_POPC && !LBFT_C0_QLANE && sim_class(p) == 0 && p.lpw <= LBFT_POPC_MAX_LPW && p.ql > 0 && !(e && atoi(e));
+}
+// ... and large batches of the headline network (4 nodes, unit rights, log-normal delays) lbft_k_run0q; LBFT_NO_QUAD=1: lbft_k_run0
+static bool quad_kernel(const Params& p) {
+  const char* e = getenv("LBFT_NO_QUAD");
+  return LBFT_C0_QUAD && sim_quad(p) && !small_batch_kernel(p) && !(e && atoi(e));
 }
 static bool lean_allowed() { const char* e = getenv("LBFT_NO_LEAN"); return !(e && atoi(e)); }
 static bool lean2_allowed() { const char* e = getenv("LBFT_LEAN2"); return lean_allowed() && !(e && !atoi(e)); }
@@ -1008,7 +1016,8 @@ int lbft_batch_layout(const lbft_batch* b, uint32_t* out) {
   out[5] = p.ql;              // event-queue slots per instance resident in LDS
   out[6] = p.lpw;             // lanes per wavefront carrying an instance
   out[7] = (uint32_t)sim_class(p) | (p.qheap << 8) | (p.qcal << 9) | ((((sim_lean(p) && lean2_allowed()) || (sim_lean1(p) && lean_allowed())) ? 1u : 0u) << 10) | ((p.ring ? 1u : 0u) << 11) |
-           (((sim_lean_q1(p) && lean2_allowed()) ? 1u : 0u) << 12) | ((small_batch_kernel(p) ? 1u : 0u) << 13);
+           (((sim_lean_q1(p) && lean2_allowed()) ? 1u : 0u) << 12) | ((small_batch_kernel(p) ? 1u : 0u) << 13) |
+           ((quad_kernel(p) ? 1u : 0u) << 14);
   return LBFT_OK;
 }
 
@@ -1199,7 +1208,8 @@ static int launch_run(lbft_batch* b) {
   bool lean = sim_lean(p) && lean2_allowed(), lean1 = sim_lean1(p) && lean_allowed();
   const bool leanq = lean && sim_lean_q1(p);
   const bool small0 = small_batch_kernel(p);
-  const void* run_fn = leanq ? reinterpret_cast<const void*>(lbft_k_run2q) : lean ? reinterpret_cast<const void*>(lbft_k_run2l) : lean1 ? reinterpret_cast<const void*>(lbft_k_run1l) : (cls == 0 && small0) ? reinterpret_cast<const void*>(lbft_k_run0s) : cls == 0 ? reinterpret_cast<const void*>(lbft_k_run0)
+  const bool quad0 = quad_kernel(p);
+  const void* run_fn = leanq ? reinterpret_cast<const void*>(lbft_k_run2q) : lean ? reinterpret_cast<const void*>(lbft_k_run2l) : lean1 ? reinterpret_cast<const void*>(lbft_k_run1l) : (cls == 0 && small0) ? reinterpret_cast<const void*>(lbft_k_run0s) : (cls == 0 && quad0) ? reinterpret_cast<const void*>(lbft_k_run0q) : cls == 0 ? reinterpret_cast<const void*>(lbft_k_run0)
                      : cls == 1 ? reinterpret_cast<const void*>(lbft_k_run<1>) : reinterpret_cast<const void*>(lbft_k_run<2>);
   HIP_TRY(hipFuncSetAttribute(run_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
   const u32 nwaves = b->run_waves, block = 64u * nwaves;
@@ -1209,6 +1219,7 @@ static int launch_run(lbft_batch* b) {
   else if (lean) lbft_k_run2l<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (lean1) lbft_k_run1l<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (cls == 0 && small0) lbft_k_run0s<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  else if (cls == 0 && quad0) lbft_k_run0q<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (cls == 0) lbft_k_run0<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (cls == 1) lbft_k_run<1><<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else lbft_k_run<2><<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);

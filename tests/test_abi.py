@@ -113,7 +113,9 @@ def test_run_kernels_keep_their_state_in_registers(hiplib):
     and the kernel-argument block), costing 15 % and 3x: the headline kernel may spill a handful of registers (the state
     itself is > 160 bytes) and must fit two wavefronts per SIMD (<= 256 registers)."""
     kernels = _kernel_metadata(hiplib.LIB_PATH)
-    run0 = [v for k, v in kernels.items() if "lbft_k_run0" in k and "lbft_k_run0s" not in k]
+    run0 = [v for k, v in kernels.items() if "lbft_k_run0" in k and "lbft_k_run0s" not in k and "lbft_k_run0q" not in k]
+    run0q = [v for k, v in kernels.items() if "lbft_k_run0q" in k]  # the headline network fixed at compile time
+    assert len(run0q) == 1 and run0q[0]["vgpr_count"] <= 256 and run0q[0]["private_segment_fixed_size"] <= 384, run0q
     assert len(run0) == 1, sorted(kernels)
     # (round 3, instance-major rows: the wide node / snapshot loads need register tuples, and ~46 loop-INVARIANT values -- kernel
     # arguments, LDS bases -- are parked in scratch before the loop and reloaded after it: 188 bytes, two reloads inside the loop on
@@ -159,7 +161,7 @@ def test_kernel_names_from_the_layout_flag_word():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench
     import configs
-    for kc, name in ((0, "lbft_k_run0"), (8192, "lbft_k_run0s"), (1 | 1024, "lbft_k_run1l"), (1, "lbft_k_run<1>"), (2 | 256 | 512 | 2048, "lbft_k_run<2>"),
+    for kc, name in ((0, "lbft_k_run0"), (8192, "lbft_k_run0s"), (16384, "lbft_k_run0q"), (1 | 1024, "lbft_k_run1l"), (1, "lbft_k_run<1>"), (2 | 256 | 512 | 2048, "lbft_k_run<2>"),
                      (2 | 256 | 512 | 1024 | 2048, "lbft_k_run2l"), (2 | 256 | 512 | 1024 | 2048 | 4096, "lbft_k_run2q")):
         assert bench.run_kernel_name(kc) == name
         assert configs.kernel_name({"kernel_class": kc}) == name

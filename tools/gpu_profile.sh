@@ -19,6 +19,7 @@ pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_
 pass sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_THREAD_CYCLES_VALU
 pass sq3 SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS
 pass grbm GRBM_GUI_ACTIVE
+pass ifetch SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH
 python tools/pmc_summary.py $OUT > $OUT/pmc_lbft_k_run.json 2> $OUT/pmc_summary.err
 # roofline.traffic for bench.py: FETCH/WRITE per launch, stamped with the hash of the kernels' machine code (copy to profiles/current/)
 python - "$OUT" "$TAG" <<'PY'
@@ -31,5 +32,5 @@ json.dump({"FETCH_SIZE": p.get("FETCH_SIZE"), "WRITE_SIZE": p.get("WRITE_SIZE"),
            "profile": "profiles/%s/pmc_lbft_k_run.json" % tag, "workload": "bench.py default: 65536 x 4 nodes, max_clock 1000",
            "source_hash": source_hash()}, open(out + "/pmc_traffic.json", "w"), indent=1)
 PY
-rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/tcc $OUT/sq1 $OUT/sq2 $OUT/sq3 $OUT/grbm
+rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/tcc $OUT/sq1 $OUT/sq2 $OUT/sq3 $OUT/grbm $OUT/ifetch
 cat $OUT/kernel_stats.csv | head -4; cat $OUT/pmc_lbft_k_run.json | head -40; tail -1 $OUT/bench_line.json | cut -c1-600
