@@ -83,7 +83,7 @@ typedef int64_t i64;
 #define LBFT_C0_ALIGN 0   // (with LBFT_C0_IMAJOR) records padded and aligned so that none straddles a 128-byte line needlessly
 #endif
 #ifndef LBFT_C0_HCREG
-#define LBFT_C0_HCREG 0   // (with LBFT_C0_IMAJOR, networks of <= 4 nodes) the node's hcbr buffers ride in the node burst and live in registers
+#define LBFT_C0_HCREG 1   // (lbft_k_run0q, with LBFT_C0_IMAJOR) the node's hcbr buffers ride in the node burst and live in registers
 #endif
 #ifndef LBFT_FAST_TRUNC_EXP
 #define LBFT_FAST_TRUNC_EXP 1  // the delay sampler decides trunc(exp(y)) from a single-precision estimate when that is safe (SimT::trunc_exp)
@@ -655,7 +655,7 @@ struct SimT {
   LBFT_HD u32 ROT() const { return QUAD ? 0u : P.rot; }
   static constexpr bool C0I = C0 && LBFT_C0_IMAJOR != 0;
   static constexpr bool TILE64 = (C0 && !C0I) || CLS == 1 || CLS == 6;
-  static constexpr bool HCREG = C0I && LBFT_C0_HCREG != 0;
+  static constexpr bool HCREG = CLS == 9 && C0I && LBFT_C0_HCREG != 0;  // (lbft_k_run0q: 18.7 -> 18.1 ms; no gain in the generic class-0 kernels)
   static constexpr bool IMAJOR = BIG || C0I;  // tile width 1 = every instance's words contiguous (P.tw == 1), addressed at compile time
   static constexpr bool F_AX = LEAN2 ? (LBFT_LEAN_AX != 0) : (LBFT_AX != 0);      // (tuning switches above)
   static constexpr bool F_BX = LEAN2 ? (LBFT_LEAN_BX != 0) : (LBFT_BX != 0);

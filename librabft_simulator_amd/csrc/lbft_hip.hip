@@ -75,10 +75,12 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restr
 // `slot_bytes`: 12 (key + meta) or 8 (packed one-word entries, kernel class 0)
 // (class 0 with a lane-major queue front, LBFT_C0_QLANE: LBFT_QLANE_PAD more words per lane)
 #define LBFT_QPAD(slot_bytes) ((slot_bytes) == 8 && LBFT_C0_QLANE ? LBFT_QLANE_PAD : 0u)
-static inline size_t run_lds_bytes(u32 ql, u32 lpw, u32 n, u32 slot_bytes, u32 nwaves) {
+// `hcbr_lds`: class 0 with networks of <= 4 nodes keeps the nodes' hcbr buffers in LDS -- except lbft_k_run0q, which carries them in
+// registers with the node burst (LBFT_C0_HCREG)
+static inline size_t run_lds_bytes(u32 ql, u32 lpw, u32 n, u32 slot_bytes, u32 nwaves, bool hcbr_lds = true) {
   return (size_t)LBFT_TABLE_U64 * 8 + (size_t)nwaves * (ql + LBFT_QPAD(slot_bytes)) * lpw * slot_bytes + (size_t)nwaves * LBFT_NPHASES * 8 + 8 +
          (n > 16 ? (size_t)nwaves * lpw * LBFT_MAX_NODES : 0) +
-         (n <= 4 && slot_bytes == 8 && !(LBFT_C0_IMAJOR && LBFT_C0_HCREG) ? (size_t)nwaves * lpw * LBFT_LDS_HCBR_WORDS * 4 : 0);  // class 0, n <= 4: hcbr buffers
+         (n <= 4 && slot_bytes == 8 && hcbr_lds ? (size_t)nwaves * lpw * LBFT_LDS_HCBR_WORDS * 4 : 0);  // class 0, n <= 4: hcbr buffers
 }
 
 __device__ __forceinline__ size_t run_lds_bytes_dev(u32 ql, u32 lpw, u32 slot_bytes, u32 nwaves) {  // = run_lds_bytes(ql, lpw, 0, ..): where the receiver lists start
@@ -495,7 +497,7 @@ static thread_local std::string g_err;
 // class-0 batches with few networks per wavefront run lbft_k_run0s (wavefront-wide pop); LBFT_NO_POPC=1: lbft_k_run0 for every batch size
 static bool small_batch_kernel(const Params& p) {
   const char* e = getenv("LBFT_NO_POPC");
-  return LBFT_C0_POPC && !LBFT_C0_QLANE && sim_class(p) == 0 && p.lpw <= LBFT_POPC_MAX_LPW && p.ql > 0 && !(e && atoi(e));
+  return LBFT_C0_POPC && !LBFT_C0_QLANE && sim_class(p) == 0 && p.lpw <= LBFT_POPC_MAX_LPW && !(e && atoi(e));
 }
 // ... and large batches of the headline network (4 nodes, unit rights, log-normal delays) lbft_k_run0q; LBFT_NO_QUAD=1: lbft_k_run0
 static bool quad_kernel(const Params& p) {
@@ -1159,15 +1161,17 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   size_t budget = (160u * 1024u) / wg_per_cu;
   // 2 KiB slack per workgroup: with less, two workgroups of 32-lane wavefronts do not become co-resident on a CU
   u32 slot_bytes = p.qpack ? 8u : 12u;  // kernel class 0 keeps one-word entries
-  u32 ql_auto = (u32)((budget - run_lds_bytes(0, lpw, n, slot_bytes, nwaves) - 2048) / (slot_bytes * nwaves * lpw));  // (run_lds_bytes(0, ..) includes the lane padding)
+  p.lpw = lpw;
+  const bool hcbr_lds = !(LBFT_C0_IMAJOR && LBFT_C0_HCREG && quad_kernel(p));  // (the kernel choice only depends on the layout and lpw)
+  u32 ql_auto = (u32)((budget - run_lds_bytes(0, lpw, n, slot_bytes, nwaves, hcbr_lds) - 2048) / (slot_bytes * nwaves * lpw));  // (run_lds_bytes(0, ..) includes the lane padding)
   if (p.qpack && ql_auto > LBFT_PACKED_QL_MAX) ql_auto = LBFT_PACKED_QL_MAX;
   u32 ql = b->ql < 0 ? ql_auto : (u32)b->ql;
   if (ql > qcap) ql = qcap;
   if (p.qpack) ql &= ~(LBFT_POP_BATCH - 1u);  // scanned in batches of LBFT_POP_BATCH
   if (p.qcal) ql = 0;  // the calendar lives in HBM rows
-  if (run_lds_bytes(ql, lpw, n, slot_bytes, nwaves) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
+  if (run_lds_bytes(ql, lpw, n, slot_bytes, nwaves, hcbr_lds) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
   p.ql = ql;
-  b->lds_bytes = run_lds_bytes(ql, lpw, n, slot_bytes, nwaves);
+  b->lds_bytes = run_lds_bytes(ql, lpw, n, slot_bytes, nwaves, hcbr_lds);
   p.prof = b->d_prof;
   return LBFT_OK;
 }

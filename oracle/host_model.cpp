@@ -139,7 +139,8 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
     for (size_t i = tid; i < n_instances; i += threads) {
       { Sim s0(p, state.data(), (u32)i); s0.init(seeds[i]); }
       // emulate the device's launch structure: the LDS front of the queue is a cache of the HBM rows
-      if (cls == 0) { SimT<0> s(p, state.data(), (u32)i); run_one(s, i); }
+      if (cls == 0 && LBFT_C0_QUAD && sim_quad(p)) { SimT<9> s(p, state.data(), (u32)i); run_one(s, i); }  // as the device dispatches (large batches)
+      else if (cls == 0) { SimT<0> s(p, state.data(), (u32)i); run_one(s, i); }
       else if (cls == 1 && sim_lean1(p)) { SimT<6> s(p, state.data(), (u32)i); run_one(s, i); }  // as the device dispatches
       else if (cls == 1) { SimT<1> s(p, state.data(), (u32)i); run_one(s, i); }
       else if (cls == 2 && sim_lean_q1(p)) { SimT<7> s(p, state.data(), (u32)i); run_one(s, i); }  // as the device dispatches
