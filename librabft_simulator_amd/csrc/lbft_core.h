@@ -91,6 +91,13 @@ typedef int64_t i64;
 #ifndef LBFT_C0_POPC
 #define LBFT_C0_POPC 1   // small batches of class-0 networks run lbft_k_run0s (SimT<8>): the pop's scan by all 64 lanes of the wavefront
 #endif
+#ifndef LBFT_C0_HOT_FIRST
+#define LBFT_C0_HOT_FIRST 1
+#endif
+#ifndef LBFT_QUAD_CONST_OFFSETS
+#define LBFT_QUAD_CONST_OFFSETS 0  // (measured: 19.1 ms against 18.2 with run-time offsets -- the literals cost registers: 85 against 37 spilled)
+#endif
+#define LBFT_QUAD_SCAP 32u  // snapshot slots of a 4-node batch as the host sizes them by default (lbft_k_run0q needs exactly these)
 #ifndef LBFT_C0_QUAD
 #define LBFT_C0_QUAD 1   // large class-0 batches of 4-node networks with unit rights and log-normal delays run lbft_k_run0q (SimT<9>)
 #endif
@@ -649,6 +656,11 @@ struct SimT {
   LBFT_HD u32 SWORDS() const { return QUAD ? S_FIXED_WORDS + 8u : P.snap_words; }
   LBFT_HD u32 BWORDS() const { return QUAD ? (u32)B_WORDS : P.blk_words; }
   LBFT_HD u32 OFFNODE() const { return QUAD ? (u32)I_WORDS : P.off_node; }
+  // (hot-first layout, compute_layout: I_WORDS | 4 nodes | LBFT_QUAD_SCAP snapshots | reference counts | free stack | blocks)
+  LBFT_HD u32 OFFSNAP() const { return QUAD && LBFT_QUAD_CONST_OFFSETS ? (u32)I_WORDS + 4u * (NF_FIXED_WORDS + 8u) : P.off_snap; }
+  LBFT_HD u32 OFFSREF() const { return QUAD && LBFT_QUAD_CONST_OFFSETS ? (u32)I_WORDS + 4u * (NF_FIXED_WORDS + 8u) + LBFT_QUAD_SCAP * (S_FIXED_WORDS + 8u) : P.off_snap_ref; }
+  LBFT_HD u32 OFFSFREE() const { return QUAD && LBFT_QUAD_CONST_OFFSETS ? (u32)I_WORDS + 4u * (NF_FIXED_WORDS + 8u) + LBFT_QUAD_SCAP * (S_FIXED_WORDS + 8u) + LBFT_QUAD_SCAP : P.off_snap_free; }
+  LBFT_HD u32 OFFBLK() const { return QUAD && LBFT_QUAD_CONST_OFFSETS ? (u32)I_WORDS + 4u * (NF_FIXED_WORDS + 8u) + LBFT_QUAD_SCAP * (S_FIXED_WORDS + 8u) + 2u * LBFT_QUAD_SCAP : P.off_blk; }
   LBFT_HD u32 UNITW() const { return QUAD ? 1u : P.unit_weights; }
   LBFT_HD u32 DMODEL() const { return QUAD ? 0u : P.delay_model; }
   LBFT_HD u32 QUORUM() const { return QUAD ? 3u : P.quorum; }
@@ -886,7 +898,7 @@ struct SimT {
           if ((group_mask(g) >> f) & 1ULL) stf(nb, f, cw[f]);
       }
   }
-  LBFT_HD u32 bfw(u32 b, u32 f) const { return P.off_blk + (b - 1) * BWORDS() + f; }
+  LBFT_HD u32 bfw(u32 b, u32 f) const { return OFFBLK() + (b - 1) * BWORDS() + f; }
   LBFT_HD u32 bf(u32 b, u32 f) const { return ld(bfw(b, f)); }   // cold fields (B_TIME, B_CMD) and read-back
   LBFT_HD void bfs(u32 b, u32 f, u32 v) const { st(bfw(b, f), v); }
   LBFT_HD u32 blk_author(u32 b) const { return bf(b, B_LINK) >> 16; }
@@ -1031,7 +1043,7 @@ struct SimT {
       else bc_w[e][B_PEND] = hit ? v : bc_w[e][B_PEND];
     }
   }
-  LBFT_HD u32 sfw(u32 slot, u32 f) const { return P.off_snap + slot * SWORDS() + f; }
+  LBFT_HD u32 sfw(u32 slot, u32 f) const { return OFFSNAP() + slot * SWORDS() + f; }
   // extension word k >= 1 of a snapshot's TC (which = 0) / current-timeout (which = 1) author set
   LBFT_HD u32 sxw(u32 slot, u32 which, u32 k) const { return sfw(slot, S_FIXED_WORDS + 2 * NN() + which * (MW() - 1) + k - 1); }
 
@@ -1412,7 +1424,7 @@ struct SimT {
   LBFT_HD bool mask_slots() const { return QUAD ? true : LEAN2 ? false : P.scap <= 64; }
   LBFT_HD void snap_free_slot(u32 slot) {
     if (mask_slots()) snap_mask |= 1ULL << slot;
-    else { st(P.off_snap_free + snap_free, slot); snap_free++; }
+    else { st(OFFSFREE() + snap_free, slot); snap_free++; }
   }
   LBFT_HD i32 snap_alloc() {
     if (mask_slots()) {
@@ -1427,12 +1439,12 @@ struct SimT {
     snap_free--;
     u32 live = P.scap - snap_free;
     if (live > maxsnap) maxsnap = live;
-    return (i32)ld(P.off_snap_free + snap_free);
+    return (i32)ld(OFFSFREE() + snap_free);
   }
-  LBFT_HD void snap_release(u32 slot) { snap_release(slot, ld(P.off_snap_ref + slot)); }
+  LBFT_HD void snap_release(u32 slot) { snap_release(slot, ld(OFFSREF() + slot)); }
   LBFT_HD void snap_release(u32 slot, u32 refs) {  // `refs` = the slot's reference count as loaded by the caller
     u32 r = refs - 1;
-    st(P.off_snap_ref + slot, r);
+    st(OFFSREF() + slot, r);
     if (r == 0) snap_free_slot(slot);
   }
 
@@ -1909,7 +1921,7 @@ struct SimT {
 #if defined(LBFT_NO_RETIRE)
     return;
 #endif
-    if (!P.rarch_words) return;
+    if (QUAD || !P.rarch_words) return;  // (the compile-time-specialised kernel leaves batches that archive to the generic one: sim_quad)
     u32 old_epoch = nf(node, NF_EPOCH);
     if (old_epoch >= P.ecap) { fault |= F_EPOCH_OVERFLOW; return; }
     u32 base = P.off_rarch + (node * P.ecap + old_epoch) * P.rarch_words;
@@ -2200,7 +2212,7 @@ struct SimT {
   // request it answers (epoch, certificates), in one burst.
   LBFT_HD Resp load_response(u32 slot) const {
     Resp rp;
-    u32 sb = boff(P.off_snap + slot * SWORDS());
+    u32 sb = boff(OFFSNAP() + slot * SWORDS());
     rp.epoch = ldf(sb, S_EPOCH); rp.certs = ldf(sb, S_CERTS); rp.prop = ldf(sb, S_PROP_VOTE);
     u32 qb = sqw(sfw(slot, 0), 0);
     rp.req_epoch = ld(qb); rp.req_certs = ld(qb + 1);
@@ -2315,18 +2327,18 @@ struct SimT {
   LBFT_HD bool small_sets() const { return C0 && NN() <= 4; }
   LBFT_HD Snap load_snapshot(u32 slot) const {
     Snap sn;
-    u32 sb = boff(P.off_snap + slot * SWORDS());
+    u32 sb = boff(OFFSNAP() + slot * SWORDS());
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (u32 f = 0; f < S_FIXED_WORDS; f++) sn.w[f] = ldf(sb, f);
-    sn.refs = ld(P.off_snap_ref + slot);
+    sn.refs = ld(OFFSREF() + slot);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (u32 a = 0; a < 4; a++) sn.to_hcbr[a] = 0;
     if (small_sets()) {
-      u32 hb = boff(P.off_snap + slot * SWORDS() + S_FIXED_WORDS + NN());
+      u32 hb = boff(OFFSNAP() + slot * SWORDS() + S_FIXED_WORDS + NN());
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -2607,13 +2619,13 @@ struct SimT {
       else if (which == 3) refs_twin += pushed ? 1u : 0u;
       else if (which == 4) rrefs += pushed ? 1u : 0u;
       else if (q1() && (i32)pslot >= 0) {  // response / sync request under quirks bit 0: the slot travels with the event
-        if (pushed) st(P.off_snap_ref + pslot, 1); else snap_free_slot(pslot);
+        if (pushed) st(OFFSREF() + pslot, 1); else snap_free_slot(pslot);
       }
       LBFT_MARK(19);
     }
-    if (slot >= 0) { if (refs) st(P.off_snap_ref + (u32)slot, refs); else snap_free_slot((u32)slot); }
-    if (slot_twin >= 0) { if (refs_twin) st(P.off_snap_ref + (u32)slot_twin, refs_twin); else snap_free_slot((u32)slot_twin); }
-    if (q1() && n_b && rs >= 0 && !(bulk & 2u)) { if (rrefs) st(P.off_snap_ref + (u32)rs, rrefs); else snap_free_slot((u32)rs); }
+    if (slot >= 0) { if (refs) st(OFFSREF() + (u32)slot, refs); else snap_free_slot((u32)slot); }
+    if (slot_twin >= 0) { if (refs_twin) st(OFFSREF() + (u32)slot_twin, refs_twin); else snap_free_slot((u32)slot_twin); }
+    if (q1() && n_b && rs >= 0 && !(bulk & 2u)) { if (rrefs) st(OFFSREF() + (u32)rs, rrefs); else snap_free_slot((u32)rs); }
     LBFT_MARK(13);
   }
 
@@ -2886,10 +2898,10 @@ struct SimT {
       stamp += cnt;
       if (stamp >= (1u << 30)) fault |= F_STAMP_OVERFLOW;
       if (which == 0) {
-        if (sr >= 0) { if (refs) st(P.off_snap_ref + (u32)sr, refs); else snap_free_slot((u32)sr); }
-        if (st_ >= 0) { if (refs_twin) st(P.off_snap_ref + (u32)st_, refs_twin); else snap_free_slot((u32)st_); }
+        if (sr >= 0) { if (refs) st(OFFSREF() + (u32)sr, refs); else snap_free_slot((u32)sr); }
+        if (st_ >= 0) { if (refs_twin) st(OFFSREF() + (u32)st_, refs_twin); else snap_free_slot((u32)st_); }
       } else if (q1() && rs >= 0) {
-        if (rrefs) st(P.off_snap_ref + (u32)rs, rrefs); else snap_free_slot((u32)rs);
+        if (rrefs) st(OFFSREF() + (u32)rs, rrefs); else snap_free_slot((u32)rs);
       }
     }
     LBFT_MARK(19);
@@ -2962,7 +2974,7 @@ struct SimT {
       for (u32 k = 0; k < NN() * P.rcap; k++) st(P.off_trace + k, 0xffffffffu);
       for (u32 k = 0; k < NN(); k++) st(P.off_trace + NN() * P.rcap + k, 0);
     }
-    for (u32 s = 0; s < P.scap; s++) { st(P.off_snap_free + s, P.scap - 1 - s); st(P.off_snap_ref + s, 0); }
+    for (u32 s = 0; s < P.scap; s++) { st(OFFSFREE() + s, P.scap - 1 - s); st(OFFSREF() + s, 0); }
     for (u32 k = 0; k < NN() * P.ecap * P.rarch_words; k++) st(P.off_rarch + k, 0);  // (an unused archive entry reads as "no store": current_round 0)
     rng.seed(seed);
     for (u32 node = 0; node < NN(); node++) {
@@ -3231,8 +3243,11 @@ inline int sim_class(const Params& p) {
 
 // Does a class-0 batch qualify for the kernel with the headline network fixed at compile time (SimT<9>)?
 inline bool sim_quad(const Params& p) {
-  return sim_class(p) == 0 && p.n == 4 && p.unit_weights && p.delay_model == 0 && p.scap <= 64 && p.rot == 0 && !(LBFT_C0_IMAJOR && LBFT_C0_ALIGN) &&
-         p.off_node == I_WORDS && p.node_words == NF_FIXED_WORDS + 8u && p.snap_words == S_FIXED_WORDS + 8u && p.blk_words == B_WORDS;
+  return sim_class(p) == 0 && p.n == 4 && p.unit_weights && p.delay_model == 0 && (LBFT_QUAD_CONST_OFFSETS ? p.scap == LBFT_QUAD_SCAP : p.scap <= 64) && p.rot == 0 && p.rarch_words == 0 &&
+         LBFT_C0_IMAJOR && !LBFT_C0_ALIGN && p.off_node == I_WORDS && p.node_words == NF_FIXED_WORDS + 8u && p.snap_words == S_FIXED_WORDS + 8u &&
+         p.blk_words == B_WORDS &&
+         (!LBFT_QUAD_CONST_OFFSETS || (p.off_snap == I_WORDS + 4u * (NF_FIXED_WORDS + 8u) && p.off_snap_ref == p.off_snap + LBFT_QUAD_SCAP * (S_FIXED_WORDS + 8u) &&
+                                       p.off_snap_free == p.off_snap_ref + LBFT_QUAD_SCAP && p.off_blk == p.off_snap_free + LBFT_QUAD_SCAP));
 }
 // Does a class-2 / class-1 batch qualify for the lean kernel of its class (SimT<5> / SimT<6>)?
 inline bool sim_lean_features(const Params& p) { return (!(p.quirks & 1u) || (LBFT_LEAN_Q1 && p.n > 32)) && !p.rcap && !p.drop_ppm && !p.part_size; }
@@ -3257,6 +3272,21 @@ inline u64 compute_layout(Params& p) {
   p.off_node = (u32)w; p.node_words = NF_FIXED_WORDS + 2 * p.n + 4 * (p.mw - 1);
   if (c0a) p.node_words = (u32)up(p.node_words, 32);
   w += (u64)p.n * p.node_words;
+  p.snap_words = S_FIXED_WORDS + 2 * p.n + 2 * (p.mw - 1) + ((p.quirks & 1u) ? 2 : 0);  // + the request's (epoch, certificates)
+  p.blk_words = B_WORDS + 4 * (p.mw - 1);  // + extension words (nodes / authors >= 32) of KNOWN, QC, PEND and VOTERS
+  // class 0, instance-major: notification snapshots and the block pool follow the nodes, the queue's spill rows come last -- the first
+  // word of every hot region then depends on num_nodes and snapshot_capacity alone, which the kernel with the headline network fixed at
+  // compile time (SimT<9>) turns into immediates
+  const bool hot_first = LBFT_C0_IMAJOR && LBFT_C0_HOT_FIRST && sim_class(p) == 0;
+  auto snaps_blocks = [&]() {
+    if (c0a) { p.snap_words = (u32)up(p.snap_words, 16); w = up(w, 16); }
+    p.off_snap = (u32)w; w += (u64)p.scap * p.snap_words;
+    p.off_snap_ref = (u32)w; w += p.scap;
+    p.off_snap_free = (u32)w; w += p.scap;
+    if (c0a) { p.blk_words = (u32)up(p.blk_words, 16); w = up(w, 16); }
+    p.off_blk = (u32)w; w += (u64)p.bcap * p.blk_words;
+  };
+  if (hot_first) snaps_blocks();
   p.off_qhi = (u32)w; w += p.qcap;
   p.off_qlo = (u32)w; w += p.qcap;  // (the calendar stores no keys: these rows hold its stack of freed slots)
   p.off_qmeta = (u32)w; w += p.qcap;
@@ -3264,14 +3294,7 @@ inline u64 compute_layout(Params& p) {
   p.off_cal_head = (u32)w; w += p.cal_buckets;
   p.off_cal_tail = (u32)w; w += p.cal_buckets;
   p.off_cal_bm = (u32)w; w += (p.cal_buckets + 31) / 32 + (p.qcal ? 1 : 0);
-  p.snap_words = S_FIXED_WORDS + 2 * p.n + 2 * (p.mw - 1) + ((p.quirks & 1u) ? 2 : 0);  // + the request's (epoch, certificates)
-  if (c0a) { p.snap_words = (u32)up(p.snap_words, 16); w = up(w, 16); }
-  p.off_snap = (u32)w; w += (u64)p.scap * p.snap_words;
-  p.off_snap_ref = (u32)w; w += p.scap;
-  p.off_snap_free = (u32)w; w += p.scap;
-  p.blk_words = B_WORDS + 4 * (p.mw - 1);  // + extension words (nodes / authors >= 32) of KNOWN, QC, PEND and VOTERS
-  if (c0a) { p.blk_words = (u32)up(p.blk_words, 16); w = up(w, 16); }
-  p.off_blk = (u32)w; w += (u64)p.bcap * p.blk_words;
+  if (!hot_first) snaps_blocks();  // (zero_calendar relies on head / tail / bitmap being the rows right before the snapshots here)
   p.off_log = (u32)w; w += (u64)p.n * p.lcap;
   p.off_list = (u32)w; w += p.n > 16 ? p.n : 0;
   p.off_trace = (u32)w; w += p.rcap ? (u64)p.n * p.rcap + p.n : 0;

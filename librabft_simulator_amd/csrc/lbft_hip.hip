@@ -1268,7 +1268,7 @@ int lbft_batch_run_steps(lbft_batch* b, int64_t max_clock, uint32_t steps, uint6
 }
 
 struct CheckpointHeader {
-  char magic[8];  // "LBFTCKP3"
+  char magic[8];  // "LBFTCKP4"
   u32 n, qcap, scap, bcap, lcap, rcap, total_words, equiv;
   // everything that changes the meaning of the state words without changing their number: the protocol mode, the fault model,
   // the kernel class and the queue discipline / key encoding it implies, the archive capacity of retired record stores
@@ -1286,7 +1286,7 @@ static u32 weights_hash(const std::vector<u32>& w) {
 }
 static void fill_header(const lbft_batch* b, CheckpointHeader& h) {
   memset(&h, 0, sizeof(h));
-  memcpy(h.magic, "LBFTCKP3", 8);
+  memcpy(h.magic, "LBFTCKP4", 8);
   const Params& p = b->p; const lbft_config& c = b->cfg;
   h.n = p.n; h.qcap = p.qcap; h.scap = p.scap; h.bcap = p.bcap; h.lcap = p.lcap; h.rcap = p.rcap; h.total_words = p.total_words;
   h.equiv = p.equiv; h.m = b->m; h.cpe = c.commands_per_epoch; h.max_clock = b->started_max_clock; h.tci = c.target_commit_interval;
@@ -1315,7 +1315,7 @@ int lbft_batch_checkpoint_load(lbft_batch* b, const void* buf, size_t len) {
   if (b->ran || b->manual || b->started) { g_err = "load a checkpoint into a fresh (or reset) batch"; return LBFT_ERR_STATE; }
   CheckpointHeader h;
   memcpy(&h, buf, sizeof(h));
-  if (memcmp(h.magic, "LBFTCKP3", 8) != 0) { g_err = "not a checkpoint (or one of an older format)"; return LBFT_ERR_INVALID; }
+  if (memcmp(h.magic, "LBFTCKP4", 8) != 0) { g_err = "not a checkpoint (or one of an older format)"; return LBFT_ERR_INVALID; }
   // the batch must have been created with the same configuration; capacities come from the checkpoint.  A failed load leaves
   // the batch's own capacities as they were.
   const lbft_config saved_cfg = b->cfg;
@@ -1328,7 +1328,8 @@ int lbft_batch_checkpoint_load(lbft_batch* b, const void* buf, size_t len) {
     b->started_max_clock = h.max_clock;
     CheckpointHeader mine;
     fill_header(b, mine);
-    if (memcmp(&mine, &h, sizeof(h)) != 0) { g_err = "checkpoint was taken from a batch with a different configuration"; rc = LBFT_ERR_INVALID; }
+    if (memcmp(&mine, &h, sizeof(h)) != 0) { g_err = "checkpoint was taken from a batch with a different configuration (parameters, capacities, protocol mode -- or a different kernel family: the "
+              "LBFT_NO_LEAN / LBFT_LEAN2 / LBFT_RING tuning variables and lbft_batch_keep_retired_stores change what the state words hold)"; rc = LBFT_ERR_INVALID; }
     else if (len != sizeof(h) + b->state_bytes) { g_err = "checkpoint size mismatch"; rc = LBFT_ERR_INVALID; }
   }
   if (rc != LBFT_OK) { b->cfg = saved_cfg; b->rcap = saved_rcap; b->started_max_clock = saved_max_clock; return rc; }
