@@ -46,6 +46,13 @@ PARITY = {
     "c3shard_8192x4": "oracle == reference goldens (3/8 nodes, LogNormal(10,4)); 4 nodes: oracle-as-spec, same code path",
 }
 PARITY_DEFAULT = "oracle-as-spec (no reference answer: extension / size the reference never ran)"
+# What a line measures, where that is not what its name suggests (printed with the line)
+NOTES = {
+    "c4_16384x64_longtail_equivocators": "DEGENERATE as SURVEY 8(d) wrote it: under reference quirk Q1 stragglers never catch up and the network stops committing "
+                                         "(0 commits by clock 300): this line times a stalled protocol; c4live is the configuration exercising what it is named for",
+    "c5_8192x100_weighted_epochs": "DEGENERATE as SURVEY 8(d) wrote it: clock 300 ends before the first epoch change (50 commands per epoch, ~8 commits): no "
+                                   "reconfiguration is exercised; c5live is",
+}
 
 
 def kernel_name(layout):
@@ -120,7 +127,7 @@ def run(name, scale=1.0, reps=1, lpw=0):
     liveness = {"min_node_commits": {"min": int(worst.min()), "median": float(np.median(worst)), "max": int(worst.max())},
                 "instances_with_5_commits_at_every_node": float((worst >= 5).mean()),
                 "epochs_min_max": [int(res.epochs.min()), int(res.epochs.max())]}
-    out = {"config": name, "parity": PARITY.get(name, PARITY_DEFAULT), "liveness": liveness, "roofline": roofline(sim.layout(), k, best, name), "instances": m, "nodes": c["nodes"], "max_clock": c["max_clock"], "kernel_ms": best,
+    out = {"config": name, "note": NOTES.get(name), "parity": PARITY.get(name, PARITY_DEFAULT), "liveness": liveness, "roofline": roofline(sim.layout(), k, best, name), "instances": m, "nodes": c["nodes"], "max_clock": c["max_clock"], "kernel_ms": best,
            "rounds_per_s": k["rounds"] / (best * 1e-3), "commits_per_s": k["commits"] / (best * 1e-3),
            "events_per_s": sum(k["events"]) / (best * 1e-3), "events": sum(k["events"]), "rounds": k["rounds"], "commits": k["commits"],
            "faulted_instances": k["faulted_instances"], "max_queue": k["max_queue"], "max_snapshots": k["max_snapshots"],
