@@ -97,6 +97,9 @@ typedef int64_t i64;
 #ifndef LBFT_QUAD_CONST_OFFSETS
 #define LBFT_QUAD_CONST_OFFSETS 0  // (measured: 19.1 ms against 18.2 with run-time offsets -- the literals cost registers: 85 against 37 spilled)
 #endif
+#ifndef LBFT_QUAD_PAIR
+#define LBFT_QUAD_PAIR 1
+#endif
 #define LBFT_QUAD_SCAP 32u  // snapshot slots of a 4-node batch as the host sizes them by default (lbft_k_run0q needs exactly these)
 #ifndef LBFT_C0_QUAD
 #define LBFT_C0_QUAD 1   // large class-0 batches of 4-node networks with unit rights and log-normal delays run lbft_k_run0q (SimT<9>)
@@ -645,7 +648,16 @@ struct SimT {
   // LDS queue front is done by all 64 lanes of the wavefront (coop_find, run_popc) -- a kernel of its own so that neither carries the
   // other's scan (with both, lbft_k_run0 grew from 57.8 to 61.4 KB and the 65 536-network batch from 22.4 to 24.0 ms: the 64 KB
   // instruction cache again)
-  static constexpr bool POPC = CLS == 8;
+  // ... and lbft_k_run0q has the lanes that carry no network -- the upper half of a 32-network wavefront -- scan the other half of their
+  // column's slots (coop_find_cols: lane-private early stop at the queue's length kept, the scan's batches split over 64 / lpw lanes)
+  // (device only: the host build of the kernel logic -- oracle/host_model.cpp, one network per object -- keeps the lane-private pop)
+#if defined(__HIP_DEVICE_COMPILE__)
+  static constexpr bool PAIR = CLS == 9 && LBFT_QUAD_PAIR != 0;
+  static constexpr bool POPC = CLS == 8 || PAIR;
+#else
+  static constexpr bool PAIR = false;
+  static constexpr bool POPC = false;
+#endif
   // 9 = class 0 with the headline network fixed at compile time (lbft_k_run0q): 4 nodes, unit voting rights, log-normal delays, <= 64
   // snapshot slots, no layout padding -- loop bounds, the quorum, record sizes and the first row offsets become immediates (sim_quad())
   static constexpr bool QUAD = CLS == 9;  // (the small-batch kernel gains nothing from it: 1 024 x 4 6.2 against 5.8 ms, 8 192 x 4 10.0 against 9.9 -- latency-bound)
@@ -1294,6 +1306,35 @@ struct SimT {
     bkey = m; best = mi >> qsh;
 #else
     (void)kw; bkey = ~0ULL; best = 0;
+#endif
+  }
+  // The same for wavefronts that carry many networks (lbft_k_run0q: 16 or 32): lane l belongs to column l % lpw and to scan group
+  // l / lpw (64 / lpw groups); a column's batches of LBFT_POP_BATCH slots are dealt to its groups in turn and stop at the queue's length,
+  // which the column's leader lane (lane l % lpw) holds in `qn` (0: no live network in that column).
+  LBFT_HD void coop_find_cols(const u64* kw, u32 qn, u64& bkey, u32& best) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 lane = lbft_lane_id();
+    const u32 col = lane & (qstr - 1u), grp = lane >> qsh, groups = 64u >> qsh;
+    const u32 qcol = (u32)__shfl((int)qn, (int)col, 64);
+    const u32 nl = qcol < ql ? qcol : ql;
+    u64 m = ~0ULL; u32 mi = 0;
+    for (u32 k0 = grp * LBFT_POP_BATCH; k0 < nl; k0 += groups * LBFT_POP_BATCH) {
+      u64 kk[LBFT_POP_BATCH];
+#pragma unroll
+      for (u32 j = 0; j < LBFT_POP_BATCH; j++) kk[j] = kw[((k0 + j) << qsh) + col];
+      u64 bm; u32 bi;
+      qmin<0, LBFT_POP_BATCH>(kk, bm, bi);
+      if (bm < m) { m = bm; mi = k0 + bi; }
+    }
+    for (u32 d = qstr; d < 64u; d <<= 1) {
+      u32 olo = (u32)__shfl_xor((int)(u32)m, (int)d, 64), ohi = (u32)__shfl_xor((int)(u32)(m >> 32), (int)d, 64), oi = (u32)__shfl_xor((int)mi, (int)d, 64);
+      u64 o = ((u64)ohi << 32) | olo;
+      bool lt = o < m;
+      m = lt ? o : m; mi = lt ? oi : mi;
+    }
+    bkey = m; best = mi;
+#else
+    (void)kw; (void)qn; bkey = ~0ULL; best = 0;
 #endif
   }
   // Removes the minimum; returns false when the queue is empty.
@@ -3175,7 +3216,8 @@ struct SimT {
       if (!go) break;
 #endif
       u64 fkey; u32 fbest;
-      coop_find(kw, fkey, fbest);
+      if (PAIR) coop_find_cols(kw, go ? qlen : 0u, fkey, fbest);
+      else coop_find(kw, fkey, fbest);
       if (go) {
         StepCtx c;
         step_begin(c, fkey, fbest);
