@@ -1297,6 +1297,31 @@ struct SimT {
       u64 mm = c ? m23 : m01; u32 ii = c ? i23 : i01;
       if (mm < m) { m = mm; mi = ii; }
     }
+    if (qstr == 1u) {
+      // ONE network in the wavefront: a DPP reduction (row shifts, then the two row broadcasts) leaves the minimum in lane 63 -- no LDS
+      // crossbar round trips at all --, a scalar read hands it to every lane, and the lane holding it names the slot
+      u32 lo = (u32)m, hi = (u32)(m >> 32);
+#define LBFT_DPP_MIN_STEP(ctrl, rmask)                                                                                    \
+      {                                                                                                                     \
+        u32 olo = (u32)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)lo, ctrl, rmask, 0xf, false);                      \
+        u32 ohi = (u32)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)hi, ctrl, rmask, 0xf, false);                      \
+        bool lt = ohi < hi || (ohi == hi && olo < lo);                                                                      \
+        lo = lt ? olo : lo; hi = lt ? ohi : hi;                                                                             \
+      }
+      LBFT_DPP_MIN_STEP(0x111, 0xf)  // row_shr:1
+      LBFT_DPP_MIN_STEP(0x112, 0xf)  // row_shr:2
+      LBFT_DPP_MIN_STEP(0x114, 0xf)  // row_shr:4
+      LBFT_DPP_MIN_STEP(0x118, 0xf)  // row_shr:8   -> lane 15 of every row: the row's minimum
+      LBFT_DPP_MIN_STEP(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+      LBFT_DPP_MIN_STEP(0x143, 0xc)  // row_bcast:31 into rows 2 and 3 -> lane 63: the wavefront's minimum
+#undef LBFT_DPP_MIN_STEP
+      const u32 glo = (u32)__builtin_amdgcn_readlane((int)lo, 63), ghi = (u32)__builtin_amdgcn_readlane((int)hi, 63);
+      const u64 g = ((u64)ghi << 32) | glo;
+      const unsigned long long holders = __ballot(m == g && g != ~0ULL);
+      const u32 hl = holders ? (u32)__builtin_ctzll(holders) : 0u;
+      bkey = g; best = (u32)__builtin_amdgcn_readlane((int)mi, (int)hl);  // (qsh == 0: the word index is the slot)
+      return;
+    }
     for (u32 d = qstr; d < 64u; d <<= 1) {  // lanes l ^ d share l % lpw
       u32 olo = (u32)__shfl_xor((int)(u32)m, (int)d, 64), ohi = (u32)__shfl_xor((int)(u32)(m >> 32), (int)d, 64), oi = (u32)__shfl_xor((int)mi, (int)d, 64);
       u64 o = ((u64)ohi << 32) | olo;
