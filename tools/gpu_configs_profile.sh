@@ -32,7 +32,7 @@ for cfg in $PROF_CONFIGS; do
   head -3 $OUT/$cfg.kernel_stats.csv; head -30 $OUT/$cfg.pmc.json
 done
 # second pass of the lines, now with `roofline.traffic` from each configuration's own FETCH / WRITE passes
-LBFT_PMC_DIR=$OUT timeout 900 python tools/configs.py c2_1024x4_lognormal c2_1024x4_uniform c3_65536x4 c3shard_8192x4 $PROF_CONFIGS > $OUT/baseline_configs_with_traffic.jsonl 2>> $OUT/configs.err
+LBFT_PMC_DIR=$OUT timeout 900 python tools/configs.py $(echo c2_1024x4_lognormal c2_1024x4_uniform c3_65536x4 c3shard_8192x4 $PROF_CONFIGS | tr " " "\n" | awk '!s[$0]++' | tr "\n" " ") > $OUT/baseline_configs_with_traffic.jsonl 2>> $OUT/configs.err
 python - "$OUT" <<'PY'
 import json, sys
 for line in open(sys.argv[1] + "/baseline_configs_with_traffic.jsonl"):
