@@ -183,6 +183,13 @@ def test_bench_two_ranks_on_one_device():
     # same 8 192 seeds (base_seed + global index), sharded 2 x 4 096: identical aggregate work
     assert round(d["value"] * d["ms_per_step"]) == round(w["value"] * w["ms_per_step"])
     assert round(d["events_per_s"] * d["ms_per_step"]) == round(w["events_per_s"] * w["ms_per_step"])
+    # strong scaling (--total-instances: ONE 8 192-instance batch sharded over the two ranks): the same aggregate again
+    cmd_s = cmd[:cmd.index("--instances")] + ["--total-instances", "8192", "--no-cpu-baseline"]
+    out_s = subprocess.run(cmd_s, env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out_s.returncode == 0, out_s.stderr[-2000:]
+    ds = json.loads([l for l in out_s.stdout.splitlines() if l.startswith("{")][-1])
+    assert ds["n_gpus"] == 2 and ds["scaling"] == "strong" and ds["config"]["total_instances"] == 8192 and ds["config"]["instances_per_gpu"] == 4096
+    assert round(ds["value"] * ds["ms_per_step"]) == round(w["value"] * w["ms_per_step"]) and ds["parity"]["mismatches"] == 0
 
 
 def test_bench_two_ranks_nccl():
