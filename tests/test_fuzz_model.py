@@ -133,7 +133,7 @@ def test_random_configurations_on_the_device_match_the_oracle(oracle, chunk):
                                      drop_per_million=kw.get("drop_per_million", 0), partition=part, quirks=kw.get("quirks", 0),
                                      rights_rotation=kw.get("rights_rotation", 0),
                                      calendar_queue=bool(rng.random() < 0.7), max_steps_per_launch=int(rng.choice([0, 0, 173])),
-                                     lanes_per_wavefront=int(rng.choice([0, 0, 1, 2, 8, 64])), block_capacity=max_clock + 64,
+                                     lanes_per_wavefront=int(rng.choice([0, 0, 1, 2, 8, 16, 32, 64])), block_capacity=max_clock + 64,
                                      queue_capacity=max(4096, 64 * n * n),
                                      # 0 = automatic (<= 64 slots for small honest networks: the register-resident free mask)
                                      snapshot_capacity=0 if (not (kw.get("quirks", 0) & 1) and rng.random() < 0.5) else max(128, 128 * n))
