@@ -553,6 +553,13 @@ struct lbft_batch {
   bool started = false; // lbft_batch_run_steps / checkpoint_load: state initialised, event loop not drained yet
   int64_t started_max_clock = 0;
   u64 step_launches = 0;
+  // save_node asked twice in a row (size query, then the fill -- what the Python and Rust callers do) builds the image once: the image of
+  // the last (instance, node) is kept until anything writes the state rows (`generation` counts those: init, run, node calls, checkpoint load)
+  u64 generation = 0;
+  mutable u64 sn_generation = ~0ull;
+  mutable size_t sn_inst = 0;
+  mutable u32 sn_node = 0;
+  mutable std::vector<uint8_t> sn_image;
   u32 max_steps = 0;
   u32 lpw = 0;  // 0 = auto
   int ql = -1;  // LDS queue slots per instance; -1 = auto
@@ -733,6 +740,7 @@ int lbft_batch_manual_begin(lbft_batch* b, int64_t max_clock) {
   if (rc != LBFT_OK) return rc;
   u32 grid_init = (u32)((b->m + b->p.lpw - 1) / b->p.lpw);
   { int zrc = zero_calendar(b); if (zrc != LBFT_OK) return zrc; }
+  b->generation++;
   lbft_k_init<<<grid_init, LBFT_BLOCK, 0, b->stream>>>(b->p, b->d_state, b->d_seeds);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(b->stream));
@@ -755,6 +763,7 @@ static int node_op(lbft_batch* b, u32 op, size_t inst, u32 node, u32 arg0, u32 a
   if (!b->manual) { g_err = "lbft_batch_manual_begin first"; return LBFT_ERR_STATE; }
   HIP_TRY(hipSetDevice(b->device));
   unsigned long long* d_out = reinterpret_cast<unsigned long long*>(b->d_scratch);  // 16 result words
+  b->generation++;
   lbft_k_node_op<<<1, 64, 0, b->stream>>>(b->p, b->d_state, op, (u32)inst, node, arg0, arg1, node_time, d_out);
   HIP_TRY(hipGetLastError());
   if (n_out) HIP_TRY(hipMemcpyAsync(host_out, d_out, n_out * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
@@ -808,6 +817,7 @@ int lbft_node_calls(lbft_batch* b, const lbft_node_call* calls, size_t n, lbft_n
     b->calls_cap = cap;
   }
   HIP_TRY(hipMemcpyAsync(b->d_calls, dev.data(), call_bytes, hipMemcpyHostToDevice, b->stream));
+  b->generation++;
   lbft_k_node_ops<<<(u32)((n + 63) / 64), 64, 0, b->stream>>>(b->p, b->d_state, b->d_calls, (u32)n, b->d_call_out);
   HIP_TRY(hipGetLastError());
   std::vector<unsigned long long> h(n * 16);
@@ -1188,6 +1198,7 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
   u32 grid_init = (u32)((b->m + lpw - 1) / lpw);
   HIP_TRY(hipEventRecord(b->ev0, b->stream));
   { int zrc = zero_calendar(b); if (zrc != LBFT_OK) return zrc; }
+  b->generation++;
   lbft_k_init<<<grid_init, LBFT_BLOCK, 0, b->stream>>>(p, b->d_state, b->d_seeds);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev1, b->stream));
@@ -1219,6 +1230,7 @@ static int launch_run(lbft_batch* b) {
   const u32 nwaves = b->run_waves, block = 64u * nwaves;
   u32 grid_run = (u32)((b->m + (size_t)nwaves * p.lpw - 1) / ((size_t)nwaves * p.lpw));
   HIP_TRY(hipMemsetAsync(b->d_unfinished, 0, sizeof(u32), b->stream));
+  b->generation++;
   if (leanq) lbft_k_run2q<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (lean) lbft_k_run2l<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (lean1) lbft_k_run1l<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
@@ -1242,6 +1254,7 @@ int lbft_batch_run_steps(lbft_batch* b, int64_t max_clock, uint32_t steps, uint6
     u32 grid_init = (u32)((b->m + b->p.lpw - 1) / b->p.lpw);
     HIP_TRY(hipEventRecord(b->ev0, b->stream));
     { int zrc = zero_calendar(b); if (zrc != LBFT_OK) return zrc; }
+    b->generation++;
     lbft_k_init<<<grid_init, LBFT_BLOCK, 0, b->stream>>>(b->p, b->d_state, b->d_seeds);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ev1, b->stream));
@@ -1333,6 +1346,7 @@ int lbft_batch_checkpoint_load(lbft_batch* b, const void* buf, size_t len) {
     else if (len != sizeof(h) + b->state_bytes) { g_err = "checkpoint size mismatch"; rc = LBFT_ERR_INVALID; }
   }
   if (rc != LBFT_OK) { b->cfg = saved_cfg; b->rcap = saved_rcap; b->started_max_clock = saved_max_clock; return rc; }
+  b->generation++;
   HIP_TRY(hipMemcpy(b->d_state, (const char*)buf + sizeof(h), b->state_bytes, hipMemcpyHostToDevice));
   HIP_TRY(hipEventRecord(b->ev0, b->stream));
   HIP_TRY(hipEventRecord(b->ev1, b->stream));
@@ -1498,17 +1512,22 @@ int lbft_batch_save_node(const lbft_batch* b, size_t inst, uint32_t node, void* 
   if (!b->ran && !b->manual) { g_err = "run the batch (or start a node-level session) first"; return LBFT_ERR_STATE; }
   HIP_TRY(hipSetDevice(b->device));
   const Params& dp = b->p;
-  // this instance's rows, contiguous on the host (a tile of width 1)
-  std::vector<u32> hw(dp.total_words);
-  if (dp.tw == 1)  // instance-major rows: one contiguous copy
-    HIP_TRY(hipMemcpy(hw.data(), b->d_state + word_offset(dp, (u32)inst, 0), (size_t)4 * dp.total_words, hipMemcpyDeviceToHost));
-  else
-    HIP_TRY(hipMemcpy2D(hw.data(), sizeof(u32), b->d_state + word_offset(dp, (u32)inst, 0), (size_t)4 * dp.tw, sizeof(u32), dp.total_words,
-                        hipMemcpyDeviceToHost));
-  std::vector<uint8_t> image;
-  std::string err;
-  int rc = build_node_image(dp, hw.data(), node, b->weights.data(), b->cfg.delta, b->cfg.gamma, b->cfg.lambda, b->cfg.target_commit_interval, image, err);
-  if (rc != 0) { g_err = err; return LBFT_ERR_UNSUPPORTED; }
+  if (b->sn_generation != b->generation || b->sn_inst != inst || b->sn_node != node) {
+    // this instance's rows, contiguous on the host (a tile of width 1)
+    std::vector<u32> hw(dp.total_words);
+    if (dp.tw == 1)  // instance-major rows: one contiguous copy
+      HIP_TRY(hipMemcpy(hw.data(), b->d_state + word_offset(dp, (u32)inst, 0), (size_t)4 * dp.total_words, hipMemcpyDeviceToHost));
+    else
+      HIP_TRY(hipMemcpy2D(hw.data(), sizeof(u32), b->d_state + word_offset(dp, (u32)inst, 0), (size_t)4 * dp.tw, sizeof(u32), dp.total_words,
+                          hipMemcpyDeviceToHost));
+    std::string err;
+    b->sn_generation = ~0ull;
+    b->sn_image.clear();
+    int rc = build_node_image(dp, hw.data(), node, b->weights.data(), b->cfg.delta, b->cfg.gamma, b->cfg.lambda, b->cfg.target_commit_interval, b->sn_image, err);
+    if (rc != 0) { g_err = err; return LBFT_ERR_UNSUPPORTED; }
+    b->sn_generation = b->generation; b->sn_inst = inst; b->sn_node = node;
+  }
+  const std::vector<uint8_t>& image = b->sn_image;
   *len = image.size();
   if (buf && cap < image.size()) { g_err = "save_node: the buffer is smaller than the image (*len holds the size needed)"; return LBFT_ERR_INVALID; }
   if (buf) memcpy(buf, image.data(), image.size());

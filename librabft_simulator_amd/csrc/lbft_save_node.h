@@ -17,8 +17,9 @@ namespace lbft {
 namespace save_node_detail {
 struct BinOut {
   std::vector<uint8_t> b;
-  void u64v(u64 v) { for (int i = 0; i < 8; i++) b.push_back((uint8_t)(v >> (8 * i))); }
-  void u32v(u32 v) { for (int i = 0; i < 4; i++) b.push_back((uint8_t)(v >> (8 * i))); }
+  // (little-endian host, like the image: words are appended with one copy each)
+  void u64v(u64 v) { size_t o = b.size(); b.resize(o + 8); memcpy(b.data() + o, &v, 8); }
+  void u32v(u32 v) { size_t o = b.size(); b.resize(o + 4); memcpy(b.data() + o, &v, 4); }
   void f64v(double d) { u64 u; memcpy(&u, &d, 8); u64v(u); }
   void opt(bool some, u64 v) { b.push_back(some ? 1 : 0); if (some) u64v(v); }
 };
@@ -88,6 +89,7 @@ inline int build_node_image(const Params& dp, u32* hw, u32 node, const u32* weig
     }
   }
   BinOut w;
+  w.b.reserve(4096 + (size_t)nblocks * 400);
   auto put_vote = [&](u32 blk, u32 a) {  // Vote = SignedValue<Vote_> (record.rs:65-80)
     const BlockInfo& r = B[blk];
     w.u64v(r.epoch); w.u64v(r.round); w.u64v(r.hash); w.u64v(r.state); w.opt(r.has_cs, r.cs); w.u64v(a);

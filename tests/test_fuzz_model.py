@@ -148,6 +148,52 @@ def test_random_configurations_on_the_device_match_the_oracle(oracle, chunk):
             assert c[key] == rc[key], (key, kw)
 
 
+# The headline network's own kernel (lbft_k_run0q: 4 nodes, unit voting rights, log-normal delays, <= 64 snapshot slots, fixed at
+# compile time; pairs of lanes scanning a queue): everything else about the configuration drawn at random -- pacemaker parameters,
+# epoch lengths, delay mean / variance, equivocators, loss, partitions, Q2 -- with 16 / 32 / 64 networks per wavefront and launches
+# cut into pieces.  At least half of the draws must have run on that kernel (the rest fall to lbft_k_run0: more snapshot slots).
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_QUAD_CHUNKS", "2"))))
+def test_random_headline_network_configurations_on_the_device_match_the_oracle(oracle, chunk):
+    import librabft_simulator_amd as amd
+    rng = np.random.default_rng(31337 + chunk)
+    on_quad = 0
+    for _ in range(10):
+        kw = draw_config(rng)
+        kw["num_nodes"] = n = 4
+        for k in ("voting_rights", "rights_rotation", "delay_model", "uniform_lo", "uniform_hi"):
+            kw.pop(k, None)
+        if kw.get("equivocate_every", 0) > n:
+            kw["equivocate_every"] = n
+        if "partition_size" in kw:
+            kw["partition_size"] = min(kw["partition_size"], n - 1)
+        if rng.random() < 0.5:
+            kw["quirks"] = kw.get("quirks", 0) & 2  # Q1 (peers answering requests) needs more snapshot slots than the kernel fixes
+        kw.setdefault("mean", float(rng.choice([3.0, 10.0, 25.0])))
+        kw.setdefault("variance", float(rng.choice([0.0, 4.0, 100.0])))
+        max_clock = int(rng.choice([300, 600, 1000, 2500]))
+        m = int(rng.choice([129, 300, 700]))
+        seeds = rng.integers(1, 2 ** 62, m, dtype=np.uint64)
+        ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds, max_clock, threads=8, history_cap=96)
+        nc = amd.NodeConfig(kw.get("target_commit_interval", 100000), kw.get("delta", 20), kw.get("gamma", 2.0), kw.get("lambda_", 0.5))
+        part = (kw["partition_size"], kw["partition_start"], kw["partition_end"]) if "partition_size" in kw else None
+        sim = amd.BatchSimulator.new(seeds, n, amd.RandomDelay.new(kw["mean"], kw["variance"]), nc, commands_per_epoch=kw.get("commands_per_epoch", 30000),
+                                     equivocate_every=kw.get("equivocate_every", 0), drop_per_million=kw.get("drop_per_million", 0), partition=part,
+                                     quirks=kw.get("quirks", 0), calendar_queue=bool(rng.random() < 0.3), max_steps_per_launch=int(rng.choice([0, 0, 173])),
+                                     lanes_per_wavefront=int(rng.choice([16, 32, 64])), block_capacity=max_clock + 64)
+        on_quad += bool(sim.layout()["kernel_class"] & 16384)
+        res = sim.loop_until(max_clock, allow_faults=True)
+        assert not res.faults.any(), (kw, sorted(set(int(f) for f in res.faults)), res.counters, sim.layout())
+        assert (res.commit_counts == ref["commit_counts"]).all(), kw
+        assert (res.active_rounds == ref["active_rounds"]).all(), kw
+        assert (res.last_committed_states == ref["last_states"]).all(), kw
+        assert (res.committed_histories(96) == ref["histories"]).all(), kw
+        c, rc = res.counters, ref["counters"]
+        for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
+            assert c[key] == rc[key], (key, kw)
+    assert on_quad >= 5, on_quad
+
+
 # the same for networks of 33..128 nodes: the cooperative large-network kernel (lanes per wavefront 1..32, multi-launch)
 @pytest.mark.gpu
 @pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_LARGE_CHUNKS", "3"))))

@@ -86,6 +86,24 @@ def test_device_image_equals_oracle_image(oracle, name):
             assert a == b, (name, t, node)
 
 
+@pytest.mark.gpu
+def test_device_image_follows_the_state_across_runs_of_one_batch(oracle):
+    """The library keeps the last image it built (size query + fill = one build); anything that writes the state rows must drop it."""
+    import librabft_simulator_amd as amd
+    seed = 9
+    cfg = oracle.make_config(math_mode=1, num_nodes=4)
+    batch = amd.BatchSimulator.new(np.array([seed], dtype=np.uint64), 4, amd.RandomDelay.new(10.0, 4.0), amd.NodeConfig())
+    seen = set()
+    for t in (300, 700, 300):
+        batch.reset()
+        res = batch.loop_until(t)
+        for node in (2, 2, 0):
+            img = res.save_node(0, node)
+            assert img == oracle.OracleSim(cfg, seed).run_until(t).save_node(node), (t, node)
+            seen.add(img)
+    assert len(seen) == 4
+
+
 # Nodes that have changed epoch carry their retired record stores (past_record_stores, node.rs:43,233-238,331-348): c5live-shaped runs.
 EPOCH_CASES = {
     "n4_q3_cpe5": (dict(num_nodes=4, commands_per_epoch=5, quirks=3), 5, (400, 1000)),
