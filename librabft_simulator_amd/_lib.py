@@ -15,6 +15,7 @@ LBFT_ERR_HIP = -2
 LBFT_ERR_UNSUPPORTED = -3
 LBFT_ERR_STATE = -4
 LBFT_ERR_FAULT = -5
+LBFT_FAULT_TRACE_OVERFLOW = 1 << 11  # include/lbft.h: a node went past the round-switch trace's capacity
 
 FAULT_NAMES = {
     1 << 0: "queue_overflow", 1 << 1: "snapshot_overflow", 1 << 2: "block_overflow", 1 << 3: "log_overflow",
@@ -136,6 +137,26 @@ class LbftError(RuntimeError):
         self.code = code
 
 
+def _one_hip_runtime():
+    """PyTorch-ROCm wheels ship their own libamdhip64.so.7 / libhsa-runtime64 under torch/lib.  A process must hold ONE ROCr runtime: if
+    liblbft_hip.so pulls in /opt/rocm's first and torch is imported afterwards, torch loads its own copy next to it and finds no device
+    (torch.cuda.is_available() turns False).  Loaded the other way round, liblbft_hip.so's libamdhip64.so.7 resolves to the copy already
+    in the process.  So: when torch is installed but not imported yet, map torch's runtime first."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load liblbft_hip.so (built in-tree by librabft_simulator_amd.build)."""
     global _lib
@@ -145,6 +166,7 @@ def lib():
         raise ImportError(
             "%s is missing: build it with `python -m librabft_simulator_amd.build` (needs hipcc). "
             "There is no CPU fallback." % LIB_PATH)
+    _one_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.lbft_batch_create.argtypes = [C.POINTER(LbftConfig), vp, C.c_size_t, C.c_int, C.POINTER(vp)]

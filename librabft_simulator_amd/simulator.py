@@ -282,11 +282,24 @@ class BatchSimulator:
         directory (bft-lib/src/simulator.rs:380-381, data_writer.rs): when given, the round-switch trace is recorded on
         the device and ``round_switches.txt`` / ``number_of_messages.txt`` of instance 0 are written there in the
         reference's CSV format.  ``round_trace=N`` only records (N rounds per node) for ``BatchResult.round_switches``."""
-        if csv_path is not None and round_trace is None:
-            round_trace = min(int(max_clock) + 64, 1 << 16)  # a round takes at least one time unit (n <= 2, zero delays)
+        # The trace rows are allocated for EVERY instance of the batch (num_nodes x round_trace words each).  Left to this method, the
+        # capacity starts from a realistic bound -- a round of >= 3 nodes takes two network hops, max_clock / 5 rounds is generous for
+        # delays of mean >= 5 -- and only a run that overflows it (F_TRACE_OVERFLOW: tiny networks, near-zero delays) is repeated with
+        # the worst case, one round per time unit (at most 65 536 rounds: longer horizons need an explicit round_trace).
+        auto = csv_path is not None and round_trace is None
+        worst = min(int(max_clock) + 64, 1 << 16)
+        if auto:
+            round_trace = min(int(max_clock) // 5 + 64, worst)
         if round_trace:
             check(_lib.lib().lbft_batch_enable_round_trace(self._h, int(round_trace)))
-        check(_lib.lib().lbft_batch_run_until(self._h, int(max_clock)), allow_fault=allow_faults)
+        rc = check(_lib.lib().lbft_batch_run_until(self._h, int(max_clock)), allow_fault=allow_faults or auto)
+        if auto and rc == _lib.LBFT_ERR_FAULT:
+            if round_trace < worst and (BatchResult(self).faults & _lib.LBFT_FAULT_TRACE_OVERFLOW).any():
+                self.reset()
+                check(_lib.lib().lbft_batch_enable_round_trace(self._h, worst))
+                rc = check(_lib.lib().lbft_batch_run_until(self._h, int(max_clock)), allow_fault=True)
+            if rc == _lib.LBFT_ERR_FAULT and not allow_faults:
+                check(rc)
         res = BatchResult(self)
         if csv_path is not None:
             write_data_files(csv_path, *res.round_switches(0), self.num_nodes)

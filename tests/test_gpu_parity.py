@@ -366,11 +366,16 @@ def test_full_size_65536x4_properties(amd, oracle):
 def test_round_switch_csv_equals_reference_data_writer(amd, oracle, tmp_path):
     """`--create_csv` (bft-lib/src/data_writer.rs): device trace == the oracle's DataWriter, and the files have the
     reference's layout (header `node i`, empty cells, one message count)."""
-    for n, max_clock, kw in ((3, 1000, {}), (4, 2000, {}), (8, 600, {}), (5, 1500, dict(mean=10.0, variance=400.0))):
+    # (the last two: rounds far shorter than the trace capacity loop_until starts from -- the run is repeated with the worst-case capacity)
+    for n, max_clock, kw in ((3, 1000, {}), (4, 2000, {}), (8, 600, {}), (5, 1500, dict(mean=10.0, variance=400.0)), (2, 700, dict(mean=1.0, variance=0.0)),
+                             (1, 500, dict(delta=4, gamma=1.0))):
         seeds = np.arange(50, 58, dtype=np.uint64)
-        sim = amd.BatchSimulator.new(seeds, n, amd.RandomDelay.new(kw.get("mean", 10.0), kw.get("variance", 4.0)))
+        sim = amd.BatchSimulator.new(seeds, n, amd.RandomDelay.new(kw.get("mean", 10.0), kw.get("variance", 4.0)),
+                                     amd.NodeConfig(100000, kw.get("delta", 20), kw.get("gamma", 2.0), 0.5))
         res = sim.loop_until(max_clock, csv_path=str(tmp_path / ("csv%d" % n)))
         cfg = oracle.make_config(num_nodes=n, math_mode=1, **kw)
+        if n <= 2:
+            assert res.active_rounds.max() > max_clock // 5 + 64  # (the first capacity did overflow)
         for i, seed in enumerate(seeds):
             o = oracle.OracleSim(cfg, int(seed)).enable_data_writer()
             o.run_until(max_clock)
