@@ -5,8 +5,8 @@ include/lbft.h.  The package contains only what that path needs: csrc/ (hand-wri
 the C ABI), the ctypes binding and the host-side mirror of the reference's simulator interface.
 """
 from ._lib import LbftError, lib  # noqa: F401
-from .simulator import (BatchResult, BatchSimulator, Command, GlobalTime, NodeConfig, RandomDelay,  # noqa: F401
-                        Simulator, State)
+from .simulator import (BatchResult, BatchSimulator, Command, Duration, GlobalTime, NodeConfig, NodeTime,  # noqa: F401
+                        RandomDelay, Simulator, State)
 
-__all__ = ["BatchSimulator", "BatchResult", "Simulator", "RandomDelay", "NodeConfig", "GlobalTime", "State",
+__all__ = ["BatchSimulator", "BatchResult", "Simulator", "RandomDelay", "NodeConfig", "GlobalTime", "NodeTime", "Duration", "State",
            "Command", "LbftError", "lib"]

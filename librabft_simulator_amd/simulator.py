@@ -22,7 +22,13 @@ from ._lib import COMMIT_DTYPE, RECORD_HASH_DTYPE, LbftActions, LbftConfig, Lbft
 
 Command = namedtuple("Command", ["proposer", "index"])  # simulated_context.rs:31-35
 Author = int
-NodeTime = int
+
+
+class NodeTime(int):
+    """bft-lib/src/base_types.rs NodeTime(i64): a node's local clock (global time minus its startup time)."""
+
+    def __repr__(self):
+        return "NodeTime(%d)" % int(self)
 
 
 class State(int):
@@ -33,10 +39,20 @@ class State(int):
 
 
 class GlobalTime(int):
-    """bft-lib/src/simulator.rs:35-37."""
+    """bft-lib/src/simulator.rs:35-37; the conversions of :120-126 (a node's startup time: ``BatchResult.startup_times``)."""
 
     def __repr__(self):
         return "GlobalTime(%d)" % int(self)
+
+    def to_node_time(self, startup_time):
+        return NodeTime(int(self) - int(startup_time))
+
+    @classmethod
+    def from_node_time(cls, node_time, startup_time):
+        return cls(int(node_time) + int(startup_time))
+
+    def __add__(self, duration):  # GlobalTime + Duration (simulator.rs:90-96)
+        return GlobalTime(int(self) + int(duration))
 
 
 class Duration(int):

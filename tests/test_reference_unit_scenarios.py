@@ -128,3 +128,13 @@ def test_simulated_context_scenario_device(oracle):
     for i in range(len(seeds)):
         h = [[(x["proposer"], x["index"], x["time"]) for x in hist[i, node]] for node in range(2)]
         _check_simulated_context_scenario(h, cc[i], res.epochs[i], [int(x) for x in res.last_committed_states[i]])
+
+
+def test_time_conversion_of_the_host_mirror():
+    """bft-lib/src/unit_tests/simulator_tests.rs:6-12, on the Python mirror of GlobalTime / NodeTime (simulator.rs:120-126), and
+    base_type_tests.rs:6-9's arithmetic on the wrapped integers."""
+    from librabft_simulator_amd import Duration, GlobalTime, NodeTime
+    x, start = GlobalTime(15), GlobalTime(3)
+    assert x.to_node_time(start) == NodeTime(12) and isinstance(x.to_node_time(start), NodeTime)
+    assert GlobalTime.from_node_time(NodeTime(12), start) == x
+    assert GlobalTime(3) + Duration(4) == GlobalTime(7) and repr(GlobalTime(3) + Duration(4)) == "GlobalTime(7)"
