@@ -1,9 +1,6 @@
+# scratch driver for one gpurun call: the whole device suite, then the smoke entry point
 set -u
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r03k
-timeout 300 python tools/sweep.py --libs liblbft_hip_msgprof.so --grid 0:-1 > gpurun_out/r03k/msgprof.jsonl 2> gpurun_out/r03k/err.txt; tail -3 gpurun_out/r03k/err.txt
-python - <<'PY'
-import json
-for l in open('gpurun_out/r03k/msgprof.jsonl'):
-    d=json.loads(l); print(d['kernel_ms'], d.get('counts'), d.get('wave_steps'), d['events'])
-PY
+mkdir -p gpurun_out/suite
+( time timeout 1200 python -m pytest tests/ -x -q -m gpu ) > gpurun_out/suite/pytest_gpu.txt 2>&1; echo rc=$?; tail -6 gpurun_out/suite/pytest_gpu.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
