@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Headline benchmark: simulated consensus rounds/sec on 65 536 x 4-node LibraBFTv2 instances per GPU.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched with
-torch.distributed.run, one rank per GPU (RCCL).  A "step" is one pass of the hot path over one batch of
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it with
+torch.distributed.run, one rank per GPU (RCCL) -- and when it is started WITHOUT a launcher (`python bench.py --gpus 8`:
+no WORLD_SIZE in the environment) it re-executes itself under `python -m torch.distributed.run --nproc-per-node N`
+(rendezvous on 127.0.0.1, a free port), so the command line alone decides the number of ranks; a launcher whose
+WORLD_SIZE disagrees with --gpus is an error.  `n_gpus` in the output is the communicator's size.  A "step" is one pass of the hot path over one batch of
 synthetic input: Simulator::new + loop_until(max_clock) for every instance of the batch (seeds already
 resident in HBM), including the device-side reduction and the D2H copy of the counters.  Rank 0 prints
 ONE JSON line.  Instances shard across ranks with no data-path collective (weak scaling: 65 536 instances
-per GPU); one all-reduce aggregates the throughput counters.
+per GPU); ONE collective (an all-gather of one counter row per rank, reduced locally) aggregates the throughput counters.
 """
 import argparse
 import json
@@ -37,7 +40,23 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses HIP device 0")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the oracle sample")
+    ap.add_argument("--native-collective", action="store_true",
+                    help="also aggregate the counters through the C ABI's own collective (lbft_batch_counters_allreduce: ncclAllGather on a "
+                         "communicator built with ncclCommInitRank, one device per rank) and check it against the torch.distributed aggregate")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run with N ranks on this node."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def algorithmic_bytes_per_event(layout, counters):
@@ -80,6 +99,56 @@ def measured_traffic_gb():
                 "source_hash": t.get("source_hash")}
     except Exception:
         return None
+
+
+def measured_issue():
+    """Instruction-issue figures of lbft_k_run per launch from the SQ passes of the same stamped profile (the bound that binds: the
+    headline kernel is VALU-issue / divergence bound, not HBM bound): VALU instructions, the share of the chip's VALU issue slots they
+    occupy (4 cycles per wavefront instruction on a 16-lane SIMD, 1 024 SIMDs), and the lanes active per VALU instruction."""
+    path = os.path.join(ROOT, "profiles", "current", "pmc_issue.json")
+    try:
+        from librabft_simulator_amd.build import source_hash
+        with open(path) as f:
+            t = json.load(f)
+        if t.get("source_hash") != source_hash():
+            return None
+        cycles = t["GRBM_GUI_ACTIVE"] / 8.0  # (summed over the 8 XCDs)
+        return {"valu_insts": t["SQ_INSTS_VALU"], "salu_insts": t.get("SQ_INSTS_SALU"),
+                "valu_busy_frac": t["SQ_INSTS_VALU"] * 4.0 / (1024.0 * cycles),
+                "lanes_per_valu_inst": t["SQ_THREAD_CYCLES_VALU"] / t["SQ_INSTS_VALU"],
+                "wave_cycles_issuing_frac": t.get("SQ_ACTIVE_INST_ANY", 0) / max(t.get("SQ_WAVE_CYCLES", 1), 1) if t.get("SQ_ACTIVE_INST_ANY") else None,
+                "wave_cycles_waiting_frac": t.get("SQ_WAIT_ANY", 0) / max(t.get("SQ_WAVE_CYCLES", 1), 1) if t.get("SQ_WAIT_ANY") else None,
+                "profile": t.get("profile"), "source_hash": t.get("source_hash")}
+    except Exception:
+        return None
+
+
+def native_collective(res, rank, world, local_rank):
+    """The C ABI's own collective on N ranks: a RCCL communicator built here with ncclCommInitRank (the unique id travels through
+    torch.distributed's object broadcast), then lbft_batch_counters_allreduce = ONE ncclAllGather on the batch's stream."""
+    import ctypes
+    import torch.distributed as dist
+    rccl = ctypes.CDLL("librccl.so.1")
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid = UniqueId()
+    box = [None]
+    if rank == 0:
+        assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+        box[0] = bytes(ctypes.string_at(ctypes.byref(uid), 128))
+    dist.broadcast_object_list(box, src=0)
+    ctypes.memmove(ctypes.byref(uid), box[0], 128)
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    comm = ctypes.c_void_p()
+    rc = rccl.ncclCommInitRank(ctypes.byref(comm), world, uid, rank)
+    if rc != 0:
+        raise RuntimeError("ncclCommInitRank failed: %d" % rc)
+    try:
+        return res.counters_allreduce(comm.value)
+    finally:
+        rccl.ncclCommDestroy(comm)
 
 
 def cpu_baseline(args, nodes, max_clock):
@@ -169,9 +238,14 @@ def main():
     args = parse()
     import numpy as np
     import torch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); start it as `python bench.py --gpus N` "
+                         "or under torch.distributed.run --nproc-per-node N with the same N" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.single_device:
@@ -221,12 +295,22 @@ def main():
     agg = aggregate_counters(c, device=("cuda" if (dist is None or args.backend == "nccl") else None), extra_max=[elapsed])
     rounds, commits, events, faulted = float(agg["rounds"]), float(agg["commits"]), float(sum(agg["events"])), float(agg["faulted_instances"])
     elapsed = float(agg["extra_max"][0])
+    if dist is not None:
+        world = dist.get_world_size()  # n_gpus = the communicator's size
+    native = None
+    if args.native_collective and dist is not None and args.backend == "nccl" and not args.single_device:
+        nat = native_collective(res, rank, world, local_rank)
+        keys = ("events", "rounds", "commits", "rng_draws", "events_scheduled", "faulted_instances", "timers_folded", "node_updates",
+                "max_queue", "max_snapshots", "max_blocks")
+        native = {"ranks": world, "matches_torch_aggregate": all(nat[k] == agg[k] for k in keys), "rounds": nat["rounds"]}
     if rank == 0:
         per_step = elapsed / args.steps
         k_ms = float(np.mean(kernel_ms))
         layout = sim.layout()
         bpe = algorithmic_bytes_per_event(layout, c)
-        traffic = measured_traffic_gb() if (m, args.nodes, args.max_clock) == (65536, 4, 1000) else None
+        headline = (m, args.nodes, args.max_clock) == (65536, 4, 1000)
+        traffic = measured_traffic_gb() if headline else None
+        issue = measured_issue() if headline else None
         local_events = sum(c["events"])
         achieved = local_events * bpe / (k_ms * 1e-3) / 1e9
         ex_bytes, pops = executed_bytes(layout, c)
@@ -250,24 +334,44 @@ def main():
             "events_per_s": events / per_step,
             "events_note": "queue_pops_per_s = events the device executes; events_per_s = reference-equivalent events (adds the duplicate timers folded at scheduling time)",
             "faulted_instances": faulted,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            # `achieved` / `frac`: the algorithmic bytes of what the device EXECUTES (folded duplicate timers never reach the queue;
+            # cancelled timers and requests do not write node rows back) over the kernel's duration -- the honest fraction.  The
+            # SURVEY 8(d) figure charged to every reference-equivalent event stands beside it as `frac_reference_equivalent`.
+            "roofline": {"bound": "hbm", "achieved": achieved_ex, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_ex / HBM_PEAK_GBS,
                          "traffic": traffic["gb_corrected"] if traffic else None, "traffic_unit": "GB per launch",
                          "traffic_detail": traffic, "kernel": run_kernel_name(layout.get("kernel_class", 0)), "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_event": bpe, "algorithmic_gb_per_launch": local_events * bpe / 1e9,
-                         "events_per_launch": local_events,
-                         # the same roofline with traffic charged only where the device moves rows (folded duplicate timers never
-                         # reach the queue; cancelled timers and requests do not write node rows back): the stricter of the two
-                         "executed": {"achieved": achieved_ex, "frac": achieved_ex / HBM_PEAK_GBS, "gb_per_launch": ex_bytes / 1e9,
-                                      "queue_pops_per_launch": pops, "node_updates_per_launch": c.get("node_updates"),
-                                      "timers_folded_per_launch": c.get("timers_folded"),
-                                      "queue_pops_per_s": pops / (k_ms * 1e-3)},
+                         "algorithmic_gb_per_launch": ex_bytes / 1e9,
+                         "queue_pops_per_launch": pops, "node_updates_per_launch": c.get("node_updates"),
+                         "timers_folded_per_launch": c.get("timers_folded"), "queue_pops_per_s": pops / (k_ms * 1e-3),
+                         "executed_le_traffic": (ex_bytes / 1e9 <= traffic["gb_corrected"]) if traffic else None,
+                         "frac_reference_equivalent": achieved / HBM_PEAK_GBS,
+                         "reference_equivalent": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "bytes_per_event": bpe,
+                                                  "gb_per_launch": local_events * bpe / 1e9, "events_per_launch": local_events},
+                         # (kept for readers of earlier rounds' lines: the same numbers under their old names)
+                         "executed": {"achieved": achieved_ex, "frac": achieved_ex / HBM_PEAK_GBS, "gb_per_launch": ex_bytes / 1e9},
+                         # the bound that binds ("report both ... events/s per CU"): instruction issue under divergence
+                         "issue": dict(issue or {}, pops_per_s_per_cu=pops / (k_ms * 1e-3) / 256.0,
+                                       events_per_s_per_cu=local_events / (k_ms * 1e-3) / 256.0,
+                                       note="VALU-issue / divergence bound: see DESIGN.md section 5; counters from the stamped PMC profile (null when stale)"),
                          "layout": layout},
         }
+        if native is not None:
+            out["native_collective"] = native
         if args.parity_instances > 0:  # (rank 0's shard of the timed batch; oracle = test infrastructure, used only as the checker)
             out["parity"] = parity_gate(args, sim, res, seeds, args.nodes, args.max_clock)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args, args.nodes, args.max_clock)
         print(json.dumps(out))
+        if out["roofline"]["executed_le_traffic"] is False:  # the "algorithmic" bytes must be a lower bound of what crosses the L2 boundary
+            sys.stderr.write("bench.py: executed algorithmic bytes %.2f GB exceed the measured traffic %.2f GB\n" % (ex_bytes / 1e9, traffic["gb_corrected"]))
+            if dist is not None:
+                dist.destroy_process_group()
+            sys.exit(4)
+        if native is not None and not native["matches_torch_aggregate"]:
+            sys.stderr.write("bench.py: the native collective disagrees with the torch.distributed aggregate\n")
+            if dist is not None:
+                dist.destroy_process_group()
+            sys.exit(5)
         if out.get("parity", {}).get("mismatches", 0) != 0:
             sys.stderr.write("bench.py: PARITY GATE FAILED: %s\n" % json.dumps(out["parity"]))
             if dist is not None:

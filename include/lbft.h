@@ -172,8 +172,10 @@ int lbft_batch_last_committed_states(const lbft_batch* b, uint64_t* out);
  * before the run; otherwise such a node is LBFT_ERR_UNSUPPORTED (nodes still in epoch 0 always work). */
 int lbft_batch_save_node(const lbft_batch* b, size_t inst, uint32_t node, void* buf, size_t cap, size_t* len);
 /* Multi-GPU: instances shard over the GPUs with no data-path collective; the run's ONE collective aggregates the
- * throughput counters of all ranks: a RCCL ncclAllReduce(ncclSum) over xGMI of the eleven additive counters of lbft_batch_counters
- * (followed by a three-word ncclMax for the high-water marks).  `nccl_comm` is the caller's ncclComm_t for this batch's device (any
+ * throughput counters of all ranks: ONE RCCL ncclAllGather over xGMI of the fourteen counter words of lbft_batch_counters per rank,
+ * reduced locally (the eleven additive counters summed, the three high-water marks by maximum: two reduction operators, which one
+ * ncclAllReduce cannot mix -- the same single collective the Python host issues through torch.distributed, distributed.py
+ * gather_rows).  `nccl_comm` is the caller's ncclComm_t for this batch's device (any
  * host language: the library loads librccl itself, on first use); the collective runs on the batch's stream.  `out` receives the
  * aggregate; launches is this rank's.  Every rank of the communicator must call it. */
 int lbft_batch_counters_allreduce(lbft_batch* b, void* nccl_comm, lbft_counters* out);
@@ -197,7 +199,8 @@ void lbft_batch_destroy(lbft_batch* b);
 void* lbft_batch_stream(const lbft_batch* b);
 int lbft_batch_last_run_ms(const lbft_batch* b, float* init_ms, float* run_ms);
 size_t lbft_batch_device_bytes(const lbft_batch* b);
-/* Sizes behind the roofline arithmetic (bench.py): out[8] = bytes of one node's rows, of one queued event, of one
+/* Sizes behind the roofline arithmetic (bench.py): out[8] = bytes ONE EVENT MOVES of a node's rows (the fixed words + set extension
+ * words of a node burst; plus the node's 2n hcbr words where they ride in the burst: lbft_k_run0q), of one queued event, of one
  * notification snapshot, of one block record, HBM bytes per instance, LDS-resident queue slots, lanes per wavefront,
  * kernel size class | heap-queue flag << 8 | calendar-queue flag << 9 | two-wavefronts-per-SIMD ("lean") kernel flag << 10 |
  * cooperative-bulk-send flag << 11 (large networks on the calendar queue: all lanes of a wavefront execute a network's broadcasts) |

@@ -137,14 +137,39 @@ class LbftError(RuntimeError):
         self.code = code
 
 
+def _needed_hip_soname(path, tag_wanted=1):
+    """DT_NEEDED entry of `path` that names the HIP runtime (e.g. "libamdhip64.so.7"; tag_wanted = 14: the file's own DT_SONAME), or
+    None (pure-Python ELF walk)."""
+    import struct
+    try:
+        blob = open(path, "rb").read()
+        shoff, = struct.unpack_from("<Q", blob, 0x28)
+        shentsize, shnum, _ = struct.unpack_from("<HHH", blob, 0x3A)
+        secs = [struct.unpack_from("<IIQQQQII", blob, shoff + i * shentsize) for i in range(shnum)]
+        for name, typ, flags, addr, off, size, link, info in secs:
+            if typ == 6:  # SHT_DYNAMIC
+                _, _, _, _, stroff, strsize, _, _ = secs[link]
+                for k in range(size // 16):
+                    tag, val = struct.unpack_from("<qQ", blob, off + 16 * k)
+                    if tag == tag_wanted:  # DT_NEEDED = 1, DT_SONAME = 14
+                        s = blob[stroff + val:blob.index(b"\0", stroff + val)].decode()
+                        if s.startswith("libamdhip64"):
+                            return s
+    except Exception:
+        pass
+    return None
+
+
 def _one_hip_runtime():
     """PyTorch-ROCm wheels ship their own libamdhip64.so.7 / libhsa-runtime64 under torch/lib.  A process must hold ONE ROCr runtime: if
     liblbft_hip.so pulls in /opt/rocm's first and torch is imported afterwards, torch loads its own copy next to it and finds no device
     (torch.cuda.is_available() turns False).  Loaded the other way round, liblbft_hip.so's libamdhip64.so.7 resolves to the copy already
-    in the process.  So: when torch is installed but not imported yet, map torch's runtime first."""
+    in the process.  So: when torch is installed but not imported yet, map torch's runtime first -- unless LBFT_NO_TORCH_HIP=1 says not
+    to (a process that will never import torch), or torch's bundled runtime has another soname (major version) than the one
+    liblbft_hip.so was linked against: binding to a foreign HIP runtime is worse than the system one, so /opt/rocm's is used then."""
     import importlib.util
     import sys
-    if "torch" in sys.modules:
+    if "torch" in sys.modules or os.environ.get("LBFT_NO_TORCH_HIP", "") not in ("", "0"):
         return
     try:
         spec = importlib.util.find_spec("torch")
@@ -152,9 +177,14 @@ def _one_hip_runtime():
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return
-    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-    if os.path.exists(path):
-        C.CDLL(path, mode=C.RTLD_GLOBAL)
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    path = os.path.join(libdir, "libamdhip64.so")
+    if not os.path.exists(path):
+        return
+    want, have = _needed_hip_soname(LIB_PATH), _needed_hip_soname(path, 14)
+    if want and have and want != have:
+        return  # torch bundles a runtime of another soname than this library needs: leave it to the loader (/opt/rocm)
+    C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
 def lib():

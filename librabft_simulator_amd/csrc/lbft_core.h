@@ -104,6 +104,25 @@ typedef int64_t i64;
 #ifndef LBFT_C0_QUAD
 #define LBFT_C0_QUAD 1   // large class-0 batches of 4-node networks with unit rights and log-normal delays run lbft_k_run0q (SimT<9>)
 #endif
+// Light-event drain (kernel class 0): a popped event that needs no update_node -- a request under the reference's routing (quirk Q1: one
+// delay sample + one push) or a cancelled timer (three words of its node) -- is finished right after the pop and the lane pops again,
+// up to LBFT_DRAIN times per step, so that it enters the heavy part of the step (node burst, update_node, send loop) with an event that
+// needs it.  Per-network event order and RNG draw order are unchanged.  (23 % of the headline batch's pops are such events.)
+#ifndef LBFT_DRAIN
+#define LBFT_DRAIN 0
+#endif
+#ifndef LBFT_DRAIN_TIMERS
+#define LBFT_DRAIN_TIMERS 1
+#endif
+#ifndef LBFT_DRAIN_REQ
+#define LBFT_DRAIN_REQ 1
+#endif
+// (kernel class 0) the notification snapshot of an event is allocated and written BEFORE the send loop, at one site that every sending
+// lane reaches together, instead of inside the loop at the first notification whose time lies within the horizon (a different
+// iteration for lanes whose list starts behind a sync request); a snapshot that ends up with no reference is freed as before.
+#ifndef LBFT_C0_SNAP_HOIST
+#define LBFT_C0_SNAP_HOIST 0
+#endif
 #ifndef LBFT_POPC_MAX_LPW
 #define LBFT_POPC_MAX_LPW 8u  // networks per wavefront up to which lbft_k_run0s is used (measured: 1 024 x 4: 6.3 against 7.5 ms, 8 192: 10.9 against 12.1,
                               // 16 384 (8 per wavefront): 14.8 against 15.9; 32 per wavefront: the lane-private scan stops at the queue's length and wins)
@@ -2624,6 +2643,10 @@ struct SimT {
     i32 slot = -1, slot_twin = -1, rs = 0;
     u32 refs = 0, refs_twin = 0, rrefs = 0;
     bool equivocal = false;
+    if (C0 && LBFT_C0_SNAP_HOIST && n_a) {
+      slot = snap_alloc();
+      if (slot < 0) slot = -2; else write_snapshot(node, (u32)slot);
+    }
     for (u32 j = 0; j < total; j++) {
       // receivers.shuffle(rng) (simulator.rs:343) / create_request + senders.shuffle(rng) (simulator.rs:365-370): each
       // drawn right before the delays of its list; one site for both lists (they never start at the same j)
@@ -3080,7 +3103,8 @@ struct SimT {
   // scalar send loop handles) + step_end (write-back); the cooperative kernels run coop_bulk between the two.
   struct StepCtx { u32 node, sender, kind; i32 t_event; bool do_update; };
   // (fkey, fbest): class 8 only -- the pop's scan was done by the whole wavefront (run_popc / coop_find): smallest LDS-resident key, its slot
-  LBFT_HD bool step_begin(StepCtx& c, u64 fkey = 0, u32 fbest = 0) {  // false: the queue is empty
+  // `pre`: the event was popped by the caller already (light-event drain): (pt, pkind, pmeta)
+  LBFT_HD bool step_begin(StepCtx& c, u64 fkey = 0, u32 fbest = 0, bool pre = false, i32 pt = 0, u32 pkind = 0, u32 pmeta = 0) {  // false: the queue is empty
     {
       i32 t; u32 kind, meta;
       // A response that spans several epochs (quirks bit 0) is one event but several steps: between two epochs the reference runs
@@ -3089,6 +3113,7 @@ struct SimT {
       // registers alive across it).
       const bool resumed = q1() && cont != 0;
       if (resumed) { t = clock; kind = 2; meta = ld(I_CONT_META); }
+      else if (pre) { t = pt; kind = pkind; meta = pmeta; }
       else {
         if (POPC) {  // (the scan was done by the whole wavefront: run_popc)
           if (qlen == 0) return false;
@@ -3196,6 +3221,46 @@ struct SimT {
     }
     return true;
   }
+  // ---- light-event drain (LBFT_DRAIN; class 0 only: reference request routing, no trace, lossless) ----
+  static constexpr u32 DRAIN = C0 ? (u32)LBFT_DRAIN : 0u;
+  // If the popped event needs no update_node, process it completely -- exactly what step_begin / send_loop / step_end do for it -- and
+  // return true; otherwise touch nothing and return false.
+  LBFT_HD bool try_light(i32 t, u32 kind, u32 meta) {
+    const u32 node = meta & 0xffu, sender = (meta >> 8) & 0xffu, slot = meta >> 16;
+    if (LBFT_DRAIN_REQ && kind == 1) {  // DataSyncRequestEvent, answered on the requester (simulator.rs:441-453): one response, no node state
+      if (t > clock) clock = t;
+      last_node = node;
+      ev1++; LBFT_STAT(3);
+      i64 d = sample_delay();
+      i64 tr = d > INT64_MAX - (i64)clock ? INT64_MAX : (i64)clock + d;
+      push_event(tr, 2, node, sender, 0);
+      return true;
+    }
+    if (LBFT_DRAIN_TIMERS && kind == 3) {  // UpdateTimerEvent (simulator.rs:403-415): cancelled?
+      const i32 clk = t > clock ? t : clock;
+      const u32 nb = boff(OFFNODE() + node * NWORDS());
+      const i32 ign = (i32)ldf(nb, NF_IGNORE_UNTIL);
+      const u32 ltt = ldf(nb, NF_LAST_TIMER_T);
+      if (clk > ign) return false;
+      clock = clk;
+      last_node = node;
+      LBFT_STAT(0); LBFT_STAT(1);
+      ev3 += 1 + slot;
+      if (LBFT_UNLIKELY((u32)clk == ltt)) {  // folded duplicates of this timer (only when a later timer fell past the horizon)
+        const u32 dups = ldf(nb, NF_TIMER_DUPS);
+        if (dups != 0) {
+          u32 ds = ldf(nb, NF_DUP_STAMP) + 1;
+          vd_stamp = (vd_time == (u32)clk && vd_stamp > ds) ? vd_stamp : ds;
+          vd_time = (u32)clk;
+        }
+        ev3 += dups;
+        stf(nb, NF_TIMER_DUPS, 0);
+        stf(nb, NF_LAST_TIMER_T, 0xffffffffu);
+      }
+      return true;
+    }
+    return false;
+  }
   LBFT_HD void step_end(const StepCtx& c) {
     if (c.do_update) {
       LBFT_DRAIN_VMEM();
@@ -3216,6 +3281,23 @@ struct SimT {
     for (;;) {
       if (steps >= max_steps) return false;
       StepCtx c;
+      if (DRAIN) {
+        i32 t; u32 kind, meta;
+        if (!pop_event(t, kind, meta)) return true;
+        steps++;
+        bool have = true;
+        for (u32 d = 0; d < DRAIN; d++) {
+          if (!try_light(t, kind, meta)) break;
+          LBFT_STEP_DONE();
+          have = false;
+          if (steps >= max_steps) return false;
+          if (!pop_event(t, kind, meta)) return true;
+          steps++;
+          have = true;
+        }
+        if (have) { step_begin(c, 0, 0, true, t, kind, meta); step_end(c); LBFT_STEP_DONE(); }
+        continue;
+      }
       if (!step_begin(c)) return true;
       steps++;
       // (a kernel class with cooperative bulk sends that is run lane-per-network -- the generic read-back class, the host
@@ -3243,6 +3325,29 @@ struct SimT {
       u64 fkey; u32 fbest;
       if (PAIR) coop_find_cols(kw, go ? qlen : 0u, fkey, fbest);
       else coop_find(kw, fkey, fbest);
+      if (DRAIN) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        i32 t = 0; u32 kind = 0, meta = 0;
+        bool have = go;
+        if (go) { pop_take(fkey, fbest, t, kind, meta); steps++; }
+        for (u32 d = 0; d < DRAIN; d++) {
+          const bool light = have && try_light(t, kind, meta);
+          if (light) have = false;
+          const bool again = light && steps < max_steps && qlen != 0;
+          if (__ballot(again) == 0) break;
+          // (only the columns whose lane asks for another event are scanned again)
+          if (PAIR) coop_find_cols(kw, again ? qlen : 0u, fkey, fbest);
+          else coop_find(kw, fkey, fbest);
+          if (again) { pop_take(fkey, fbest, t, kind, meta); steps++; have = true; }
+        }
+        if (have) {
+          StepCtx c;
+          step_begin(c, 0, 0, true, t, kind, meta);
+          step_end(c);
+        }
+#endif
+        continue;
+      }
       if (go) {
         StepCtx c;
         step_begin(c, fkey, fbest);

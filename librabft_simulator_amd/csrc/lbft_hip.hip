@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -542,6 +543,7 @@ struct lbft_batch {
   u32* d_unfinished = nullptr;
   u64* d_states_out = nullptr;
   unsigned long long* d_counters = nullptr;
+  mutable std::mutex sn_mutex;  // guards the save_node image cache (sn_*): lbft_batch_save_node takes a const batch but fills the cache
   u32* d_scratch = nullptr;  // m * n words for gathers
   lbft_node_call* d_calls = nullptr;  // lbft_node_calls: the calls of one batch and their result words
   unsigned long long* d_call_out = nullptr;
@@ -1020,7 +1022,8 @@ int lbft_batch_layout(const lbft_batch* b, uint32_t* out) {
   // only touched where a timeout is inserted or copied -- for networks of <= 4 nodes they live in LDS for the whole launch.  A
   // notification snapshot: its fixed words + set extension words; for <= 4 nodes also its 2n hcbr words (always fetched with it), for
   // larger networks the hcbr words an event happens to carry are NOT counted (the figure is a lower bound there).
-  out[0] = (NF_FIXED_WORDS + 4 * (p.mw - 1)) * 4;
+  // (lbft_k_run0q, LBFT_C0_HCREG: the node's 2n hcbr words ride in its burst -- hc_load / hc_store -- and are counted)
+  out[0] = (NF_FIXED_WORDS + 4 * (p.mw - 1) + ((quad_kernel(p) && LBFT_C0_HCREG) ? 2 * p.n : 0)) * 4;
   out[1] = (p.qpack ? 8 : 12);
   out[2] = (S_FIXED_WORDS + 2 * (p.mw - 1) + (p.n <= 4 ? 2 * p.n : 0)) * 4;
   out[3] = (B_WORDS + 4 * (p.mw - 1)) * 4;   // bytes of one block record
@@ -1512,6 +1515,7 @@ int lbft_batch_save_node(const lbft_batch* b, size_t inst, uint32_t node, void* 
   if (!b->ran && !b->manual) { g_err = "run the batch (or start a node-level session) first"; return LBFT_ERR_STATE; }
   HIP_TRY(hipSetDevice(b->device));
   const Params& dp = b->p;
+  std::lock_guard<std::mutex> sn_lock(b->sn_mutex);  // (two threads saving different nodes of one batch share the one-image cache)
   if (b->sn_generation != b->generation || b->sn_inst != inst || b->sn_node != node) {
     // this instance's rows, contiguous on the host (a tile of width 1)
     std::vector<u32> hw(dp.total_words);
@@ -1541,35 +1545,60 @@ int lbft_batch_counters(const lbft_batch* b, lbft_counters* out) {
   return LBFT_OK;
 }
 
-// ---- the run's ONE collective, natively: RCCL all-reduce of the throughput counters over xGMI ----
-// librccl is not linked: it is loaded when the first all-reduce is asked for (a single-GPU user never maps it).
+// ---- the run's ONE collective, natively: every rank contributes its 14 counter words, RCCL over xGMI ----
+// Sums and high-water marks need different reduction operators, which one ncclAllReduce call cannot mix: the collective is ONE
+// ncclAllGather of 14 words per rank, reduced locally (exactly what the Python host does through torch.distributed:
+// librabft_simulator_amd/distributed.py gather_rows).  librccl is not linked: it is loaded when the first aggregation is asked for (a
+// single-GPU user never maps it).
 namespace {
-typedef int (*nccl_allreduce_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, int /*ncclRedOp_t*/, void* /*ncclComm_t*/, hipStream_t);
-nccl_allreduce_fn g_nccl_allreduce = nullptr;
-const int kNcclUint64 = 5, kNcclSum = 0, kNcclMax = 2;  // rccl.h: ncclUint64 = 5; ncclSum = 0, ncclProd = 1, ncclMax = 2
+typedef int (*nccl_allgather_fn)(const void*, void*, size_t, int /*ncclDataType_t*/, void* /*ncclComm_t*/, hipStream_t);
+typedef int (*nccl_commcount_fn)(void* /*ncclComm_t*/, int*);
+nccl_allgather_fn g_nccl_allgather = nullptr;
+nccl_commcount_fn g_nccl_commcount = nullptr;
+const int kNcclUint64 = 5;  // rccl.h: ncclUint64 = 5
+const size_t kCounterWords = 14;
 }
 int lbft_batch_counters_allreduce(lbft_batch* b, void* nccl_comm, lbft_counters* out) {
   if (!b || !nccl_comm || !out) return LBFT_ERR_INVALID;
   if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
-  if (!g_nccl_allreduce) {
+  if (!g_nccl_allgather) {
     void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!h) { g_err = std::string("librccl not found: ") + dlerror(); return LBFT_ERR_HIP; }
-    g_nccl_allreduce = reinterpret_cast<nccl_allreduce_fn>(dlsym(h, "ncclAllReduce"));
-    if (!g_nccl_allreduce) { g_err = "ncclAllReduce not found in librccl"; return LBFT_ERR_HIP; }
+    g_nccl_commcount = reinterpret_cast<nccl_commcount_fn>(dlsym(h, "ncclCommCount"));
+    g_nccl_allgather = reinterpret_cast<nccl_allgather_fn>(dlsym(h, "ncclAllGather"));
+    if (!g_nccl_allgather || !g_nccl_commcount) { g_nccl_allgather = nullptr; g_err = "ncclAllGather / ncclCommCount not found in librccl"; return LBFT_ERR_HIP; }
   }
   HIP_TRY(hipSetDevice(b->device));
+  int world = 0;
+  int rc = g_nccl_commcount(nccl_comm, &world);
+  if (rc != 0 || world < 1) { g_err = "ncclCommCount failed with ncclResult_t " + std::to_string(rc); return LBFT_ERR_HIP; }
   const lbft_counters& c = b->counters;
-  // [0, 11): sums -- ONE ncclAllReduce(ncclSum); [11, 14): high-water marks -- a second, three-word one with ncclMax
-  unsigned long long h[14] = {c.events[0], c.events[1], c.events[2], c.events[3], c.rng_draws, c.rounds, c.commits, c.events_scheduled,
-                              c.faulted_instances, c.timers_folded, c.node_updates, c.max_queue, c.max_snapshots, c.max_blocks};
-  unsigned long long* d = reinterpret_cast<unsigned long long*>(b->d_scratch);  // (>= 256 bytes)
-  HIP_TRY(hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, b->stream));
-  int rc = g_nccl_allreduce(d, d, 11, kNcclUint64, kNcclSum, nccl_comm, b->stream);
-  if (rc == 0) rc = g_nccl_allreduce(d + 11, d + 11, 3, kNcclUint64, kNcclMax, nccl_comm, b->stream);
-  if (rc != 0) { g_err = "ncclAllReduce failed with ncclResult_t " + std::to_string(rc); return LBFT_ERR_HIP; }
-  HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, b->stream));
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  // [0, 11): summed over the ranks; [11, 14): high-water marks, the largest of any rank
+  unsigned long long mine[kCounterWords] = {c.events[0], c.events[1], c.events[2], c.events[3], c.rng_draws, c.rounds, c.commits, c.events_scheduled,
+                                            c.faulted_instances, c.timers_folded, c.node_updates, c.max_queue, c.max_snapshots, c.max_blocks};
+  const size_t scratch_bytes = b->m * b->cfg.num_nodes * sizeof(u64) + 256;  // (lbft_batch_create)
+  const size_t need = ((size_t)world + 1) * sizeof(mine);
+  unsigned long long* d = reinterpret_cast<unsigned long long*>(b->d_scratch);
+  unsigned long long* d_big = nullptr;
+  if (need > scratch_bytes) { HIP_TRY(hipMalloc(&d_big, need)); d = d_big; }
+  std::vector<unsigned long long> all((size_t)world * kCounterWords);
+  int st = LBFT_OK;
+  do {
+    if (hipMemcpyAsync(d, mine, sizeof(mine), hipMemcpyHostToDevice, b->stream) != hipSuccess) { st = LBFT_ERR_HIP; break; }
+    rc = g_nccl_allgather(d, d + kCounterWords, kCounterWords, kNcclUint64, nccl_comm, b->stream);
+    if (rc != 0) { g_err = "ncclAllGather failed with ncclResult_t " + std::to_string(rc); st = LBFT_ERR_HIP; break; }
+    if (hipMemcpyAsync(all.data(), d + kCounterWords, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream) != hipSuccess) { st = LBFT_ERR_HIP; break; }
+    if (hipStreamSynchronize(b->stream) != hipSuccess) { st = LBFT_ERR_HIP; break; }
+  } while (0);
+  if (d_big) hipFree(d_big);
+  if (st != LBFT_OK) { if (st == LBFT_ERR_HIP && g_err.empty()) g_err = "HIP error in lbft_batch_counters_allreduce"; return st; }
+  unsigned long long h[kCounterWords] = {0};
+  for (int r = 0; r < world; r++)
+    for (size_t k = 0; k < kCounterWords; k++) {
+      const unsigned long long v = all[(size_t)r * kCounterWords + k];
+      if (k < 11) h[k] += v; else h[k] = v > h[k] ? v : h[k];
+    }
   *out = c;
   out->events[0] = h[0]; out->events[1] = h[1]; out->events[2] = h[2]; out->events[3] = h[3];
   out->rng_draws = h[4]; out->rounds = h[5]; out->commits = h[6]; out->events_scheduled = h[7]; out->faulted_instances = h[8];

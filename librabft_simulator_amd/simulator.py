@@ -311,11 +311,19 @@ class BatchSimulator:
         rc = check(_lib.lib().lbft_batch_run_until(self._h, int(max_clock)), allow_fault=allow_faults or auto)
         if auto and rc == _lib.LBFT_ERR_FAULT:
             if round_trace < worst and (BatchResult(self).faults & _lib.LBFT_FAULT_TRACE_OVERFLOW).any():
+                import warnings
+                warnings.warn("loop_until(csv_path=...): a node passed the automatic round-trace capacity (%d rounds); the whole batch is run "
+                              "AGAIN with the worst case (%d rounds per node = %d trace words per instance, every instance of the batch). "
+                              "Pass round_trace=N to choose the capacity yourself." % (round_trace, worst, self.num_nodes * (worst + 1)))
                 self.reset()
                 check(_lib.lib().lbft_batch_enable_round_trace(self._h, worst))
                 rc = check(_lib.lib().lbft_batch_run_until(self._h, int(max_clock)), allow_fault=True)
             if rc == _lib.LBFT_ERR_FAULT and not allow_faults:
-                check(rc)
+                # (the text comes from the instances' fault words, not from lbft_last_error: that may be another call's)
+                f = BatchResult(self).faults
+                bits = int(np.bitwise_or.reduce(f)) if len(f) else 0
+                names = [n for b, n in sorted(_lib.FAULT_NAMES.items()) if bits & b] or ["fault bits 0x%x" % bits]
+                raise LbftError(rc, "%d instance(s) faulted: %s" % (int((f != 0).sum()), ", ".join(names)))
         res = BatchResult(self)
         if csv_path is not None:
             write_data_files(csv_path, *res.round_switches(0), self.num_nodes)

@@ -17,7 +17,7 @@ import json, sys
 for line in open(sys.argv[1] + "/baseline_configs.jsonl"):
     d = json.loads(line)
     print(d["config"], "ms", round(d["kernel_ms"], 2), "ev/s %.3g" % d["events_per_s"], "faulted", d["faulted_instances"], d["liveness"], "frac", round(d["roofline"]["frac"], 4),
-          "frac_exec", round(d["roofline"]["executed"]["frac"], 4), d["roofline"]["kernel"], "GB", round(d["device_gb"], 1))
+          "frac_ref_equiv", round(d["roofline"]["frac_reference_equivalent"], 4), d["roofline"]["kernel"], "GB", round(d["device_gb"], 1))
 PY
 pass() { cfg=$1; name=$2; shift 2; timeout 600 rocprofv3 --kernel-trace --pmc "$@" -d $OUT/$cfg.$name -o pmc --output-format csv -- python tools/configs.py $cfg > $OUT/$cfg.$name.log 2>&1 || tail -3 $OUT/$cfg.$name.log; }
 for cfg in $PROF_CONFIGS; do
@@ -37,5 +37,5 @@ python - "$OUT" <<'PY'
 import json, sys
 for line in open(sys.argv[1] + "/baseline_configs_with_traffic.jsonl"):
     d = json.loads(line); r = d["roofline"]
-    print(d["config"], "ms", round(d["kernel_ms"], 2), "frac", round(r["frac"], 4), "exec", round(r["executed"]["frac"], 4), "traffic GB", r["traffic"], "t/alg", r.get("traffic_over_algorithmic"), "t/exec", r.get("traffic_over_executed"))
+    print(d["config"], "ms", round(d["kernel_ms"], 2), "frac", round(r["frac"], 4), "ref_equiv", round(r["frac_reference_equivalent"], 4), "traffic GB", r["traffic"], "t/ref", r.get("traffic_over_reference_equivalent"), "t/exec", r.get("traffic_over_executed"))
 PY

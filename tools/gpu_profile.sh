@@ -31,6 +31,11 @@ p = json.load(open(out + "/pmc_lbft_k_run.json"))
 json.dump({"FETCH_SIZE": p.get("FETCH_SIZE"), "WRITE_SIZE": p.get("WRITE_SIZE"), "unit": "KB per launch of the run kernel (rocprofv3 --pmc, separate passes)",
            "profile": "profiles/%s/pmc_lbft_k_run.json" % tag, "workload": "bench.py default: 65536 x 4 nodes, max_clock 1000",
            "source_hash": source_hash()}, open(out + "/pmc_traffic.json", "w"), indent=1)
+# roofline.issue for bench.py: the SQ passes, stamped the same way (copy to profiles/current/)
+keys = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAVES", "GRBM_GUI_ACTIVE")
+json.dump(dict({k: p.get(k) for k in keys}, unit="per launch of the run kernel (rocprofv3 --pmc, separate passes)",
+               profile="profiles/%s/pmc_lbft_k_run.json" % tag, workload="bench.py default: 65536 x 4 nodes, max_clock 1000", source_hash=source_hash()),
+          open(out + "/pmc_issue.json", "w"), indent=1)
 PY
 rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/tcc $OUT/sq1 $OUT/sq2 $OUT/sq3 $OUT/grbm $OUT/ifetch
 cat $OUT/kernel_stats.csv | head -4; cat $OUT/pmc_lbft_k_run.json | head -40; tail -1 $OUT/bench_line.json | cut -c1-600
