@@ -171,11 +171,18 @@ def test_bench_two_ranks_on_one_device():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--backend", "gloo", "--single-device", "--instances", "4096",
            "--no-cpu-baseline"]
+    # first WITHOUT an external launcher (`python bench.py --gpus 2 ...`: bench.py starts its own two ranks), then under the driver's launcher
+    env_bare = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    bare = subprocess.run([sys.executable] + cmd[cmd.index(os.path.join(root, "bench.py")):], env=env_bare, capture_output=True, text=True, timeout=600, cwd=root)
+    assert bare.returncode == 0, bare.stderr[-2000:]
+    db = json.loads([l for l in bare.stdout.splitlines() if l.startswith("{")][-1])
+    assert db["n_gpus"] == 2 and db["scaling"] == "weak" and db["faulted_instances"] == 0 and db["parity"]["mismatches"] == 0
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["faulted_instances"] == 0
+    assert round(d["value"] * d["ms_per_step"]) == round(db["value"] * db["ms_per_step"])
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--instances", "8192", "--no-cpu-baseline"],
                          env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
@@ -211,12 +218,14 @@ def test_bench_two_ranks_nccl():
         port = sk.getsockname()[1]
     for extra, scaling in ((["--instances", "4096"], "weak"), (["--total-instances", "8192"], "strong")):
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra
+               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--native-collective"] + extra
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
         assert out.returncode == 0, out.stderr[-2000:]
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
         assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["faulted_instances"] == 0 and d["parity"]["mismatches"] == 0
         assert d["config"]["total_instances"] == 8192
+        # the C ABI's own collective on two ranks (ncclCommInitRank + lbft_batch_counters_allreduce) == the torch.distributed aggregate
+        assert d["native_collective"]["ranks"] == 2 and d["native_collective"]["matches_torch_aggregate"]
 
 
 def test_multi_launch_equals_single_launch(amd, oracle):
