@@ -117,6 +117,8 @@ extern "C" {
     fn lbft_batch_create(cfg: *const LbftConfig, seeds: *const u64, n: usize, device: c_int, out: *mut *mut c_void) -> c_int;
     fn lbft_batch_run_until(b: *mut c_void, max_clock: i64) -> c_int;
     fn lbft_batch_save_node(b: *const c_void, inst: usize, node: u32, buf: *mut c_void, cap: usize, len: *mut usize) -> c_int;
+    /// node.rs:211-231 on the device: the bincode NodeState image into the GPU-resident node (guard "state from the future" included)
+    fn lbft_batch_load_node(b: *mut c_void, inst: usize, node: u32, image: *const c_void, len: usize, node_time: i64) -> c_int;
     /// many trait calls (each on another instance) in one launch + one synchronisation: see include/lbft.h `lbft_node_calls`
     pub fn lbft_node_calls(b: *mut c_void, calls: *const LbftNodeCall, n: usize, results: *mut LbftNodeResult) -> c_int;
     /// the run's one collective, natively: ONE ncclAllGather of the 14 counter words per rank on the caller's ncclComm_t, reduced locally
@@ -313,9 +315,12 @@ impl GpuNode {
 }
 
 impl ConsensusNode<SimulatedContext> for GpuNode {
-    /// node.rs:211-231: the reference deserialises the bincode image `save_node` stored and refuses "to restore saved
-    /// state from the future".  The state itself lives in HBM for the lifetime of the batch; what is stored in the
-    /// context is the NodeTime of the last save, so the same guard applies.
+    /// node.rs:211-231: `bincode::deserialize(read_value("node_state"))` + the guard "refusing to restore saved state from the
+    /// future".  The image the context holds under the reference's key -- written by `save_node` below, or by a reference
+    /// `NodeState` of the same run -- is loaded INTO the GPU-resident node (`lbft_batch_load_node`: records are found by their
+    /// hashes in the instance's block pool, the guard runs in the library against `clock`); without an image the node attaches
+    /// to the state resident in HBM (a fresh batch: `NodeState::make_initial_state`), exactly as the reference's simulator falls
+    /// back to `make_initial_state` when `load_node` finds no value (simulator.rs:221).
     fn load_node(context: &mut SimulatedContext, clock: NodeTime) -> AsyncResult<Self> {
         let attached = ATTACH.with(|a| a.borrow().clone());
         let author = context.author();
@@ -325,6 +330,13 @@ impl ConsensusNode<SimulatedContext> for GpuNode {
                 None => bail!("attach_loads_to(batch, instance) first"),
             };
             let mut node = batch.node(inst, author);
+            if let Some(image) = context.read_value(NODE_IMAGE_KEY.to_string()).await? {
+                ensure!(!image.is_empty(), "the last save_node of this node failed: no image to restore");
+                let rc = unsafe {
+                    lbft_batch_load_node(batch.batch.handle, inst, author.0 as u32, image.as_ptr() as *const c_void, image.len(), clock.0)
+                };
+                check(rc)?;  // LBFT_ERR_STATE = "refusing to restore saved state from the future" (lbft_last_error has the text)
+            }
             if let Some(bytes) = context.read_value(SAVE_KEY.to_string()).await? {
                 ensure!(bytes.len() == 8, "corrupt save marker");
                 let mut b = [0u8; 8];

@@ -171,6 +171,19 @@ int lbft_batch_last_committed_states(const lbft_batch* b, uint64_t* out);
  * (past_record_stores, node.rs:43,338-340): the device keeps them in full only when lbft_batch_keep_retired_stores(b, 1) was called
  * before the run; otherwise such a node is LBFT_ERR_UNSUPPORTED (nodes still in epoch 0 always work). */
 int lbft_batch_save_node(const lbft_batch* b, size_t inst, uint32_t node, void* buf, size_t cap, size_t* len);
+/* ConsensusNode::load_node (librabft-v2/src/node.rs:211-231): bincode::deserialize::<NodeState>(image) into the device-resident node
+ * (inst, node) -- the inverse of lbft_batch_save_node, any HashMap order accepted.  `node_time` is the reference's guard
+ * (node.rs:219-228): an image whose latest_query_all_time / tracker.latest_commit_time / pacemaker.active_round_start_time lies after it
+ * is refused with LBFT_ERR_STATE ("refusing to restore saved state from the future") and nothing is written.  Records are identified
+ * by their hashes among the records of the instance's block pool: an image saved from this instance (any node, now or earlier), from
+ * another batch run with the same seed and configuration, or by the reference / the oracle for the same run loads; an image that names
+ * a record the pool does not hold is LBFT_ERR_UNSUPPORTED, one saved under another configuration (nodes, voting rights, NodeConfig) or
+ * malformed is LBFT_ERR_INVALID -- in every failing case the node is left untouched.  Written: the NodeState (record store with the
+ * node's blocks / certificates / timeouts / votes / election, pacemaker, epoch, voting constraints, commit tracker, retired record
+ * stores).  Not written: what the reference keeps outside NodeState -- the simulator's timer bookkeeping and startup time
+ * (SimulatedNode, bft-lib/src/simulator.rs:53-59) and the SmrContext (ledger and pending states, simulated_context.rs:75-83), which its
+ * load_node receives separately.  Call after a run, in a node-level session, or between bounded launches (lbft_batch_run_steps). */
+int lbft_batch_load_node(lbft_batch* b, size_t inst, uint32_t node, const void* image, size_t len, int64_t node_time);
 /* Multi-GPU: instances shard over the GPUs with no data-path collective; the run's ONE collective aggregates the
  * throughput counters of all ranks: ONE RCCL ncclAllGather over xGMI of the fourteen counter words of lbft_batch_counters per rank,
  * reduced locally (the eleven additive counters summed, the three high-water marks by maximum: two reduction operators, which one

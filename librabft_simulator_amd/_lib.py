@@ -117,7 +117,7 @@ RECORD_HASH_DTYPE = np.dtype([("block_hash", "<u8"), ("state", "<u8"), ("qc_hash
 ABI_SYMBOLS = [
     "lbft_batch_create", "lbft_batch_run_until", "lbft_batch_reset", "lbft_batch_commit_counts",
     "lbft_batch_active_rounds", "lbft_batch_committed_history", "lbft_batch_committed_histories", "lbft_batch_committed_record_hashes",
-    "lbft_batch_last_committed_states", "lbft_batch_last_committed_state", "lbft_batch_save_node", "lbft_batch_startup_times", "lbft_batch_epochs", "lbft_batch_counters",
+    "lbft_batch_last_committed_states", "lbft_batch_last_committed_state", "lbft_batch_save_node", "lbft_batch_load_node", "lbft_batch_startup_times", "lbft_batch_epochs", "lbft_batch_counters",
     "lbft_batch_faults", "lbft_batch_destroy", "lbft_batch_stream", "lbft_batch_last_run_ms",
     "lbft_batch_device_bytes", "lbft_batch_set_max_steps", "lbft_batch_set_lanes_per_wavefront",
     "lbft_batch_set_lds_queue_slots", "lbft_batch_set_calendar_queue", "lbft_batch_phase_cycles", "lbft_batch_layout",
@@ -219,6 +219,8 @@ def lib():
     L.lbft_batch_last_committed_state.restype = C.c_int
     L.lbft_batch_save_node.argtypes = [vp, C.c_size_t, C.c_uint32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.lbft_batch_save_node.restype = C.c_int
+    L.lbft_batch_load_node.argtypes = [vp, C.c_size_t, C.c_uint32, vp, C.c_size_t, C.c_int64]
+    L.lbft_batch_load_node.restype = C.c_int
     L.lbft_batch_counters.argtypes = [vp, C.POINTER(LbftCounters)]
     L.lbft_batch_counters.restype = C.c_int
     L.lbft_batch_destroy.argtypes = [vp]

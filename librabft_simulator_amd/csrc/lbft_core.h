@@ -71,6 +71,11 @@ typedef int64_t i64;
 #ifndef LBFT_BLK_CACHE_LEAN2
 #define LBFT_BLK_CACHE_LEAN2 1
 #endif
+#ifndef LBFT_BLK_CACHE_LEAN5
+#define LBFT_BLK_CACHE_LEAN5 3  // lbft_k_run2l (SimT<5>): three records fit since the scalar / record accesses stopped holding a register per field
+                                // (round 4: 22 spilled registers; c4 354.6 -> 351.6 ms, c5 1.931 -> 1.897 s; two records 386 ms / 2.12 s; the kernel with
+                                // the record exchange, SimT<7>, loses with two: 3.03 against 2.82 s)
+#endif
 // Kernel class 0 (the headline small-network path): instance-major rows (tile width 1) instead of 64-instance word-interleaved tiles.
 // The lanes of a class-0 wavefront work on different nodes, snapshot slots and blocks of their instances, i.e. on different ROWS: in a
 // word-interleaved tile every such word access touches one 128-byte line per distinct row (a 41-word node burst: 4 lines per word, a
@@ -122,6 +127,12 @@ typedef int64_t i64;
 // iteration for lanes whose list starts behind a sync request); a snapshot that ends up with no reference is freed as before.
 #ifndef LBFT_C0_SNAP_HOIST
 #define LBFT_C0_SNAP_HOIST 0
+#endif
+#ifndef LBFT_C0_NO_TRACE_STATE
+#define LBFT_C0_NO_TRACE_STATE 1  // (class 0 never traces) the round trace's bookkeeping -- last_node, vd_time / vd_stamp -- is not maintained in class 0
+#endif
+#ifndef LBFT_QUAD_LDS_ROUND_TABLES
+#define LBFT_QUAD_LDS_ROUND_TABLES 1  // (with the line above: 65 536 x 4 16.43 -> 16.26 ms) lbft_k_run0q: leader / duration lookups that the LDS tables cover are plain LDS reads (not a load through a selected pointer)
 #endif
 #ifndef LBFT_POPC_MAX_LPW
 #define LBFT_POPC_MAX_LPW 8u  // networks per wavefront up to which lbft_k_run0s is used (measured: 1 024 x 4: 6.3 against 7.5 ms, 8 192: 10.9 against 12.1,
@@ -342,6 +353,11 @@ enum BlockField : u32 {
   B_VOTERS,  // authors 0..31 whose votes the block's QuorumCertificate contains (written once, by the author, when it forms the QC)
   B_WORDS
 };
+#ifndef LBFT_BLK_PLAIN_FIFO
+#define LBFT_BLK_PLAIN_FIFO 1  // plain round-robin replacement of the cached block records (no "recently used" bits, no aging pass per insertion):
+                               // round 4, 65 536 x 4: 17.63 -> 17.05 ms -- the second-chance bookkeeping (a bit set per hit, three test-and-advance
+                               // steps per insertion, inlined at 22 lookup sites: 480 of the kernel's 6.8 k instructions) cost more than the few misses it saved
+#endif
 #ifndef LBFT_BLK_CACHE
 #define LBFT_BLK_CACHE 3  // register-resident block records per instance (second-chance FIFO); measured: 2 -> 29.2 ms, 3 -> 27.9, 4 -> 28.0 (19 spilled registers), 5 -> 29.8
 #endif
@@ -930,8 +946,12 @@ struct SimT {
       }
   }
   LBFT_HD u32 bfw(u32 b, u32 f) const { return OFFBLK() + (b - 1) * BWORDS() + f; }
-  LBFT_HD u32 bf(u32 b, u32 f) const { return ld(bfw(b, f)); }   // cold fields (B_TIME, B_CMD) and read-back
-  LBFT_HD void bfs(u32 b, u32 f, u32 v) const { st(bfw(b, f), v); }
+  // (through the record's base + a field offset, NOT ld(bfw(b, f)): with instance-major rows `(first word + f) * 4 + lane offset` is
+  // reassociated by the compiler into `first word * 4 + (f * 4 + lane offset)` and the bracket hoisted out of the event loop -- one
+  // VGPR per distinct field for the whole launch (17 of them in lbft_k_run0q) and an add per access; with the base zero-extended first
+  // the field offset becomes the instruction's immediate and consecutive fields merge into wide accesses)
+  LBFT_HD u32 bf(u32 b, u32 f) const { return ldf(boff(bfw(b, 0)), f); }   // cold fields (B_TIME, B_CMD) and read-back
+  LBFT_HD void bfs(u32 b, u32 f, u32 v) const { stf(boff(bfw(b, 0)), f, v); }
   LBFT_HD u32 blk_author(u32 b) const { return bf(b, B_LINK) >> 16; }
 
   // ---- block records: a FIFO of LBFT_BLK_CACHE hot records in registers.  Only this lane ever touches its
@@ -955,7 +975,7 @@ struct SimT {
     LBFT_HD u32 epoch() const { return w[B_EPOCH]; }
     LBFT_HD u32 depth() const { return w[B_DEPTH]; }
   };
-  static constexpr u32 BCN = LEAN2 ? LBFT_BLK_CACHE_LEAN2 : LBFT_BLK_CACHE;
+  static constexpr u32 BCN = CLS == 5 ? LBFT_BLK_CACHE_LEAN5 : LEAN2 ? LBFT_BLK_CACHE_LEAN2 : LBFT_BLK_CACHE;
   mutable u32 bc_id[BCN];
   mutable u32 bc_w[BCN][BC_WORDS];
   mutable u32 bc_next, bc_ref;  // FIFO hand + "recently used" bits (second chance: a hot old block survives)
@@ -967,7 +987,7 @@ struct SimT {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (u32 t = 0; t < BCN; t++) {  // skip (and age) entries used since the hand last passed
+    for (u32 t = 0; t < (LBFT_BLK_PLAIN_FIFO ? 0u : BCN); t++) {  // skip (and age) entries used since the hand last passed
       if ((bc_ref >> bc_next) & 1u) {
         bc_ref &= ~(1u << bc_next);
         bc_next = bc_next + 1 == BCN ? 0 : bc_next + 1;
@@ -994,22 +1014,26 @@ struct SimT {
     Blk r;
     bool hit = false;
     r.xk = 0; r.x[0] = r.x[1] = r.x[2] = 0;  // (node-set extension words: fetched by the first bm_* operation that needs them)
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = 0;
+    // one select per further entry (the value of a miss is overwritten by the loads below): r = entry 0, then entry e where it is the hit
+    bool he[BCN];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (u32 e = 0; e < BCN; e++) {
-      if (bc_id[e] == b) {
-        hit = true;
-        bc_ref |= 1u << e;
+      he[e] = bc_id[e] == b;
+      hit = hit || he[e];
+      if (!LBFT_BLK_PLAIN_FIFO && he[e]) bc_ref |= 1u << e;
+    }
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-        for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = bc_w[e][f];
-      }
+    for (u32 f = 0; f < BC_WORDS; f++) {
+      u32 v = bc_w[0][f];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 e = 1; e < BCN; e++) v = he[e] ? bc_w[e][f] : v;
+      r.w[f] = v;
     }
     LBFT_COUNT(26);
     LBFT_STAT(44);
@@ -1063,7 +1087,7 @@ struct SimT {
   }
   // Write-through update of one mask word of block b (f is B_KNOWN, B_QC or B_PEND).
   LBFT_HD void blk_put(u32 b, u32 f, u32 v) const {
-    st(bfw(b, f), v);
+    bfs(b, f, v);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -1078,42 +1102,46 @@ struct SimT {
   // extension word k >= 1 of a snapshot's TC (which = 0) / current-timeout (which = 1) author set
   LBFT_HD u32 sxw(u32 slot, u32 which, u32 k) const { return sfw(slot, S_FIXED_WORDS + 2 * NN() + which * (MW() - 1) + k - 1); }
 
+  // instance scalars: row `f` of the instance through its first row + an immediate (see bf(): a plain ld(I_X) costs a VGPR per scalar
+  // that stays live from the loads at the start of a launch to the stores at its end)
+  LBFT_HD u32 ldi(u32 f) const { return ldf(boff(0), f); }
+  LBFT_HD void sti(u32 f, u32 v) const { stf(boff(0), f, v); }
   LBFT_HD void load_scalars() {
-    clock = (i32)ld(I_CLOCK); stamp = ld(I_STAMP);
-    rng.s0 = ld(I_RNG0) | ((u64)ld(I_RNG1) << 32); rng.s1 = ld(I_RNG2) | ((u64)ld(I_RNG3) << 32);
-    rng.s2 = ld(I_RNG4) | ((u64)ld(I_RNG5) << 32); rng.s3 = ld(I_RNG6) | ((u64)ld(I_RNG7) << 32);
-    rng.draws = ld(I_DRAWS);
-    qlen = ld(I_QLEN); snap_free = ld(I_SNAP_FREE); nblocks = ld(I_NBLOCKS); fault = ld(I_FAULT);
-    ev0 = ld(I_EV0); ev1 = ld(I_EV1); ev2 = ld(I_EV2); ev3 = ld(I_EV3);
-    maxq = ld(I_MAXQ); maxsnap = ld(I_MAXSNAP);
+    clock = (i32)ldi(I_CLOCK); stamp = ldi(I_STAMP);
+    rng.s0 = ldi(I_RNG0) | ((u64)ldi(I_RNG1) << 32); rng.s1 = ldi(I_RNG2) | ((u64)ldi(I_RNG3) << 32);
+    rng.s2 = ldi(I_RNG4) | ((u64)ldi(I_RNG5) << 32); rng.s3 = ldi(I_RNG6) | ((u64)ldi(I_RNG7) << 32);
+    rng.draws = ldi(I_DRAWS);
+    qlen = ldi(I_QLEN); snap_free = ldi(I_SNAP_FREE); nblocks = ldi(I_NBLOCKS); fault = ldi(I_FAULT);
+    ev0 = ldi(I_EV0); ev1 = ldi(I_EV1); ev2 = ldi(I_EV2); ev3 = ldi(I_EV3);
+    maxq = ldi(I_MAXQ); maxsnap = ldi(I_MAXSNAP);
     if (!LEAN2) {  // (state the two-wavefront large-network kernels never touch stays in its rows)
-      snap_mask = ld(I_SNAP_MASK_LO) | ((u64)ld(I_SNAP_MASK_HI) << 32);
-      last_node = ld(I_LAST_NODE); vd_time = ld(I_VD_TIME); vd_stamp = ld(I_VD_STAMP);
+      snap_mask = ldi(I_SNAP_MASK_LO) | ((u64)ldi(I_SNAP_MASK_HI) << 32);
+      last_node = ldi(I_LAST_NODE); vd_time = ldi(I_VD_TIME); vd_stamp = ldi(I_VD_STAMP);
     } else { snap_mask = 0; last_node = 0; vd_time = 0xffffffffu; vd_stamp = 0; }
-    cal_cursor = ld(I_CAL_CURSOR); cal_free = ld(I_CAL_FREE); cal_bump = ld(I_CAL_BUMP);
-    n_fold = ld(I_NFOLD); n_upd = ld(I_NUPD);
-    cont = ld(I_CONT);
+    cal_cursor = ldi(I_CAL_CURSOR); cal_free = ldi(I_CAL_FREE); cal_bump = ldi(I_CAL_BUMP);
+    n_fold = ldi(I_NFOLD); n_upd = ldi(I_NUPD);
+    cont = ldi(I_CONT);
     sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0;
-    if (RING) { rng.rhead = ld(I_RING_HEAD); rng.rcnt = ld(I_RING_CNT); }
+    if (RING) { rng.rhead = ldi(I_RING_HEAD); rng.rcnt = ldi(I_RING_CNT); }
     blk_cache_reset();
   }
   LBFT_HD void store_scalars(bool done) {
-    st(I_CLOCK, (u32)clock); st(I_STAMP, stamp);
-    st(I_RNG0, (u32)rng.s0); st(I_RNG1, (u32)(rng.s0 >> 32)); st(I_RNG2, (u32)rng.s1); st(I_RNG3, (u32)(rng.s1 >> 32));
-    st(I_RNG4, (u32)rng.s2); st(I_RNG5, (u32)(rng.s2 >> 32)); st(I_RNG6, (u32)rng.s3); st(I_RNG7, (u32)(rng.s3 >> 32));
-    st(I_DRAWS, rng.draws);
-    st(I_QLEN, qlen); st(I_SNAP_FREE, snap_free); st(I_NBLOCKS, nblocks); st(I_FAULT, fault);
-    st(I_EV0, ev0); st(I_EV1, ev1); st(I_EV2, ev2); st(I_EV3, ev3);
-    st(I_MAXQ, maxq); st(I_MAXSNAP, maxsnap);
+    sti(I_CLOCK, (u32)clock); sti(I_STAMP, stamp);
+    sti(I_RNG0, (u32)rng.s0); sti(I_RNG1, (u32)(rng.s0 >> 32)); sti(I_RNG2, (u32)rng.s1); sti(I_RNG3, (u32)(rng.s1 >> 32));
+    sti(I_RNG4, (u32)rng.s2); sti(I_RNG5, (u32)(rng.s2 >> 32)); sti(I_RNG6, (u32)rng.s3); sti(I_RNG7, (u32)(rng.s3 >> 32));
+    sti(I_DRAWS, rng.draws);
+    sti(I_QLEN, qlen); sti(I_SNAP_FREE, snap_free); sti(I_NBLOCKS, nblocks); sti(I_FAULT, fault);
+    sti(I_EV0, ev0); sti(I_EV1, ev1); sti(I_EV2, ev2); sti(I_EV3, ev3);
+    sti(I_MAXQ, maxq); sti(I_MAXSNAP, maxsnap);
     if (!LEAN2) {
-      st(I_SNAP_MASK_LO, (u32)snap_mask); st(I_SNAP_MASK_HI, (u32)(snap_mask >> 32));
-      st(I_LAST_NODE, last_node); st(I_VD_TIME, vd_time); st(I_VD_STAMP, vd_stamp);
+      sti(I_SNAP_MASK_LO, (u32)snap_mask); sti(I_SNAP_MASK_HI, (u32)(snap_mask >> 32));
+      sti(I_LAST_NODE, last_node); sti(I_VD_TIME, vd_time); sti(I_VD_STAMP, vd_stamp);
     }
-    st(I_CAL_CURSOR, cal_cursor); st(I_CAL_FREE, cal_free); st(I_CAL_BUMP, cal_bump);
-    st(I_NFOLD, n_fold); st(I_NUPD, n_upd);
-    if (q1()) st(I_CONT, cont);
-    if (RING) { st(I_RING_HEAD, rng.rhead); st(I_RING_CNT, rng.rcnt); }
-    st(I_DONE, done ? 1u : 0u);
+    sti(I_CAL_CURSOR, cal_cursor); sti(I_CAL_FREE, cal_free); sti(I_CAL_BUMP, cal_bump);
+    sti(I_NFOLD, n_fold); sti(I_NUPD, n_upd);
+    if (q1()) sti(I_CONT, cont);
+    if (RING) { sti(I_RING_HEAD, rng.rhead); sti(I_RING_CNT, rng.rcnt); }
+    sti(I_DONE, done ? 1u : 0u);
   }
 
   // ---- network delay (simulator.rs:110-118; rand_distr 0.4 LogNormal / StandardNormal ziggurat) ----
@@ -1560,6 +1588,11 @@ struct SimT {
     // when the two pointer members happen to sit at the same offset of their structs, the optimiser merges the two
     // branches into one load through a phi of `this` and `&P`, after which neither struct is promoted to registers any
     // more (the whole simulator state silently moves to scratch memory; tests/test_abi.py guards the symptom).
+    if (QUAD && LBFT_QUAD_LDS_ROUND_TABLES) {  // (no rotation: shift == 0; a 4-node run to clock 1000 stays far below the table's 1 024 rounds)
+      if (LBFT_LIKELY(round < leader_lds_len)) return leader_lds[round];
+      if (round < P.leader_len) return P.leader_tab[round];
+      return compute_leader(P.weights, NN(), P.total_votes, round, shift);
+    }
     if (LBFT_LIKELY(round < P.leader_len)) {
       const u8* tab = (round < leader_lds_len && shift == 0) ? leader_lds : P.leader_tab + (size_t)shift * P.leader_len;
       return tab[round];
@@ -1865,7 +1898,7 @@ struct SimT {
     bool first = nf(node, NF_BAL0_BLK) == b;  // (field indices stay compile-time constants: the node cache lives in registers)
     for (u32 k = 0; k < MW(); k++) {
       u32 v = first ? am_word(node, NF_BAL0_AUTHORS, k) : am_word(node, NF_BAL1_AUTHORS, k);
-      st(k == 0 ? bfw(b, B_VOTERS) : bfw(b, B_WORDS + 3 * (MW() - 1) + k - 1), v);
+      bfs(b, k == 0 ? (u32)B_VOTERS : B_WORDS + 3 * (MW() - 1) + k - 1, v);
     }
     insert_qc(node, b, rb);
     return true;
@@ -1880,6 +1913,10 @@ struct SimT {
     if (LBFT_UNLIKELY(round <= hccr)) { fault |= F_INTERNAL; return 0; }
     u32 k = round - hccr;
     if (LBFT_UNLIKELY(k >= P.dur_len)) { fault |= F_DURATION_TABLE; k = P.dur_len - 1; }
+    if (QUAD && LBFT_QUAD_LDS_ROUND_TABLES) {
+      if (LBFT_LIKELY(k < dur_lds_len)) return dur_lds[k];
+      return P.dur_tab[k];
+    }
     const i64* tab = k < dur_lds_len ? dur_lds : P.dur_tab;  // (a selected pointer: see leader())
     return tab[k];
   }
@@ -2313,13 +2350,14 @@ struct SimT {
   // `twin`: (E2) the copy for even-indexed receivers of an equivocator's notification carries the twin proposal
   // `skip_hcbr`: the caller copies the timeouts' highest_certified_block_round words itself (coop_bulk: all lanes at once)
   LBFT_HD void write_snapshot(u32 node, u32 slot, bool twin = false, bool skip_hcbr = false) const {
-    st(sfw(slot, S_EPOCH), nf(node, NF_EPOCH));
+    const u32 sb0 = boff(sfw(slot, 0));  // (record base + immediate field offsets: see bf())
+    stf(sb0, S_EPOCH, nf(node, NF_EPOCH));
     // highest_commit_certificate (data_sync.rs:84-92): the current store's, else the previous epoch's store's.
     // Reference quirk Q2: EpochId::previous() returns the SAME epoch (base_types.rs:31-37), so that lookup finds
     // the current store again and yields None; quirks bit 1 makes it id - 1 as intended.
     u32 hcc = nf(node, NF_HCC_BLK);
     if (!hcc && (P.quirks & 2u) && nf(node, NF_EPOCH) != 0) hcc = nf(node, NF_PREV_EPOCH_HCC);
-    st(sfw(slot, S_CERTS), hcc | (nf(node, NF_HQC_BLK) << 16));
+    stf(sb0, S_CERTS, hcc | (nf(node, NF_HQC_BLK) << 16));
     u32 pb = proposed_block(node);
     // "Do not reshare other leaders' proposals."  current_proposed_block is only ever set to a block authored by the
     // leader of its round (record_store.rs:469), and proposed_block() answers for the pacemaker's round: the author is
@@ -2329,26 +2367,25 @@ struct SimT {
     u32 vote = 0;  // current_vote(local author) (record_store.rs:762-764)
     if (am_test(node, NF_BAL0_AUTHORS, node)) vote = nf(node, NF_BAL0_BLK);
     else if (am_test(node, NF_BAL1_AUTHORS, node)) vote = nf(node, NF_BAL1_BLK);
-    st(sfw(slot, S_PROP_VOTE), pb | (vote << 16));
+    stf(sb0, S_PROP_VOTE, pb | (vote << 16));
     u32 htc = nf(node, NF_HTC_ROUND);
     u32 tcm = htc ? nf(node, NF_TC_MASK) : 0;
     u32 tom = nf(node, NF_TO_MASK);
-    st(sfw(slot, S_TC_ROUND), htc);
-    st(sfw(slot, S_TO_ROUND), nf(node, NF_CUR_ROUND));
-    st(sfw(slot, S_TC_MASK), tcm);
-    st(sfw(slot, S_TO_MASK), tom);
+    stf(sb0, S_TC_ROUND, htc);
+    stf(sb0, S_TO_ROUND, nf(node, NF_CUR_ROUND));
+    stf(sb0, S_TC_MASK, tcm);
+    stf(sb0, S_TO_MASK, tom);
     u32 tc_sel = nf(node, NF_TC_SEL);
     if (hc_reg()) {
       // both buffers whole, no loop over the sets: a receiver only reads the words of authors in the sets
-      u32 sb = sfw(slot, S_FIXED_WORDS);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (u32 a = 0; a < 4; a++) if (a < NN()) st(sb + a, tc_sel ? hcw[4 + a] : hcw[a]);
+      for (u32 a = 0; a < 4; a++) if (a < NN()) stf(sb0, S_FIXED_WORDS + a, tc_sel ? hcw[4 + a] : hcw[a]);
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (u32 a = 0; a < 4; a++) if (a < NN()) st(sb + NN() + a, tc_sel ? hcw[a] : hcw[4 + a]);
+      for (u32 a = 0; a < 4; a++) if (a < NN()) stf(sb0, S_FIXED_WORDS + NN() + a, tc_sel ? hcw[a] : hcw[4 + a]);
     } else
     if (!skip_hcbr) {
       copy_hcbr(node, slot, tcm, 0, tc_sel, S_FIXED_WORDS);
@@ -3126,7 +3163,7 @@ struct SimT {
       i32 t_event = t;
       if (t > clock) clock = t;
       u32 node = meta & 0xffu, sender = (meta >> 8) & 0xffu, slot = meta >> 16;
-      if (!LEAN) last_node = node;
+      if (!LEAN && !(C0 && LBFT_C0_NO_TRACE_STATE)) last_node = node;
       // One shared site for the node-row burst (and, for a notification, its snapshot words in the same
       // burst), one for update_node + process_node_actions: lanes of a wavefront that handle different
       // event kinds issue their loads together instead of one serialized round trip per kind.
@@ -3147,7 +3184,7 @@ struct SimT {
         LBFT_STAT(0);
         ev3 += 1 + slot;  // slot > 0: a materialised group of folded duplicates (see process_node_actions)
         if ((u32)clock == nf(node, NF_LAST_TIMER_T)) {  // folded duplicates of this timer
-          if (!LEAN && nf(node, NF_TIMER_DUPS) != 0) {  // their pops follow, interleaved by stamp with the other timers of this time (round trace only)
+          if (!LEAN && !(C0 && LBFT_C0_NO_TRACE_STATE) && nf(node, NF_TIMER_DUPS) != 0) {  // their pops follow, interleaved by stamp with the other timers of this time (round trace only)
             u32 ds = nf(node, NF_DUP_STAMP) + 1;
             vd_stamp = (vd_time == (u32)clock && vd_stamp > ds) ? vd_stamp : ds;
             vd_time = (u32)clock;

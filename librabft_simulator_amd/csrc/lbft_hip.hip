@@ -1512,7 +1512,7 @@ int lbft_batch_committed_record_hashes(const lbft_batch* b, size_t inst, uint32_
 // rows are copied to the host and serialised there -- a read-back format conversion like the history export, not simulation.
 int lbft_batch_save_node(const lbft_batch* b, size_t inst, uint32_t node, void* buf, size_t cap, size_t* len) {
   if (!b || !len || inst >= b->m || node >= b->p.n) return LBFT_ERR_INVALID;
-  if (!b->ran && !b->manual) { g_err = "run the batch (or start a node-level session) first"; return LBFT_ERR_STATE; }
+  if (!b->ran && !b->manual && !b->started) { g_err = "run the batch (or start a node-level session) first"; return LBFT_ERR_STATE; }
   HIP_TRY(hipSetDevice(b->device));
   const Params& dp = b->p;
   std::lock_guard<std::mutex> sn_lock(b->sn_mutex);  // (two threads saving different nodes of one batch share the one-image cache)
@@ -1535,6 +1535,32 @@ int lbft_batch_save_node(const lbft_batch* b, size_t inst, uint32_t node, void* 
   *len = image.size();
   if (buf && cap < image.size()) { g_err = "save_node: the buffer is smaller than the image (*len holds the size needed)"; return LBFT_ERR_INVALID; }
   if (buf) memcpy(buf, image.data(), image.size());
+  return LBFT_OK;
+}
+
+// ---- ConsensusNode::load_node (librabft-v2/src/node.rs:211-231): a bincode NodeState image into one device-resident node -------------
+// The inverse of lbft_batch_save_node (lbft_save_node.h load_node_image): the instance's rows are copied to the host, the image's
+// records are found by hash among the instance's block pool, the node's rows (record store, pacemaker, voting constraints, tracker,
+// retired stores) are rewritten and copied back.  Like save_node a read-back-sized format conversion, not simulation.
+int lbft_batch_load_node(lbft_batch* b, size_t inst, uint32_t node, const void* image, size_t len, int64_t node_time) {
+  if (!b || !image || inst >= b->m || node >= b->p.n) return LBFT_ERR_INVALID;
+  if (!b->ran && !b->manual && !b->started) { g_err = "run the batch (or start a node-level session) first"; return LBFT_ERR_STATE; }
+  HIP_TRY(hipSetDevice(b->device));
+  const Params& dp = b->p;
+  std::lock_guard<std::mutex> sn_lock(b->sn_mutex);
+  std::vector<u32> hw(dp.total_words);
+  u32* d_rows = b->d_state + word_offset(dp, (u32)inst, 0);
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  if (dp.tw == 1) HIP_TRY(hipMemcpy(hw.data(), d_rows, (size_t)4 * dp.total_words, hipMemcpyDeviceToHost));
+  else HIP_TRY(hipMemcpy2D(hw.data(), sizeof(u32), d_rows, (size_t)4 * dp.tw, sizeof(u32), dp.total_words, hipMemcpyDeviceToHost));
+  std::string err;
+  int rc = load_node_image(dp, hw.data(), node, b->weights.data(), b->cfg.delta, b->cfg.gamma, b->cfg.lambda, b->cfg.target_commit_interval,
+                           static_cast<const uint8_t*>(image), len, node_time, err);
+  if (rc != 0) { g_err = err; return rc == -4 ? LBFT_ERR_STATE : rc == -3 ? LBFT_ERR_UNSUPPORTED : LBFT_ERR_INVALID; }
+  if (dp.tw == 1) HIP_TRY(hipMemcpy(d_rows, hw.data(), (size_t)4 * dp.total_words, hipMemcpyHostToDevice));
+  else HIP_TRY(hipMemcpy2D(d_rows, (size_t)4 * dp.tw, hw.data(), sizeof(u32), sizeof(u32), dp.total_words, hipMemcpyHostToDevice));
+  b->generation++;  // (a cached save_node image of this batch is stale now)
+  b->sn_generation = ~0ull;
   return LBFT_OK;
 }
 

@@ -381,6 +381,13 @@ class BatchSimulator:
         check(_lib.lib().lbft_batch_save_node(self._h, int(instance), int(node), buf.ctypes.data, ln.value, C.byref(ln)))
         return buf.tobytes()
 
+    def load_node(self, instance, node, image, node_time):
+        """ConsensusNode::load_node (node.rs:211-231): the bincode NodeState ``image`` (bytes) into the device-resident node; raises
+        LbftError (LBFT_ERR_STATE) for "saved state from the future" (``node_time`` before the image's own times), LBFT_ERR_UNSUPPORTED
+        for an image naming records this instance's block pool does not hold.  The node is untouched when it raises."""
+        buf = np.frombuffer(bytes(image), dtype=np.uint8)
+        check(_lib.lib().lbft_batch_load_node(self._h, int(instance), int(node), buf.ctypes.data, len(buf), int(node_time)))
+
     def reset(self):
         check(_lib.lib().lbft_batch_reset(self._h))
 
@@ -474,6 +481,11 @@ class NodeHandle:
     def save_node(self):
         """ConsensusNode::save_node (node.rs:233-238) -> the bincode image of this node's NodeState."""
         return self._sim.save_node(self.instance, self.author)
+
+    def load_node(self, image, clock):
+        """ConsensusNode::load_node (node.rs:211-231): restore this node's NodeState from a save_node image; `clock` = the node's time
+        (the reference refuses "saved state from the future")."""
+        self._sim.load_node(self.instance, self.author, image, clock)
 
     def view(self):
         v = LbftNodeView()

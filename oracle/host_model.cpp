@@ -24,10 +24,14 @@ static const u64 ET[256] = LBFT_EXP_TAB_INIT;
 static uint8_t* g_image_buf = nullptr;
 static size_t g_image_stride = 0;
 static size_t* g_image_lens = nullptr;
+// ... and, when set, the result of a save -> scrub -> load -> save round trip of every node through lbft_save_node.h's loader
+// (load_node_image, what lbft_batch_load_node runs): 0 = the second image equals the first byte for byte, 1 = it differs, < 0 = the loader's code
+static int* g_roundtrip = nullptr;
 
 extern "C" {
 
 void lbft_hostmodel_capture_node_images(uint8_t* buf, size_t stride, size_t* lens) { g_image_buf = buf; g_image_stride = stride; g_image_lens = lens; }
+void lbft_hostmodel_roundtrip_node_images(int* results) { g_roundtrip = results; }
 
 typedef struct lbft_hostmodel_caps {
   uint32_t qcap, scap, bcap, lcap;
@@ -163,8 +167,55 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
       int irc = build_node_image(p, hw.data(), k, weights.data(), cfg->delta, cfg->gamma, cfg->lambda, cfg->target_commit_interval, image, err);
       g_image_lens[k] = irc == 0 ? image.size() : (size_t)-1;
       if (irc == 0 && image.size() <= g_image_stride) memcpy(g_image_buf + (size_t)k * g_image_stride, image.data(), image.size());
+      if (g_roundtrip && irc == 0) {
+        // scrub everything of node k that is NodeState (its rows but the simulator's / context's words, its bit in every block's KNOWN / QC
+        // set, its archive of retired stores), load the image, save again
+        std::vector<u32> h2(hw);
+        Params hp = p; hp.m = 1; hp.stride = 64; hp.tw = 1; hp.rsh = 2; hp.weights = weights.data();
+        Sim s2(hp, h2.data(), 0);
+        const u32 keep[] = {NF_STARTUP, NF_IGNORE_UNTIL, NF_LAST_TIMER_T, NF_TIMER_DUPS, NF_DUP_STAMP, NF_NEXT_CMD, NF_LAST_COMMITTED_BLK, NF_NCOMMITS};
+        for (u32 f = 0; f < hp.node_words; f++) {
+          bool kept = false;
+          for (u32 q : keep) kept |= q == f;
+          if (!kept) s2.nfms(k, f, 0xdeadbeefu);
+        }
+        for (u32 x = 1; x <= s2.ld(I_NBLOCKS); x++)
+          for (u32 f : {(u32)B_KNOWN, (u32)B_QC}) {
+            u32 w = k < 32 ? s2.bfw(x, f) : s2.bxw(x, f, k >> 5);
+            s2.st(w, s2.ld(w) ^ (1u << (k & 31u)));  // (flipped: a loader that leaves bits alone is caught either way)
+          }
+        for (u32 q = 0; q < hp.ecap * hp.rarch_words; q++) s2.st(hp.off_rarch + k * hp.ecap * hp.rarch_words + q, 0x5a5a5a5au);
+        // quirks bit 0: the snapshot-format summaries of the node's retired stores (what its peers' record exchange reads) -- zeroed here,
+        // compared with the original rows after the load
+        const u32 arch_words = (hp.quirks & 1u) ? s2.nfm(k, NF_EPOCH) * hp.snap_words : 0;
+        const u32 arch0 = hp.off_arch + k * hp.ecap * hp.snap_words;
+        const u32 my_epoch = hw[s2.nfw(k, NF_EPOCH)];
+        const u32 arch_n = (hp.quirks & 1u) ? (my_epoch < hp.ecap ? my_epoch : hp.ecap) * hp.snap_words : 0;
+        (void)arch_words;
+        for (u32 q = 0; q < arch_n; q++) s2.st(arch0 + q, 0);
+        std::string lerr;
+        int lrc = load_node_image(p, h2.data(), k, weights.data(), cfg->delta, cfg->gamma, cfg->lambda, cfg->target_commit_interval, image.data(), image.size(),
+                                  INT64_MAX, lerr);
+        if (lrc != 0) g_roundtrip[k] = lrc;
+        else {
+          std::vector<uint8_t> again;
+          int brc = build_node_image(p, h2.data(), k, weights.data(), cfg->delta, cfg->gamma, cfg->lambda, cfg->target_commit_interval, again, lerr);
+          g_roundtrip[k] = brc != 0 ? brc - 100 : (again == image ? 0 : 1);
+          for (u32 q = 0; q < arch_n && g_roundtrip[k] == 0; q++) {
+            // (the request words of a response slot -- sqw -- are not part of a store summary; a skipped epoch id has no entry)
+            u32 within = q % hp.snap_words;
+            if (within >= S_FIXED_WORDS + 2 * hp.n + 2 * (hp.mw - 1)) continue;
+            if (h2[arch0 + q] != hw[arch0 + q]) g_roundtrip[k] = 3;
+          }
+          // ... and the guard of node.rs:219-228: a node time before the image's own times is refused and nothing is written
+          std::vector<u32> h3(h2);
+          int grc = load_node_image(p, h3.data(), k, weights.data(), cfg->delta, cfg->gamma, cfg->lambda, cfg->target_commit_interval, image.data(), image.size(),
+                                    INT64_MIN + 1, lerr);
+          if (g_roundtrip[k] == 0 && (grc != -4 || h3 != h2)) g_roundtrip[k] = 2;
+        }
+      }
     }
-    g_image_buf = nullptr; g_image_lens = nullptr;
+    g_image_buf = nullptr; g_image_lens = nullptr; g_roundtrip = nullptr;
   }
   if (counters) memset(counters, 0, sizeof(*counters));
   int rc = 0;

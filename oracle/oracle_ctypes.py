@@ -388,10 +388,17 @@ def hostmodel_lib():
     return _hm
 
 
-def hostmodel_node_images(cfg, seed, max_clock, **caps):
+def hostmodel_node_images(cfg, seed, max_clock, roundtrip=None, **caps):
     """save_node images (bytes, or None when unsupported) of every node of ONE network run on the host model: the image builder of the
-    product library (csrc/lbft_save_node.h) applied to the host model's state rows."""
+    product library (csrc/lbft_save_node.h) applied to the host model's state rows.  `roundtrip`: a list that receives, per node, the
+    result of save -> scrub the node's NodeState -> load_node_image (the product library's loader) -> save: 0 = byte-identical."""
     L = hostmodel_lib()
+    rt = None
+    if roundtrip is not None:
+        rt = (C.c_int * cfg.num_nodes)(*([-999] * cfg.num_nodes))
+        L.lbft_hostmodel_roundtrip_node_images.argtypes = [C.c_void_p]
+        L.lbft_hostmodel_roundtrip_node_images.restype = None
+        L.lbft_hostmodel_roundtrip_node_images(C.addressof(rt))
     n, stride = cfg.num_nodes, 1 << 22
     buf = np.zeros(n * stride, dtype=np.uint8)
     lens = (C.c_size_t * n)()
@@ -404,6 +411,8 @@ def hostmodel_node_images(cfg, seed, max_clock, **caps):
     for k in range(n):
         ln = int(lens[k])
         out.append(None if ln == 2 ** 64 - 1 else buf[k * stride:k * stride + ln].tobytes())
+    if roundtrip is not None:
+        roundtrip[:] = [int(v) for v in rt]
     return out
 
 

@@ -14,19 +14,10 @@ def pytest_configure(config):
 
 
 def _gpu_available():
-    """True when a HIP device is visible (hipGetDeviceCount through the runtime the product library uses); no torch import needed."""
-    import ctypes
-    for name in ("libamdhip64.so", "libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so"):
-        try:
-            hip = ctypes.CDLL(name)
-        except OSError:
-            continue
-        n = ctypes.c_int(0)
-        try:
-            return hip.hipGetDeviceCount(ctypes.byref(n)) == 0 and n.value > 0
-        except Exception:
-            return False
-    return False
+    """True when this host exposes an AMD GPU to compute: the kernel driver's /dev/kfd node is there and usable.  Deliberately NOT a
+    hipGetDeviceCount call: loading a HIP runtime here, before the product library has mapped the one it shares with torch
+    (librabft_simulator_amd/_lib.py _one_hip_runtime), puts two ROCr runtimes into the process and the second finds no device."""
+    return os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK | os.W_OK)
 
 
 def pytest_collection_modifyitems(config, items):

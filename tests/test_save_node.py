@@ -57,13 +57,17 @@ def test_image_builder_on_the_compact_model_equals_oracle_image(oracle, name):
         sim = oracle.OracleSim(cfg, seed).run_until(t)
         caps = dict(qcap=max(4096, 8 * n * n), scap=(n * n + 8 * n + 64) if kw.get("quirks", 0) & 1 else max(64, 16 * n), bcap=512, lcap=512,
                     ql=48 if n <= 16 and not special else 0, qheap=1 if n > 16 else 0, qcal=1 if n > 32 else 0, ring=256 if n > 32 else 0, tw=8 if n > 32 else 0)
-        images = oracle.hostmodel_node_images(cfg, seed, t, **caps)
+        rt = []
+        images = oracle.hostmodel_node_images(cfg, seed, t, roundtrip=rt, **caps)
         for node in range(n):
             a, b = sim.save_node(node), images[node]
             assert b is not None
             if a != b:
                 assert node_state(b) == node_state(a), (name, t, node)  # (a readable diff first)
             assert a == b, (name, t, node)
+        # ConsensusNode::load_node (node.rs:211-231) through the product library's loader (csrc/lbft_save_node.h load_node_image): every
+        # node's NodeState scrubbed, the image loaded, saved again == the image; a node time before the image's own times is refused
+        assert rt == [0] * n, (name, t, rt)
 
 
 @pytest.mark.gpu
@@ -124,7 +128,9 @@ def test_image_builder_serves_nodes_that_changed_epoch(oracle, name):
         sim = oracle.OracleSim(cfg, seed).run_until(t)
         caps = dict(qcap=max(4096, 8 * n * n), scap=(n * n + 8 * n + 64), bcap=1024, lcap=1024, ql=0, qheap=1 if n > 16 else 0, qcal=1 if n > 32 else 0,
                     ring=256 if n > 32 else 0, tw=8 if n > 32 else 0, keep_stores=1)
-        images = oracle.hostmodel_node_images(cfg, seed, t, **caps)
+        rt = []
+        images = oracle.hostmodel_node_images(cfg, seed, t, roundtrip=rt, **caps)
+        assert rt == [0] * n, (name, t, rt)  # save -> scrub -> load -> save incl. every retired store (load_node_image)
         epochs = []
         for node in range(n):
             a, b = sim.save_node(node), images[node]
@@ -179,3 +185,80 @@ def test_device_without_the_archive_refuses_nodes_that_changed_epoch():
     small = np.zeros(16, dtype=np.uint8)
     rc = _lib.lib().lbft_batch_save_node(res0._sim._h, 0, 0, small.ctypes.data, small.size, ctypes.byref(ln))
     assert rc == -1 and ln.value > 16  # LBFT_ERR_INVALID, *len = the size needed
+
+
+LOAD_CASES = {
+    "n4_reference": (dict(num_nodes=4), 7, 1000, 400),
+    "n4_epochs_cpe5_q3": (dict(num_nodes=4, commands_per_epoch=5, quirks=3), 5, 1000, 900),
+    "n7_rotating_rights_q3_cpe3": (dict(num_nodes=7, voting_rights=[2, 1, 1, 3, 1, 2, 1], commands_per_epoch=3, quirks=3, rights_rotation=1), 11, 700, 1500),
+    "n40_weighted_rotating_q3_cpe3": (dict(num_nodes=40, voting_rights=[1 + (i % 4) for i in range(40)], commands_per_epoch=3, quirks=3, rights_rotation=1), 7, 450, 30000),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(LOAD_CASES))
+def test_device_load_node_round_trips_images_of_two_points_in_time(oracle, name):
+    """lbft_batch_load_node = ConsensusNode::load_node (node.rs:211-231) on the device.  A batch is advanced in bounded launches; every node
+    of instance 1 is saved mid-run (T1) and at the end (T2).  Loading the T1 image into the finished node and saving again returns the T1
+    image byte for byte (a real rollback of the NodeState: rounds, certificates, votes, retired stores), loading T2 restores T2; the final
+    image also equals the oracle's.  The reference's guard and the unknown-record refusal leave the node untouched."""
+    import librabft_simulator_amd as amd
+    kw, seed, max_clock, steps = LOAD_CASES[name]
+    cfg = oracle.make_config(math_mode=1, **kw)
+    kwd = dict(kw)
+    n = kwd.pop("num_nodes")
+    seeds = np.array([seed + 1, seed], dtype=np.uint64)
+    sim = amd.BatchSimulator.new(seeds, n, amd.RandomDelay.new(10.0, 4.0), keep_retired_stores=True, **kwd)
+    left, res = sim.run_steps(max_clock, steps)
+    assert left > 0  # mid-run
+    img1 = [sim.save_node(1, node) for node in range(n)]
+    for _ in range(10000):
+        left, res = sim.run_steps(max_clock, 4 * steps)
+        if left == 0:
+            break
+    assert left == 0
+    img2 = [sim.save_node(1, node) for node in range(n)]
+    ora = oracle.OracleSim(cfg, seed).run_until(max_clock)
+    assert [ora.save_node(node) for node in range(n)] == img2
+    assert any(a != b for a, b in zip(img1, img2))
+    far = 1 << 40
+    for node in range(n):
+        sim.load_node(1, node, img1[node], far)
+        assert sim.save_node(1, node) == img1[node], (name, node)
+        assert node_state(sim.save_node(1, node)) == node_state(img1[node])
+    for node in range(n):  # (the other nodes are back at T1 while this one returns to T2: no cross-talk through the shared block pool)
+        sim.load_node(1, node, img2[node], far)
+        assert sim.save_node(1, node) == img2[node], (name, node)
+    # instance 0 (another seed) never moved
+    other = amd.BatchSimulator.new(seeds, n, amd.RandomDelay.new(10.0, 4.0), keep_retired_stores=True, **kwd).loop_until(max_clock)
+    assert all(sim.save_node(0, node) == other.save_node(0, node) for node in range(n))
+    # node.rs:219-228: a node time before the image's own times
+    ns = node_state(img2[0])
+    latest = max(ns["latest_query_all_time"], ns["tracker"]["latest_commit_time"], ns["pacemaker"]["active_round_start_time"])
+    with pytest.raises(amd.LbftError) as e:
+        sim.load_node(1, 0, img2[0], latest - 1)
+    assert e.value.code == -4 and "future" in str(e.value)
+    sim.load_node(1, 0, img2[0], latest)  # (equal is accepted: node_time >= previous_time)
+    # an image of ANOTHER run names records this instance's pool does not hold; a truncated image is malformed
+    with pytest.raises(amd.LbftError) as e:
+        sim.load_node(1, 0, other.save_node(0, 0), far)
+    assert e.value.code == -3
+    with pytest.raises(amd.LbftError) as e:
+        sim.load_node(1, 0, img2[0][:-5], far)
+    assert e.value.code == -1
+    assert [sim.save_node(1, node) for node in range(n)] == img2  # every refusal left the node untouched
+
+
+@pytest.mark.gpu
+def test_device_load_node_takes_the_oracle_image_and_the_run_goes_on(oracle):
+    """A NodeState saved by ANOTHER implementation of the same run (the oracle = the reference's records and hashes) loads into the device
+    node in a node-level session, and the node behaves as the saved one: its next update_node equals the oracle node's."""
+    import librabft_simulator_amd as amd
+    seed, t = 9, 600
+    cfg = oracle.make_config(num_nodes=4, math_mode=1)
+    ora = oracle.OracleSim(cfg, seed).run_until(t)
+    res = amd.BatchSimulator.new(np.array([seed], dtype=np.uint64), 4, amd.RandomDelay.new(10.0, 4.0)).loop_until(t)
+    for node in range(4):
+        img = ora.save_node(node)
+        res._sim.load_node(0, node, img, 1 << 40)
+        assert res.save_node(0, node) == img
