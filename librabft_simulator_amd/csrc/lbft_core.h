@@ -134,6 +134,13 @@ typedef int64_t i64;
 #ifndef LBFT_QUAD_LDS_ROUND_TABLES
 #define LBFT_QUAD_LDS_ROUND_TABLES 1  // (with the line above: 65 536 x 4 16.43 -> 16.26 ms) lbft_k_run0q: leader / duration lookups that the LDS tables cover are plain LDS reads (not a load through a selected pointer)
 #endif
+#ifndef LBFT_WB_ALL
+#define LBFT_WB_ALL 0  // (class 0, instance-major) end_node writes the node's whole burst back unconditionally: no dirty-group tracking
+#endif
+#ifndef LBFT_COMMIT_CHAIN
+#define LBFT_COMMIT_CHAIN 1  // (round 4: 65 536 x 4 15.79 -> 15.57 ms) (n <= 32) a commit that does not extend the last one directly: the chain of blocks to commit (nearly always 2-3) is
+                             // collected in ONE pass of dependent fetches and committed from registers, instead of one walk per committed block
+#endif
 #ifndef LBFT_POPC_MAX_LPW
 #define LBFT_POPC_MAX_LPW 8u  // networks per wavefront up to which lbft_k_run0s is used (measured: 1 024 x 4: 6.3 against 7.5 ms, 8 192: 10.9 against 12.1,
                               // 16 384 (8 per wavefront): 14.8 against 15.9; 32 per wavefront: the lane-private scan stops at the queue's length and wins)
@@ -143,7 +150,16 @@ typedef int64_t i64;
 #endif
 #define LBFT_QLANE_PAD 2u  // (u64 words)
 #ifndef LBFT_POP_BATCH
-#define LBFT_POP_BATCH 16u // packed LDS queue front (class 0): independent loads in flight per batch of the pop's scan (a power of two)
+#define LBFT_POP_BATCH 16u // packed LDS queue front (class 0): independent loads in flight per batch of the pop's scan
+#endif
+// ... and for lbft_k_run0q, whose scan is shared by the two 32-lane halves of the wavefront: one pass covers 2 x the batch.  With batches
+// of 16 a lane whose queue holds more than 32 events (7 % of the pops, but some lane of 32 in 88 % of the wavefront-steps) sent the
+// whole wavefront through a second pass; 24 covers the 48 slots that 99.999 % of the pops stay below.
+#ifndef LBFT_POP_BATCH_QUAD
+#define LBFT_POP_BATCH_QUAD 24u  // (round 4: 15.60 -> 15.42 ms with 48 slots; 72 slots 15.50; batches of 32: 15.87)
+#endif
+#ifndef LBFT_PACKED_QL_QUAD
+#define LBFT_PACKED_QL_QUAD 48u  // LDS queue slots of lbft_k_run0q (a multiple of its batch); the 0.001 % of pushes beyond them spill to the HBM rows
 #endif
 #define LBFT_MAX_NODES 128  // node / author sets are 1..4 32-bit words (word 0 in the hot rows, the rest in extension rows)
 
@@ -357,6 +373,9 @@ enum BlockField : u32 {
 #define LBFT_BLK_PLAIN_FIFO 1  // plain round-robin replacement of the cached block records (no "recently used" bits, no aging pass per insertion):
                                // round 4, 65 536 x 4: 17.63 -> 17.05 ms -- the second-chance bookkeeping (a bit set per hit, three test-and-advance
                                // steps per insertion, inlined at 22 lookup sites: 480 of the kernel's 6.8 k instructions) cost more than the few misses it saved
+#endif
+#ifndef LBFT_BLK_CACHE_QUAD
+#define LBFT_BLK_CACHE_QUAD 4  // lbft_k_run0q: four records fit since round 4 freed the registers (238 VGPRs, no spill): 15.50 -> 15.38 ms; two: 17.4
 #endif
 #ifndef LBFT_BLK_CACHE
 #define LBFT_BLK_CACHE 3  // register-resident block records per instance (second-chance FIFO); measured: 2 -> 29.2 ms, 3 -> 27.9, 4 -> 28.0 (19 spilled registers), 5 -> 29.8
@@ -722,6 +741,7 @@ struct SimT {
   static constexpr bool COOP = BIG;
   static constexpr bool RING = BIG || CLS == 3;
   bool coop_on;  // set by run_coop: the event loop is being run by a whole wavefront
+  static constexpr u32 PB = CLS == 9 ? LBFT_POP_BATCH_QUAD : LBFT_POP_BATCH;  // slots per batch of the packed queue's scan
   LBFT_HD bool coop() const { return COOP && coop_on && P.qcal != 0 && P.ring != 0 && !lossy(); }
   LBFT_HD bool wide() const { return BIG ? true : (CLS == 3 ? NN() > 32 : false); }
   LBFT_HD bool heap() const { return C0 ? false : (BIG ? true : P.qheap != 0); }
@@ -777,7 +797,7 @@ struct SimT {
     if (RING) { rng.rtile = tile; rng.rrsh = rsh(); rng.rbase = boff(P.off_ring); rng.rmask = P.ring ? P.ring - 1u : 0xffffffffu; rng.rhead = 0; rng.rcnt = 0; }
   }
   LBFT_HD void attach_queue(u64* keys, u32* metas, u32 stride, u32 slots) {
-    qk = keys; qm = metas; qstr = stride; ql = qpacked() ? (slots & ~(LBFT_POP_BATCH - 1u)) : slots;  // packed entries are scanned in batches of LBFT_POP_BATCH
+    qk = keys; qm = metas; qstr = stride; ql = qpacked() ? slots - slots % PB : slots;  // packed entries are scanned in batches of PB
     qsh = 0;
     while ((1u << qsh) < stride) qsh++;  // (a shift instead of a quarter-rate 32-bit multiply per slot access)
     hsh = qsh;
@@ -915,7 +935,7 @@ struct SimT {
   mutable u32 cdirty;
   LBFT_HD u32 nf(u32 node, u32 f) const { return f < NF_FIXED_WORDS ? cw[f] : ld(nfw(node, f)); }
   LBFT_HD void nfs(u32 node, u32 f, u32 v) const {
-    if (f < NF_FIXED_WORDS) { cw[f] = v; cdirty |= 1u << group_of(f); }
+    if (f < NF_FIXED_WORDS) { cw[f] = v; if (!(C0I && LBFT_WB_ALL)) cdirty |= 1u << group_of(f); }
     else st(nfw(node, f), v);
   }
   LBFT_HD void begin_node(u32 node) const {
@@ -932,6 +952,15 @@ struct SimT {
   LBFT_HD void end_node(u32 node) const {
     ax_store(node);
     u32 nb = boff(OFFNODE() + node * NWORDS());
+    if (C0I && LBFT_WB_ALL) {
+      if (hc_reg()) hcdirty = 1;
+      hc_store(nb);
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 f = 0; f < NF_FIXED_WORDS; f++) stf(nb, f, cw[f]);
+      return;
+    }
     hc_store(nb);
 #if defined(__HIPCC__)
 #pragma unroll
@@ -975,7 +1004,7 @@ struct SimT {
     LBFT_HD u32 epoch() const { return w[B_EPOCH]; }
     LBFT_HD u32 depth() const { return w[B_DEPTH]; }
   };
-  static constexpr u32 BCN = CLS == 5 ? LBFT_BLK_CACHE_LEAN5 : LEAN2 ? LBFT_BLK_CACHE_LEAN2 : LBFT_BLK_CACHE;
+  static constexpr u32 BCN = CLS == 9 ? LBFT_BLK_CACHE_QUAD : CLS == 5 ? LBFT_BLK_CACHE_LEAN5 : LEAN2 ? LBFT_BLK_CACHE_LEAN2 : LBFT_BLK_CACHE;
   mutable u32 bc_id[BCN];
   mutable u32 bc_w[BCN][BC_WORDS];
   mutable u32 bc_next, bc_ref;  // FIFO hand + "recently used" bits (second chance: a hot old block survives)
@@ -1299,7 +1328,7 @@ struct SimT {
     else {
       u64 ma, mb; u32 ia, ib;
       qmin<LO, N / 2>(kk, ma, ia);
-      qmin<LO + N / 2, N / 2>(kk, mb, ib);
+      qmin<LO + N / 2, N - N / 2>(kk, mb, ib);
       bool lt = mb < ma;
       m = lt ? mb : ma; i = lt ? ib : ia;
     }
@@ -1390,12 +1419,12 @@ struct SimT {
     const u32 qcol = (u32)__shfl((int)qn, (int)col, 64);
     const u32 nl = qcol < ql ? qcol : ql;
     u64 m = ~0ULL; u32 mi = 0;
-    for (u32 k0 = grp * LBFT_POP_BATCH; k0 < nl; k0 += groups * LBFT_POP_BATCH) {
-      u64 kk[LBFT_POP_BATCH];
+    for (u32 k0 = grp * PB; k0 < nl; k0 += groups * PB) {
+      u64 kk[PB];
 #pragma unroll
-      for (u32 j = 0; j < LBFT_POP_BATCH; j++) kk[j] = kw[((k0 + j) << qsh) + col];
+      for (u32 j = 0; j < PB; j++) kk[j] = kw[((k0 + j) << qsh) + col];
       u64 bm; u32 bi;
-      qmin<0, LBFT_POP_BATCH>(kk, bm, bi);
+      qmin<0, PB>(kk, bm, bi);
       if (bm < m) { m = bm; mi = k0 + bi; }
     }
     for (u32 d = qstr; d < 64u; d <<= 1) {
@@ -1486,14 +1515,14 @@ struct SimT {
     if (qpacked()) {
       // ql is a multiple of the batch and slots >= qlen hold the sentinel: LBFT_POP_BATCH independent loads in flight per batch,
       // then a tree of compare-selects (a sequential min pays one LDS round trip per slot)
-      for (u32 k0 = 0; k0 < nl; k0 += LBFT_POP_BATCH) {
-        u64 kk[LBFT_POP_BATCH];
+      for (u32 k0 = 0; k0 < nl; k0 += PB) {
+        u64 kk[PB];
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-        for (u32 j = 0; j < LBFT_POP_BATCH; j++) kk[j] = qk[qx(k0 + j)];
+        for (u32 j = 0; j < PB; j++) kk[j] = qk[qx(k0 + j)];
         u64 bm; u32 bi;
-        qmin<0, LBFT_POP_BATCH>(kk, bm, bi);
+        qmin<0, PB>(kk, bm, bi);
         if (bm < bkey) { bkey = bm; best = k0 + bi; }
       }
       pop_take(bkey, best, time, kind, meta);
@@ -2012,21 +2041,65 @@ struct SimT {
 #endif
     for (u32 f = 0; f < BC_WORDS; f++) r0.w[f] = 0;
     r0.xk = 0; r0.x[0] = r0.x[1] = r0.x[2] = 0;
+    if (LBFT_COMMIT_CHAIN && !wide()) {
+      constexpr u32 CAP = 4;
+      u32 cid[CAP], clink[CAP], cdep[CAP], cpend[CAP];
+      u32 kk = 0, x = start;
+      bool more = true;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+      for (u32 i = 0; i < CAP; i++) {
+        cid[i] = 0; clink[i] = 0; cdep[i] = 0; cpend[i] = 0;
+        if (more) {
+          const u32 sb = boff(bfw(x, 0));
+          const u32 link = ldf(sb, B_LINK), pr = ldf(sb, B_PREV_ROUND), d = ldf(sb, B_DEPTH), pe = ldf(sb, B_PEND);
+          cid[i] = x; clink[i] = link; cdep[i] = d; cpend[i] = pe; kk = i + 1;
+          x = link & 0xffffu;
+          more = x != 0 && pr > after;  // (the parent commits too while its round -- this block's previous_round -- is above `after`)
+        }
+      }
+      if (LBFT_LIKELY(!more)) {
+        for (u32 j = kk; j-- > 0;) {  // oldest first
+          const u32 y = j == 0 ? cid[0] : j == 1 ? cid[1] : j == 2 ? cid[2] : cid[3];
+          Blk ry = r0;
+          ry.w[B_LINK] = j == 0 ? clink[0] : j == 1 ? clink[1] : j == 2 ? clink[2] : clink[3];
+          ry.w[B_DEPTH] = j == 0 ? cdep[0] : j == 1 ? cdep[1] : j == 2 ? cdep[2] : cdep[3];
+          ry.w[B_PEND] = j == 0 ? cpend[0] : j == 1 ? cpend[1] : j == 2 ? cpend[2] : cpend[3];
+          if (LBFT_UNLIKELY(!state_pending(node, y, ry))) { fault |= F_COMMIT_UNKNOWN_STATE; return; }
+          const u32 prev = ry.prev();
+          const u32 base = prev ? prev : nf(node, NF_INIT_STATE_BLK);
+          if (LBFT_UNLIKELY(base != nf(node, NF_LAST_COMMITTED_BLK))) { fault |= F_COMMIT_NOT_SUCCESSOR; return; }
+          if (commit_block(node, y, ry.depth())) break;
+        }
+        return;
+      }
+      // (a chain longer than CAP: the general walk below)
+    }
     {  // an old block that nothing else will look at again: straight from its row, not through the cache
       u32 sb = boff(bfw(start, 0));
       r0.w[B_LINK] = ldf(sb, B_LINK); r0.w[B_PREV_ROUND] = ldf(sb, B_PREV_ROUND);
       r0.w[B_DEPTH] = ldf(sb, B_DEPTH); r0.w[B_PEND] = ldf(sb, B_PEND);
     }
+    // (the walks below visit OLD blocks that nothing else will look at again: straight from their rows -- the rows are always current,
+    // every cache update is written through -- instead of through the register cache, where each of them evicted a hot record:
+    // 47 of a 4-node network's 119 cache misses were these lookups, round 4)
     for (u32 x = (r0.prev() && r0.prev_round() > after) ? r0.prev() : 0; x;) {
-      Blk rx = blk_get(x);
-      if (rx.round() <= after) break;
+      u32 xr, xp;
+      chain_fetch(x, xr, xp);
+      if (xr <= after) break;
       k++;
-      x = rx.prev();
+      x = xp;
     }
     for (u32 j = k; j-- > 0;) {  // oldest first
       u32 y = start;
-      for (u32 s = 0; s < j; s++) y = blk_get(y).prev();
-      Blk ry = j == 0 ? r0 : blk_get(y);
+      for (u32 s = 0; s < j; s++) { u32 yr, yp; chain_fetch(y, yr, yp); y = yp; }
+      Blk ry = r0;
+      if (j != 0) {
+        u32 sb = boff(bfw(y, 0));
+        ry.w[B_LINK] = ldf(sb, B_LINK); ry.w[B_PREV_ROUND] = ldf(sb, B_PREV_ROUND);
+        ry.w[B_DEPTH] = ldf(sb, B_DEPTH); ry.w[B_PEND] = ldf(sb, B_PEND);
+      }
       // SimulatedContext::commit (simulated_context.rs:160-185)
       if (LBFT_UNLIKELY(!state_pending(node, y, ry))) { fault |= F_COMMIT_UNKNOWN_STATE; return; }
       u32 prev = ry.prev();

@@ -1177,10 +1177,12 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   p.lpw = lpw;
   const bool hcbr_lds = !(LBFT_C0_IMAJOR && LBFT_C0_HCREG && quad_kernel(p));  // (the kernel choice only depends on the layout and lpw)
   u32 ql_auto = (u32)((budget - run_lds_bytes(0, lpw, n, slot_bytes, nwaves, hcbr_lds) - 2048) / (slot_bytes * nwaves * lpw));  // (run_lds_bytes(0, ..) includes the lane padding)
-  if (p.qpack && ql_auto > LBFT_PACKED_QL_MAX) ql_auto = LBFT_PACKED_QL_MAX;
+  const bool quadk = quad_kernel(p);
+  const u32 ql_max = quadk ? LBFT_PACKED_QL_QUAD : LBFT_PACKED_QL_MAX, pop_batch = quadk ? LBFT_POP_BATCH_QUAD : LBFT_POP_BATCH;
+  if (p.qpack && ql_auto > ql_max) ql_auto = ql_max;
   u32 ql = b->ql < 0 ? ql_auto : (u32)b->ql;
   if (ql > qcap) ql = qcap;
-  if (p.qpack) ql &= ~(LBFT_POP_BATCH - 1u);  // scanned in batches of LBFT_POP_BATCH
+  if (p.qpack) ql -= ql % pop_batch;  // scanned in batches (SimT::PB)
   if (p.qcal) ql = 0;  // the calendar lives in HBM rows
   if (run_lds_bytes(ql, lpw, n, slot_bytes, nwaves, hcbr_lds) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
   p.ql = ql;
