@@ -31,7 +31,7 @@ def parse():
     ap.add_argument("--instances", type=int, default=65536, help="instances per GPU (weak scaling: the default mode)")
     ap.add_argument("--total-instances", type=int, default=0,
                     help="strong scaling: this many instances in total, sharded over the ranks (BASELINE.json config 3 read as ONE 65 536-instance batch on 1..8 GPUs)")
-    ap.add_argument("--parity-instances", type=int, default=1024, help="instances of the timed batch (strided) re-run on the CPU oracle and compared (0 = no gate)")
+    ap.add_argument("--parity-instances", type=int, default=16384, help="instances of the timed batch (strided) re-run on the CPU oracle and compared (0 = no gate)")
     ap.add_argument("--nodes", type=int, default=4)
     ap.add_argument("--max-clock", type=int, default=1000)
     ap.add_argument("--base-seed", type=int, default=1)

@@ -233,6 +233,7 @@ struct Params {
   u32 max_steps;  // events per instance per launch (0 = unlimited)
   u32 lpw;        // lanes of each wavefront that carry an instance (1..64): occupancy vs lane-utilisation knob
   u32 ql;         // event-queue slots per instance that live in LDS (slots >= ql spill to the HBM rows)
+  u32 blw;        // large-network kernels: entries of the per-network LDS window of block records behind the register cache (a power of two; 0 = none)
   unsigned long long* prof;  // LBFT_PHASE_TIMERS builds only: cycles per phase of the event loop, summed over wavefronts
 };
 
@@ -792,7 +793,7 @@ struct SimT {
 
   LBFT_HD SimT(const Params& p, u32* state, u32 i) : SimT(p, reinterpret_cast<char*>(state) + tile_offset_bytes(p, i), (i & (p.tw - 1u)) * 4u, 0) {}
   LBFT_HD SimT(const Params& p, char* tile_base, u32 lane_byte_offset, int) : P(p), tile(tile_base), lane4(lane_byte_offset), qk(nullptr), qm(nullptr), qstr(0), qsh(0), ql(0), zig_x(p.zig_x), zig_f(p.zig_f), exp_tab(p.exp_tab),
-        leader_lds(nullptr), dur_lds(nullptr), leader_lds_len(0), dur_lds_len(0), hc(nullptr), plist_lds(nullptr) {
+        leader_lds(nullptr), dur_lds(nullptr), leader_lds_len(0), dur_lds_len(0), hc(nullptr), bl(nullptr), bl_n(0), bl_sh(0), plist_lds(nullptr) {
     coop_on = false; cur_xk = 0; wtab = p.weights; hcdirty = 0; sw_epoch = 0; sw_blk = 0;
     if (RING) { rng.rtile = tile; rng.rrsh = rsh(); rng.rbase = boff(P.off_ring); rng.rmask = P.ring ? P.ring - 1u : 0xffffffffu; rng.rhead = 0; rng.rcnt = 0; }
   }
@@ -880,6 +881,16 @@ struct SimT {
   }
   LBFT_HD void attach_tables(const u64* zx, const u64* zf, const u64* et) { zig_x = zx; zig_f = zf; exp_tab = et; }
   LBFT_HD void attach_peer_list(u8* list) { plist_lds = list; }
+  // Large networks (33-128 nodes; the kernels that fit ONE cached block record in their registers): a direct-mapped window of hot block
+  // records in LDS behind the register cache -- entry b mod N of this network's lane-private column: [N tags][N x BC_WORDS words].  The
+  // 4-node kernel did not gain from such a window (its register cache misses 3 times per run); a 64-node network misses its single
+  // register record on 75 % of 117 k lookups per run, each a dependent memory round trip (round 4, host-model counters).  Write-through
+  // like the register cache (blk_put updates a resident entry), rebuilt empty at every launch.
+  u32* bl;       // nullptr = none
+  u32 bl_n, bl_sh;
+  LBFT_HD void attach_blk_window(u32* column, u32 entries, u32 stride_shift) { bl = entries ? column : nullptr; bl_n = entries; bl_sh = stride_shift; }
+  LBFT_HD u32 blx(u32 k) const { return k << bl_sh; }
+  LBFT_HD void blw_reset() const { if (bl) for (u32 e = 0; e < bl_n; e++) bl[blx(e)] = 0; }
   const u32* wtab;  // voting rights (the device attaches an LDS copy: weight() sits inside the vote / timeout insertion loops)
   LBFT_HD void attach_weights(const u32* w) { wtab = w; }
   LBFT_HD void attach_round_tables(const u8* leaders, u32 nl, const i64* durs, u32 nd) { leader_lds = leaders; leader_lds_len = nl; dur_lds = durs; dur_lds_len = nd; }
@@ -1038,6 +1049,15 @@ struct SimT {
     }
     bc_next = bc_next + 1 == BCN ? 0 : bc_next + 1;
   }
+  LBFT_HD void blw_fill(u32 b, const Blk& r) const {
+    if (!BIG || !bl) return;
+    const u32 e = b & (bl_n - 1u);
+    bl[blx(e)] = b;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 f = 0; f < BC_WORDS; f++) bl[blx(bl_n + e * BC_WORDS + f)] = r.w[f];
+  }
   mutable u32 cur_xk;  // extension word of the node sets that the current event's node lives in (0: node < 32 or n <= 32)
   LBFT_HD Blk blk_get(u32 b) const {  // b != 0
     Blk r;
@@ -1070,12 +1090,26 @@ struct SimT {
       LBFT_COUNT(25);
       LBFT_STAT(45);
       LBFT_MARK(28);  // (diagnostic builds: the time since the previous mark, so that 29 is the miss alone)
-      u32 bb = boff(bfw(b, 0));
+      bool in_window = false;
+      if (BIG && bl) {  // the LDS window first
+        const u32 e = b & (bl_n - 1u);
+        if (bl[blx(e)] == b) {
+          in_window = true;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = ldf(bb, f);  // one burst of independent loads
-      LBFT_DRAIN_VMEM();
+          for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = bl[blx(bl_n + e * BC_WORDS + f)];
+        }
+      }
+      if (!in_window) {
+        u32 bb = boff(bfw(b, 0));
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = ldf(bb, f);  // one burst of independent loads
+        LBFT_DRAIN_VMEM();
+        blw_fill(b, r);
+      }
       LBFT_MARK(29);
       blk_cache_insert(b, r);
     }
@@ -1117,6 +1151,10 @@ struct SimT {
   // Write-through update of one mask word of block b (f is B_KNOWN, B_QC or B_PEND).
   LBFT_HD void blk_put(u32 b, u32 f, u32 v) const {
     bfs(b, f, v);
+    if (BIG && bl) {
+      const u32 e = b & (bl_n - 1u);
+      if (bl[blx(e)] == b) bl[blx(bl_n + e * BC_WORDS + f)] = v;
+    }
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
@@ -1907,6 +1945,7 @@ struct SimT {
     bfs(b, B_VOTERS, 0);
     for (u32 k = 0; wide() && k < 4 * (MW() - 1); k++) bfs(b, B_WORDS + k, 0);
     blk_cache_insert(b, rb);
+    blw_fill(b, rb);
     insert_block(node, b, rb);
   }
   // create_vote (record_store.rs:676-700)
@@ -2497,8 +2536,14 @@ struct SimT {
     for (u32 q = 0; q < 4; q++) { tcw[q] = LBFT_UNI(tw_[q], k); tow[q] = LBFT_UNI(ow_[q], k); }
     const u32 src_tc = nfw(node, NF_FIXED_WORDS + tc_sel * NN()), src_to = nfw(node, NF_FIXED_WORDS + (1u - tc_sel) * NN());
     const u32 dst_tc = base + S_FIXED_WORDS, dst_to = base + S_FIXED_WORDS + NN();
-    for (u32 a0 = 0; a0 < NN(); a0 += 64u) {
-      const u32 q0 = a0 >> 5;
+    // (at most two passes of 64 authors: unrolled, so that the set words are picked with compile-time indices -- indexed by the loop
+    // variable the two four-word arrays went through scratch memory, a store + a dependent load per pass in every lane of the wavefront)
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (u32 pass = 0; pass < (LBFT_MAX_NODES + 63) / 64; pass++) {
+      const u32 a0 = pass * 64u, q0 = pass * 2u;
+      if (a0 >= NN()) break;
       PL<u32> vt, vo, ht, ho;
       LBFT_FOR_LANES(l) {
         u32 wt = l < 32u ? tcw[q0] : tcw[q0 + 1], wo = l < 32u ? tow[q0] : tow[q0 + 1];

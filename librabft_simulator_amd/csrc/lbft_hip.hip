@@ -78,6 +78,8 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restr
 #define LBFT_QPAD(slot_bytes) ((slot_bytes) == 8 && LBFT_C0_QLANE ? LBFT_QLANE_PAD : 0u)
 // `hcbr_lds`: class 0 with networks of <= 4 nodes keeps the nodes' hcbr buffers in LDS -- except lbft_k_run0q, which carries them in
 // registers with the node burst (LBFT_C0_HCREG)
+// the LDS window of block records of the large-network kernels (SimT::attach_blk_window): `entries` records + tags per network
+static inline size_t blk_window_bytes(u32 entries, u32 lpw, u32 nwaves) { return (size_t)nwaves * lpw * entries * (1u + BC_WORDS) * 4u; }
 static inline size_t run_lds_bytes(u32 ql, u32 lpw, u32 n, u32 slot_bytes, u32 nwaves, bool hcbr_lds = true) {
   return (size_t)LBFT_TABLE_U64 * 8 + (size_t)nwaves * (ql + LBFT_QPAD(slot_bytes)) * lpw * slot_bytes + (size_t)nwaves * LBFT_NPHASES * 8 + 8 +
          (n > 16 ? (size_t)nwaves * lpw * LBFT_MAX_NODES : 0) +
@@ -137,6 +139,14 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
     s.attach_tables(t_zx, t_zf, t_et);
     s.attach_round_tables(t_leader, n_leader, t_dur, n_dur);
     s.attach_weights(t_weights);
+    {  // [receiver lists: nwaves * lpw * LBFT_MAX_NODES bytes][block-record windows: lane-private columns per wavefront]
+      u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 12u, nwaves);
+      u32* win = reinterpret_cast<u32*>(lists + (size_t)nwaves * p.lpw * LBFT_MAX_NODES) + (size_t)wave * p.lpw * p.blw * (1u + BC_WORDS);
+      u32 wsh = 0;
+      while ((1u << wsh) < p.lpw) wsh++;
+      s.attach_blk_window(win + (lane & (p.lpw - 1u)), p.blw, wsh);
+      if (lane < p.lpw) s.blw_reset();
+    }
     if (lead) {
       u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 12u, nwaves);
       s.attach_peer_list(lists + ((size_t)wave * p.lpw + lane) * LBFT_MAX_NODES);
@@ -501,6 +511,14 @@ static bool small_batch_kernel(const Params& p) {
   return LBFT_C0_POPC && !LBFT_C0_QLANE && sim_class(p) == 0 && p.lpw <= LBFT_POPC_MAX_LPW && !(e && atoi(e));
 }
 // ... and large batches of the headline network (4 nodes, unit rights, log-normal delays) lbft_k_run0q; LBFT_NO_QUAD=1: lbft_k_run0
+// LBFT_BLK_WINDOW=n: entries (a power of two, default 32; 0 = off) of the large-network kernels' LDS window of block records
+static u32 blk_window_max() {
+  const char* e = getenv("LBFT_BLK_WINDOW");
+  u32 v = e ? (u32)atoi(e) : 32u;
+  while (v & (v - 1)) v &= v - 1;  // round down to a power of two
+  return v > 256u ? 256u : v;
+}
+static bool blk_window_allowed() { return blk_window_max() != 0; }
 static bool quad_kernel(const Params& p) {
   const char* e = getenv("LBFT_NO_QUAD");
   return LBFT_C0_QUAD && sim_quad(p) && !small_batch_kernel(p) && !(e && atoi(e));
@@ -1187,6 +1205,16 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   if (run_lds_bytes(ql, lpw, n, slot_bytes, nwaves, hcbr_lds) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
   p.ql = ql;
   b->lds_bytes = run_lds_bytes(ql, lpw, n, slot_bytes, nwaves, hcbr_lds);
+  // large networks: the LDS that the calendar queue leaves unused holds a window of block records per network (SimT::attach_blk_window)
+  p.blw = 0;
+  // (measured, round 4: c4live 2.77 -> 2.76 s, c5live 4.72 -> 4.60 s with 32 entries, 4.58 s with 64; the kernel without the record exchange
+  // LOSES with it -- c4 346 -> 357 ms, c5 1.90 -> 1.98 s, its three register records already serve it -- and does not get one)
+  if (sim_lean_q1(p) && lean2_allowed() && blk_window_allowed()) {
+    u32 e = blk_window_max();
+    while (e && b->lds_bytes + blk_window_bytes(e, lpw, nwaves) > 150u * 1024u) e >>= 1;
+    p.blw = e;
+    b->lds_bytes += blk_window_bytes(e, lpw, nwaves);
+  }
   p.prof = b->d_prof;
   return LBFT_OK;
 }

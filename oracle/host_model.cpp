@@ -123,6 +123,8 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
     s.attach_queue(keys.data(), metas.data(), 1, p.ql);
     std::vector<u32> hcbr(32);  // the device's LDS copy of the hcbr buffers (class 0, n <= 4)
     if (p.ql) s.attach_hcbr(hcbr.data());
+    std::vector<u32> window(32 * (1 + BC_WORDS), 0);  // the large-network kernels' LDS window of block records (32 entries, as the device's default)
+    if (p.n > 32) s.attach_blk_window(window.data(), 32, 0);
     s.load_scalars();
     s.queue_to_lds();
     s.hcbr_to_lds();
