@@ -886,11 +886,12 @@ struct SimT {
   // 4-node kernel did not gain from such a window (its register cache misses 3 times per run); a 64-node network misses its single
   // register record on 75 % of 117 k lookups per run, each a dependent memory round trip (round 4, host-model counters).  Write-through
   // like the register cache (blk_put updates a resident entry), rebuilt empty at every launch.
+  static constexpr bool BLW = CLS == 7;  // (compiled into lbft_k_run2q only: in lbft_k_run2l it cost 60 spilled registers and time, see lbft_hip.hip)
   u32* bl;       // nullptr = none
   u32 bl_n, bl_sh;
-  LBFT_HD void attach_blk_window(u32* column, u32 entries, u32 stride_shift) { bl = entries ? column : nullptr; bl_n = entries; bl_sh = stride_shift; }
+  LBFT_HD void attach_blk_window(u32* column, u32 entries, u32 stride_shift) { bl = (BLW && entries) ? column : nullptr; bl_n = entries; bl_sh = stride_shift; }
   LBFT_HD u32 blx(u32 k) const { return k << bl_sh; }
-  LBFT_HD void blw_reset() const { if (bl) for (u32 e = 0; e < bl_n; e++) bl[blx(e)] = 0; }
+  LBFT_HD void blw_reset() const { if (BLW && bl) for (u32 e = 0; e < bl_n; e++) bl[blx(e)] = 0; }
   const u32* wtab;  // voting rights (the device attaches an LDS copy: weight() sits inside the vote / timeout insertion loops)
   LBFT_HD void attach_weights(const u32* w) { wtab = w; }
   LBFT_HD void attach_round_tables(const u8* leaders, u32 nl, const i64* durs, u32 nd) { leader_lds = leaders; leader_lds_len = nl; dur_lds = durs; dur_lds_len = nd; }
@@ -1050,7 +1051,7 @@ struct SimT {
     bc_next = bc_next + 1 == BCN ? 0 : bc_next + 1;
   }
   LBFT_HD void blw_fill(u32 b, const Blk& r) const {
-    if (!BIG || !bl) return;
+    if (!BLW || !bl) return;
     const u32 e = b & (bl_n - 1u);
     bl[blx(e)] = b;
 #if defined(__HIPCC__)
@@ -1091,7 +1092,7 @@ struct SimT {
       LBFT_STAT(45);
       LBFT_MARK(28);  // (diagnostic builds: the time since the previous mark, so that 29 is the miss alone)
       bool in_window = false;
-      if (BIG && bl) {  // the LDS window first
+      if (BLW && bl) {  // the LDS window first
         const u32 e = b & (bl_n - 1u);
         if (bl[blx(e)] == b) {
           in_window = true;
@@ -1151,7 +1152,7 @@ struct SimT {
   // Write-through update of one mask word of block b (f is B_KNOWN, B_QC or B_PEND).
   LBFT_HD void blk_put(u32 b, u32 f, u32 v) const {
     bfs(b, f, v);
-    if (BIG && bl) {
+    if (BLW && bl) {
       const u32 e = b & (bl_n - 1u);
       if (bl[blx(e)] == b) bl[blx(bl_n + e * BC_WORDS + f)] = v;
     }
