@@ -109,19 +109,9 @@ typedef int64_t i64;
 #ifndef LBFT_C0_QUAD
 #define LBFT_C0_QUAD 1   // large class-0 batches of 4-node networks with unit rights and log-normal delays run lbft_k_run0q (SimT<9>)
 #endif
-// Light-event drain (kernel class 0): a popped event that needs no update_node -- a request under the reference's routing (quirk Q1: one
-// delay sample + one push) or a cancelled timer (three words of its node) -- is finished right after the pop and the lane pops again,
-// up to LBFT_DRAIN times per step, so that it enters the heavy part of the step (node burst, update_node, send loop) with an event that
-// needs it.  Per-network event order and RNG draw order are unchanged.  (23 % of the headline batch's pops are such events.)
-#ifndef LBFT_DRAIN
-#define LBFT_DRAIN 0
-#endif
-#ifndef LBFT_DRAIN_TIMERS
-#define LBFT_DRAIN_TIMERS 1
-#endif
-#ifndef LBFT_DRAIN_REQ
-#define LBFT_DRAIN_REQ 1
-#endif
+// (round 4 built and measured a "light-event drain" -- requests and cancelled timers finished right after the pop, the lane popping again
+// before the heavy part of the step: -18 % wavefront-steps, +-0 time in seven variants; EXPERIMENTS.md.  The code is in the history:
+// commit "Light-event drain + snapshot hoist as measured variants".)
 // (kernel class 0) the notification snapshot of an event is allocated and written BEFORE the send loop, at one site that every sending
 // lane reaches together, instead of inside the loop at the first notification whose time lies within the horizon (a different
 // iteration for lanes whose list starts behind a sync request); a snapshot that ends up with no reference is freed as before.
@@ -155,6 +145,11 @@ typedef int64_t i64;
 // ... and for lbft_k_run0q, whose scan is shared by the two 32-lane halves of the wavefront: one pass covers 2 x the batch.  With batches
 // of 16 a lane whose queue holds more than 32 events (7 % of the pops, but some lane of 32 in 88 % of the wavefront-steps) sent the
 // whole wavefront through a second pass; 24 covers the 48 slots that 99.999 % of the pops stay below.
+// lbft_k_run0q: the LDS queue columns are 32 lanes apart whatever the lanes per wavefront (16 or 32), so the column stride is a compile-time
+// shift and the slots of a scan batch are immediates of ONE address (24 ds_read_b64 with offsets) instead of two address operations per slot
+#ifndef LBFT_QUAD_STRIDE32
+#define LBFT_QUAD_STRIDE32 1
+#endif
 #ifndef LBFT_POP_BATCH_QUAD
 #define LBFT_POP_BATCH_QUAD 24u  // (round 4: 15.60 -> 15.42 ms with 48 slots; 72 slots 15.50; batches of 32: 15.87)
 #endif
@@ -781,7 +776,14 @@ struct SimT {
   // instruction immediates, two keys per ds_read_b128), lanes LBFT_QLANE_PAD words apart beyond the slots so that the lanes of a
   // wavefront reading the same slot fall into different banks
   static constexpr bool QLANE = C0 && LBFT_C0_QLANE != 0;
-  LBFT_HD u32 qx(u32 k) const { return QLANE ? k : k << qsh; }
+#if defined(__HIP_DEVICE_COMPILE__)
+  static constexpr bool QS32 = CLS == 9 && LBFT_QUAD_STRIDE32 != 0;
+#else
+  static constexpr bool QS32 = false;  // (the host model passes one plain column per network)
+#endif
+  LBFT_HD u32 QSH() const { return QS32 ? 5u : qsh; }
+  LBFT_HD u32 QSTR() const { return QS32 ? 32u : qstr; }
+  LBFT_HD u32 qx(u32 k) const { return QLANE ? k : k << QSH(); }
   // read-only tables (LDS copies on the device)
   const u64 *zig_x, *zig_f, *exp_tab;
   const u8* leader_lds;   // first leader_lds_len rounds of the leader table
@@ -1454,19 +1456,19 @@ struct SimT {
   LBFT_HD void coop_find_cols(const u64* kw, u32 qn, u64& bkey, u32& best) const {
 #if defined(__HIP_DEVICE_COMPILE__)
     const u32 lane = lbft_lane_id();
-    const u32 col = lane & (qstr - 1u), grp = lane >> qsh, groups = 64u >> qsh;
+    const u32 col = lane & (QSTR() - 1u), grp = lane >> QSH(), groups = 64u >> QSH();
     const u32 qcol = (u32)__shfl((int)qn, (int)col, 64);
     const u32 nl = qcol < ql ? qcol : ql;
     u64 m = ~0ULL; u32 mi = 0;
     for (u32 k0 = grp * PB; k0 < nl; k0 += groups * PB) {
       u64 kk[PB];
 #pragma unroll
-      for (u32 j = 0; j < PB; j++) kk[j] = kw[((k0 + j) << qsh) + col];
+      for (u32 j = 0; j < PB; j++) kk[j] = kw[((k0 + j) << QSH()) + col];
       u64 bm; u32 bi;
       qmin<0, PB>(kk, bm, bi);
       if (bm < m) { m = bm; mi = k0 + bi; }
     }
-    for (u32 d = qstr; d < 64u; d <<= 1) {
+    for (u32 d = QSTR(); d < 64u; d <<= 1) {
       u32 olo = (u32)__shfl_xor((int)(u32)m, (int)d, 64), ohi = (u32)__shfl_xor((int)(u32)(m >> 32), (int)d, 64), oi = (u32)__shfl_xor((int)mi, (int)d, 64);
       u64 o = ((u64)ohi << 32) | olo;
       bool lt = o < m;
@@ -3259,8 +3261,7 @@ struct SimT {
   // scalar send loop handles) + step_end (write-back); the cooperative kernels run coop_bulk between the two.
   struct StepCtx { u32 node, sender, kind; i32 t_event; bool do_update; };
   // (fkey, fbest): class 8 only -- the pop's scan was done by the whole wavefront (run_popc / coop_find): smallest LDS-resident key, its slot
-  // `pre`: the event was popped by the caller already (light-event drain): (pt, pkind, pmeta)
-  LBFT_HD bool step_begin(StepCtx& c, u64 fkey = 0, u32 fbest = 0, bool pre = false, i32 pt = 0, u32 pkind = 0, u32 pmeta = 0) {  // false: the queue is empty
+  LBFT_HD bool step_begin(StepCtx& c, u64 fkey = 0, u32 fbest = 0) {  // false: the queue is empty
     {
       i32 t; u32 kind, meta;
       // A response that spans several epochs (quirks bit 0) is one event but several steps: between two epochs the reference runs
@@ -3269,7 +3270,6 @@ struct SimT {
       // registers alive across it).
       const bool resumed = q1() && cont != 0;
       if (resumed) { t = clock; kind = 2; meta = ld(I_CONT_META); }
-      else if (pre) { t = pt; kind = pkind; meta = pmeta; }
       else {
         if (POPC) {  // (the scan was done by the whole wavefront: run_popc)
           if (qlen == 0) return false;
@@ -3377,46 +3377,6 @@ struct SimT {
     }
     return true;
   }
-  // ---- light-event drain (LBFT_DRAIN; class 0 only: reference request routing, no trace, lossless) ----
-  static constexpr u32 DRAIN = C0 ? (u32)LBFT_DRAIN : 0u;
-  // If the popped event needs no update_node, process it completely -- exactly what step_begin / send_loop / step_end do for it -- and
-  // return true; otherwise touch nothing and return false.
-  LBFT_HD bool try_light(i32 t, u32 kind, u32 meta) {
-    const u32 node = meta & 0xffu, sender = (meta >> 8) & 0xffu, slot = meta >> 16;
-    if (LBFT_DRAIN_REQ && kind == 1) {  // DataSyncRequestEvent, answered on the requester (simulator.rs:441-453): one response, no node state
-      if (t > clock) clock = t;
-      last_node = node;
-      ev1++; LBFT_STAT(3);
-      i64 d = sample_delay();
-      i64 tr = d > INT64_MAX - (i64)clock ? INT64_MAX : (i64)clock + d;
-      push_event(tr, 2, node, sender, 0);
-      return true;
-    }
-    if (LBFT_DRAIN_TIMERS && kind == 3) {  // UpdateTimerEvent (simulator.rs:403-415): cancelled?
-      const i32 clk = t > clock ? t : clock;
-      const u32 nb = boff(OFFNODE() + node * NWORDS());
-      const i32 ign = (i32)ldf(nb, NF_IGNORE_UNTIL);
-      const u32 ltt = ldf(nb, NF_LAST_TIMER_T);
-      if (clk > ign) return false;
-      clock = clk;
-      last_node = node;
-      LBFT_STAT(0); LBFT_STAT(1);
-      ev3 += 1 + slot;
-      if (LBFT_UNLIKELY((u32)clk == ltt)) {  // folded duplicates of this timer (only when a later timer fell past the horizon)
-        const u32 dups = ldf(nb, NF_TIMER_DUPS);
-        if (dups != 0) {
-          u32 ds = ldf(nb, NF_DUP_STAMP) + 1;
-          vd_stamp = (vd_time == (u32)clk && vd_stamp > ds) ? vd_stamp : ds;
-          vd_time = (u32)clk;
-        }
-        ev3 += dups;
-        stf(nb, NF_TIMER_DUPS, 0);
-        stf(nb, NF_LAST_TIMER_T, 0xffffffffu);
-      }
-      return true;
-    }
-    return false;
-  }
   LBFT_HD void step_end(const StepCtx& c) {
     if (c.do_update) {
       LBFT_DRAIN_VMEM();
@@ -3437,23 +3397,6 @@ struct SimT {
     for (;;) {
       if (steps >= max_steps) return false;
       StepCtx c;
-      if (DRAIN) {
-        i32 t; u32 kind, meta;
-        if (!pop_event(t, kind, meta)) return true;
-        steps++;
-        bool have = true;
-        for (u32 d = 0; d < DRAIN; d++) {
-          if (!try_light(t, kind, meta)) break;
-          LBFT_STEP_DONE();
-          have = false;
-          if (steps >= max_steps) return false;
-          if (!pop_event(t, kind, meta)) return true;
-          steps++;
-          have = true;
-        }
-        if (have) { step_begin(c, 0, 0, true, t, kind, meta); step_end(c); LBFT_STEP_DONE(); }
-        continue;
-      }
       if (!step_begin(c)) return true;
       steps++;
       // (a kernel class with cooperative bulk sends that is run lane-per-network -- the generic read-back class, the host
@@ -3466,51 +3409,35 @@ struct SimT {
   // that carry a network (`leader`) then execute its event.  `kw`: the wavefront's LDS key array.
   LBFT_HD bool run_popc(bool leader, const u64* kw) {
     u32 steps = 0;
-    u32 max_steps = P.max_steps ? P.max_steps : 0xffffffffu;
+    u32 max_steps = P.max_steps ? P.max_steps : 0xffffffffu;  // (>= 1)
     LBFT_PIN_VGPR(max_steps);
-    bool go = leader, drained = true;
+    bool go = leader && qlen != 0, drained = true;
     bulk = 0;
-    for (;;) {
-      if (go && steps >= max_steps) { go = false; drained = false; }
-      if (go && qlen == 0) go = false;
+    // (tested at the bottom: with the exit in the middle of the body the compiler kept two copies of the loop-carried state -- the one the
+    // exit uses and the one the step updates -- and moved ~28 registers from one to the other and back in every iteration)
 #if defined(__HIP_DEVICE_COMPILE__)
-      if (__ballot(go) == 0) break;
+    bool any = __ballot(go) != 0;
 #else
-      if (!go) break;
+    bool any = go;
 #endif
+    while (any) {
       u64 fkey; u32 fbest;
       if (PAIR) coop_find_cols(kw, go ? qlen : 0u, fkey, fbest);
       else coop_find(kw, fkey, fbest);
-      if (DRAIN) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        i32 t = 0; u32 kind = 0, meta = 0;
-        bool have = go;
-        if (go) { pop_take(fkey, fbest, t, kind, meta); steps++; }
-        for (u32 d = 0; d < DRAIN; d++) {
-          const bool light = have && try_light(t, kind, meta);
-          if (light) have = false;
-          const bool again = light && steps < max_steps && qlen != 0;
-          if (__ballot(again) == 0) break;
-          // (only the columns whose lane asks for another event are scanned again)
-          if (PAIR) coop_find_cols(kw, again ? qlen : 0u, fkey, fbest);
-          else coop_find(kw, fkey, fbest);
-          if (again) { pop_take(fkey, fbest, t, kind, meta); steps++; have = true; }
-        }
-        if (have) {
-          StepCtx c;
-          step_begin(c, 0, 0, true, t, kind, meta);
-          step_end(c);
-        }
-#endif
-        continue;
-      }
       if (go) {
         StepCtx c;
         step_begin(c, fkey, fbest);
         steps++;
         step_end(c);
         LBFT_STEP_DONE();
+        if (steps >= max_steps) { go = false; drained = false; }
+        else if (qlen == 0) go = false;
       }
+#if defined(__HIP_DEVICE_COMPILE__)
+      any = __ballot(go) != 0;
+#else
+      any = go;
+#endif
     }
     return drained;
   }

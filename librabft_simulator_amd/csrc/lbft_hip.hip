@@ -113,8 +113,9 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
   __syncthreads();
   u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const u32 qslots = p.ql + (SimT<CLS>::QLANE ? LBFT_QLANE_PAD : 0u);  // u64 words per instance in the key area
-  u64* keys = SimT<CLS>::QLANE ? lds + LBFT_TABLE_U64 + ((size_t)wave * p.lpw + lane) * qslots : lds + LBFT_TABLE_U64 + (size_t)wave * p.ql * p.lpw + lane;
-  u32* metas = reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)nwaves * qslots * p.lpw) + (size_t)wave * p.ql * p.lpw + lane;  // (CLS 0: unused, not allocated)
+  const u32 qcols = SimT<CLS>::QS32 ? 32u : p.lpw;  // queue columns per wavefront (lbft_k_run0q: always 32, see LBFT_QUAD_STRIDE32)
+  u64* keys = SimT<CLS>::QLANE ? lds + LBFT_TABLE_U64 + ((size_t)wave * p.lpw + lane) * qslots : lds + LBFT_TABLE_U64 + (size_t)wave * p.ql * qcols + lane;
+  u32* metas = reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)nwaves * qslots * qcols) + (size_t)wave * p.ql * qcols + lane;  // (CLS 0: unused, not allocated)
   const u32 meta_words = SimT<CLS>::C0 ? 0u : nwaves * p.ql * p.lpw;
   // Only the first p.lpw lanes of a wavefront carry an instance (occupancy vs lane-utilisation knob).
   u32 i = (blockIdx.x * nwaves + wave) * p.lpw + lane;
@@ -154,7 +155,7 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
       s.queue_to_lds();
     }
 #if defined(LBFT_PHASE_TIMERS)
-    u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)nwaves * qslots * p.lpw) +
+    u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)nwaves * qslots * qcols) +
                                         (size_t)meta_words + (meta_words & 1u)) + wave * LBFT_NPHASES;
     if (lane == 0) { for (int k = 0; k < LBFT_NPHASES; k++) wprof[k] = 0; wprof[31] = __builtin_readcyclecounter(); }
     s.wprof = wprof;
@@ -193,7 +194,7 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
       s.hcbr_to_lds();
     }
 #if defined(LBFT_PHASE_TIMERS)
-    u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)nwaves * qslots * p.lpw) +
+    u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)nwaves * qslots * qcols) +
                                         (size_t)meta_words + (meta_words & 1u)) + wave * LBFT_NPHASES;
     if (lane == 0) { for (int k = 0; k < LBFT_NPHASES; k++) wprof[k] = 0; wprof[31] = __builtin_readcyclecounter(); }
     s.wprof = wprof;
@@ -234,7 +235,7 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
       s.hcbr_to_lds();
 #if defined(LBFT_PHASE_TIMERS)
       // per-wavefront accumulators behind the queue columns (8-byte aligned: the meta area is a multiple of 8 words)
-      u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)nwaves * qslots * p.lpw) +
+      u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)nwaves * qslots * qcols) +
                                           (size_t)meta_words + (meta_words & 1u)) + wave * LBFT_NPHASES;
       if (lane == 0) { for (int k = 0; k < LBFT_NPHASES; k++) wprof[k] = 0; wprof[31] = __builtin_readcyclecounter(); }
       s.wprof = wprof;
@@ -1189,22 +1190,27 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   u32 wg_per_cu = (64 / lpw) * 4 / nwaves;  // workgroups that make up a CU's 256 instances
   if (wg_per_cu < 1) wg_per_cu = 1;
   if (wg_per_cu > 4) wg_per_cu = 4;
+  // (the kernels compiled for two wavefronts per SIMD run as 8-wavefront workgroups: one of them fills a CU's wavefront slots at 256
+  // registers per lane, so the whole LDS is that one workgroup's whatever its lanes per wavefront -- round 4: with the budget of two the
+  // 16-lane form of lbft_k_run0q kept 24 queue slots in LDS and spilled the rest to HBM)
+  if (two_wave_kernel && nwaves == 8) wg_per_cu = 1;
   size_t budget = (160u * 1024u) / wg_per_cu;
   // 2 KiB slack per workgroup: with less, two workgroups of 32-lane wavefronts do not become co-resident on a CU
   u32 slot_bytes = p.qpack ? 8u : 12u;  // kernel class 0 keeps one-word entries
   p.lpw = lpw;
-  const bool hcbr_lds = !(LBFT_C0_IMAJOR && LBFT_C0_HCREG && quad_kernel(p));  // (the kernel choice only depends on the layout and lpw)
-  u32 ql_auto = (u32)((budget - run_lds_bytes(0, lpw, n, slot_bytes, nwaves, hcbr_lds) - 2048) / (slot_bytes * nwaves * lpw));  // (run_lds_bytes(0, ..) includes the lane padding)
-  const bool quadk = quad_kernel(p);
+  const bool quadk = quad_kernel(p);  // (the kernel choice only depends on the layout and lpw)
+  const bool hcbr_lds = !(LBFT_C0_IMAJOR && LBFT_C0_HCREG && quadk);
+  const u32 qcols = (quadk && LBFT_QUAD_STRIDE32) ? 32u : lpw;  // queue columns per wavefront in LDS (SimT::QS32)
+  u32 ql_auto = (u32)((budget - run_lds_bytes(0, qcols, n, slot_bytes, nwaves, hcbr_lds) - 2048) / (slot_bytes * nwaves * qcols));  // (run_lds_bytes(0, ..) includes the lane padding)
   const u32 ql_max = quadk ? LBFT_PACKED_QL_QUAD : LBFT_PACKED_QL_MAX, pop_batch = quadk ? LBFT_POP_BATCH_QUAD : LBFT_POP_BATCH;
   if (p.qpack && ql_auto > ql_max) ql_auto = ql_max;
   u32 ql = b->ql < 0 ? ql_auto : (u32)b->ql;
   if (ql > qcap) ql = qcap;
   if (p.qpack) ql -= ql % pop_batch;  // scanned in batches (SimT::PB)
   if (p.qcal) ql = 0;  // the calendar lives in HBM rows
-  if (run_lds_bytes(ql, lpw, n, slot_bytes, nwaves, hcbr_lds) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
+  if (run_lds_bytes(ql, qcols, n, slot_bytes, nwaves, hcbr_lds) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
   p.ql = ql;
-  b->lds_bytes = run_lds_bytes(ql, lpw, n, slot_bytes, nwaves, hcbr_lds);
+  b->lds_bytes = run_lds_bytes(ql, qcols, n, slot_bytes, nwaves, hcbr_lds);
   // large networks: the LDS that the calendar queue leaves unused holds a window of block records per network (SimT::attach_blk_window)
   p.blw = 0;
   // (measured, round 4: c4live 2.77 -> 2.76 s, c5live 4.72 -> 4.60 s with 32 entries, 4.58 s with 64; the kernel without the record exchange
