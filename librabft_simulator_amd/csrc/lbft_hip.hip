@@ -522,7 +522,9 @@ static u32 blk_window_max() {
 static bool blk_window_allowed() { return blk_window_max() != 0; }
 static bool quad_kernel(const Params& p) {
   const char* e = getenv("LBFT_NO_QUAD");
-  return LBFT_C0_QUAD && sim_quad(p) && !small_batch_kernel(p) && !(e && atoi(e));
+  // (its LDS queue columns are 32 lanes apart at compile time, LBFT_QUAD_STRIDE32: 64 networks per wavefront -- batches beyond 131 072
+  // networks, or a forced lanes_per_wavefront -- run the generic class-0 kernel)
+  return LBFT_C0_QUAD && sim_quad(p) && !small_batch_kernel(p) && !(LBFT_QUAD_STRIDE32 && p.lpw > 32) && !(e && atoi(e));
 }
 static bool lean_allowed() { const char* e = getenv("LBFT_NO_LEAN"); return !(e && atoi(e)); }
 static bool lean2_allowed() { const char* e = getenv("LBFT_LEAN2"); return lean_allowed() && !(e && !atoi(e)); }
