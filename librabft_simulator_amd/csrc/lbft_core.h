@@ -5,8 +5,9 @@
 //     hot block records;
 //   * LDS: the front of the event queue (lane-private columns) and the read-only tables of the delay
 //     sampler / pacemaker;
-//   * HBM: everything, in tiles of 64 instances whose rows are word-interleaved (word w of instance i at
-//     tile(i / 64) + w * 256 + (i % 64) * 4 bytes), so a wavefront reads a row as one contiguous segment.
+//   * HBM: everything -- instance-major for kernel class 0 and the large-network classes (every instance's words contiguous: a lane's
+//     node / snapshot / block record is one run of words, read and written with wide accesses at `record base + immediate`), tiles of 64
+//     word-interleaved instances for class 1.
 //
 // The reference keeps records in HashMaps keyed by 64-bit BCS/SipHash values; those hashes are
 // identities only, so this model replaces them with structural ids:
@@ -374,7 +375,7 @@ enum BlockField : u32 {
 #define LBFT_BLK_CACHE_QUAD 4  // lbft_k_run0q: four records fit since round 4 freed the registers (238 VGPRs, no spill): 15.50 -> 15.38 ms; two: 17.4
 #endif
 #ifndef LBFT_BLK_CACHE
-#define LBFT_BLK_CACHE 3  // register-resident block records per instance (second-chance FIFO); measured: 2 -> 29.2 ms, 3 -> 27.9, 4 -> 28.0 (19 spilled registers), 5 -> 29.8
+#define LBFT_BLK_CACHE 3  // register-resident block records per instance (FIFO; LBFT_BLK_PLAIN_FIFO=0: second chance); round 1: 2 -> 29.2 ms, 3 -> 27.9, 4 -> 28.0 (19 spilled registers), 5 -> 29.8
 #endif
 
 // Snapshot (notification, data_sync.rs:16-39) rows; followed by tc_hcbr[n], to_hcbr[n].
@@ -1021,7 +1022,7 @@ struct SimT {
   static constexpr u32 BCN = CLS == 9 ? LBFT_BLK_CACHE_QUAD : CLS == 5 ? LBFT_BLK_CACHE_LEAN5 : LEAN2 ? LBFT_BLK_CACHE_LEAN2 : LBFT_BLK_CACHE;
   mutable u32 bc_id[BCN];
   mutable u32 bc_w[BCN][BC_WORDS];
-  mutable u32 bc_next, bc_ref;  // FIFO hand + "recently used" bits (second chance: a hot old block survives)
+  mutable u32 bc_next, bc_ref;  // FIFO hand (+ "recently used" bits of the second-chance variant, LBFT_BLK_PLAIN_FIFO=0)
   LBFT_HD void blk_cache_reset() const {
     for (u32 e = 0; e < BCN; e++) bc_id[e] = 0;
     bc_next = 0; bc_ref = 0;
