@@ -711,15 +711,34 @@ struct SimT {
   // (device only: the host build of the kernel logic -- oracle/host_model.cpp, one network per object -- keeps the lane-private pop)
 #if defined(__HIP_DEVICE_COMPILE__)
   static constexpr bool PAIR = CLS == 9 && LBFT_QUAD_PAIR != 0;
-  static constexpr bool POPC = CLS == 8 || PAIR;
+  static constexpr bool POPC = CLS == 8 || CLS == 12 || PAIR;
+  // 12 = class 8 for ONE network per wavefront (lbft_k_run0u), executed as WAVEFRONT-UNIFORM code: the network's index, its rows' base and
+  // its LDS columns are the same in all 64 lanes (derived from the wavefront's index through readfirstlane, no lane term), every lane runs
+  // the step with the same values, so the compiler's uniformity analysis places the protocol logic on the scalar unit -- SGPR state, scalar
+  // compares and real branches instead of per-lane values under execution masks (a lone lane of 64 pays a v_cmp + s_and_saveexec +
+  // s_cbranch_execz + s_or per `if`; 64-bit integer work is one scalar instruction instead of two vector ones).  Loads from the (uniform)
+  // row addresses stay vector loads (the rows are written in the same loop: the scalar cache is not coherent with them); stores and LDS
+  // writes are issued by all lanes with the same address and value.  Only the pop's scan (coop_find) has per-lane values.
+  static constexpr bool WUNI = CLS == 12;
 #else
   static constexpr bool PAIR = false;
   static constexpr bool POPC = false;
+  static constexpr bool WUNI = false;
 #endif
   // 9 = class 0 with the headline network fixed at compile time (lbft_k_run0q): 4 nodes, unit voting rights, log-normal delays, <= 64
   // snapshot slots, no layout padding -- loop bounds, the quorum, record sizes and the first row offsets become immediates (sim_quad())
   static constexpr bool QUAD = CLS == 9;  // (the small-batch kernel gains nothing from it: 1 024 x 4 6.2 against 5.8 ms, 8 192 x 4 10.0 against 9.9 -- latency-bound)
-  static constexpr bool C0 = CLS == 0 || CLS == 8 || CLS == 9;
+  static constexpr bool C0 = CLS == 0 || CLS == 8 || CLS == 9 || CLS == 12;
+  // (WUNI) the value an out-of-line helper returned, declared wavefront-uniform: a call's result counts as divergent, and through the
+  // branches that test it so would every value of the event loop after it (all lanes passed the same arguments)
+  LBFT_HD static u32 wuni(u32 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (WUNI) return (u32)__builtin_amdgcn_readfirstlane((int)v);
+#endif
+    return v;
+  }
+  LBFT_HD static u64 wuni(u64 v) { return WUNI ? ((u64)wuni((u32)(v >> 32)) << 32) | wuni((u32)v) : v; }
+  LBFT_HD static double wuni(double v) { return WUNI ? lbft_asdouble(wuni(lbft_asuint64(v))) : v; }
   LBFT_HD u32 NN() const { return QUAD ? 4u : P.n; }
   LBFT_HD u32 MW() const { return QUAD ? 1u : P.mw; }
   LBFT_HD u32 NWORDS() const { return QUAD ? NF_FIXED_WORDS + 8u : P.node_words; }
@@ -812,8 +831,9 @@ struct SimT {
     qsh = 0;
     while ((1u << qsh) < stride) qsh++;  // (a shift instead of a quarter-rate 32-bit multiply per slot access)
     hsh = qsh;
-    if (!QLANE) LBFT_PIN_VGPR(qsh);
-    LBFT_PIN_VGPR(ql);
+    // (not in the wavefront-uniform kernel: an inline-asm result counts as divergent, and everything compared with it after it)
+    if (!QLANE && !WUNI) LBFT_PIN_VGPR(qsh);
+    if (!WUNI) LBFT_PIN_VGPR(ql);
   }
   // highest_certified_block_round buffers of the nodes' timeouts (hcbr[node][2][n], behind the fixed node rows): for
   // networks of <= 4 nodes in kernel class 0 the device keeps them in LDS for the duration of a launch (32 words per
@@ -863,7 +883,7 @@ struct SimT {
       u32 v03 = (idx & 2u) ? v23 : v01, v47 = (idx & 2u) ? v67 : v45;
       return (idx & 4u) ? v47 : v03;
     }
-    if (hc_lds()) return hc[(node * 8u + buf * 4u + a) << hsh];
+    if (hc_lds()) return wuni(hc[(node * 8u + buf * 4u + a) << hsh]);  // (`hc` is a generic pointer: a flat load counts as a source of divergence)
     return nfm(node, NF_FIXED_WORDS + buf * NN() + a);
   }
   LBFT_HD void hc_set(u32 node, u32 buf, u32 a, u32 v) const {
@@ -1238,14 +1258,14 @@ struct SimT {
         while (-2.0 * yy < xx * xx) {
           double a = lbft_asdouble((1023ULL << 52) | (rng.next_u64() >> 12)) - (1.0 - 0x1p-53);
           double b = lbft_asdouble((1023ULL << 52) | (rng.next_u64() >> 12)) - (1.0 - 0x1p-53);
-          xx = lbft_log(a) / R;
-          yy = lbft_log(b);
+          xx = wuni(lbft_log(a)) / R;
+          yy = wuni(lbft_log(b));
         }
         return u < 0.0 ? xx - R : R - xx;
       }
       double f0 = lbft_asdouble(zig_f[i]), f1 = lbft_asdouble(zig_f[i + 1]);
       double f01 = (double)(rng.next_u64() >> 11) * 0x1p-53;
-      if (f1 + (f0 - f1) * f01 < lbft_exp(-x * x / 2.0, exp_tab)) return x;
+      if (f1 + (f0 - f1) * f01 < wuni(lbft_exp(-x * x / 2.0, exp_tab))) return x;
     }
   }
   // (i64) exp(y) as the reference truncates it (simulator.rs:115-117), without evaluating the exact exp when a cheap estimate
@@ -1267,7 +1287,7 @@ struct SimT {
       if (LBFT_LIKELY(fr > m && fr < 1.0f - m)) return (i64)(i32)fl;
     }
 #endif
-    return f64_to_i64_sat(lbft_exp(y, exp_tab));
+    return f64_to_i64_sat(wuni(lbft_exp(y, exp_tab)));
   }
   LBFT_HD i64 sample_delay() {
     if (DMODEL() == 1) return P.uni_lo + (i64)rng.gen_range_u64(P.uni_span);
@@ -1413,8 +1433,16 @@ struct SimT {
     const u32 words = ql << qsh;  // ql * lpw
     u64 m = ~0ULL; u32 mi = 0;
     for (u32 w0 = 0; w0 < words; w0 += 256u) {  // four independent loads per round trip
-      u64 v0 = w0 + lane < words ? kw[w0 + lane] : ~0ULL, v1 = w0 + 64u + lane < words ? kw[w0 + 64u + lane] : ~0ULL;
-      u64 v2 = w0 + 128u + lane < words ? kw[w0 + 128u + lane] : ~0ULL, v3 = w0 + 192u + lane < words ? kw[w0 + 192u + lane] : ~0ULL;
+      u64 v0, v1, v2, v3;
+      if (WUNI) {  // branch-free (clamped index + select): no lane-dependent branch inside the otherwise wavefront-uniform event loop
+        const u32 last = words - 1u;
+        const u32 i0 = w0 + lane, i1 = w0 + 64u + lane, i2 = w0 + 128u + lane, i3 = w0 + 192u + lane;
+        v0 = kw[i0 < last ? i0 : last]; v1 = kw[i1 < last ? i1 : last]; v2 = kw[i2 < last ? i2 : last]; v3 = kw[i3 < last ? i3 : last];
+        v0 = i0 < words ? v0 : ~0ULL; v1 = i1 < words ? v1 : ~0ULL; v2 = i2 < words ? v2 : ~0ULL; v3 = i3 < words ? v3 : ~0ULL;
+      } else {
+        v0 = w0 + lane < words ? kw[w0 + lane] : ~0ULL; v1 = w0 + 64u + lane < words ? kw[w0 + 64u + lane] : ~0ULL;
+        v2 = w0 + 128u + lane < words ? kw[w0 + 128u + lane] : ~0ULL; v3 = w0 + 192u + lane < words ? kw[w0 + 192u + lane] : ~0ULL;
+      }
       bool a = v1 < v0, b = v3 < v2;
       u64 m01 = a ? v1 : v0, m23 = b ? v3 : v2;
       u32 i01 = a ? w0 + 64u + lane : w0 + lane, i23 = b ? w0 + 192u + lane : w0 + 128u + lane;
@@ -1422,7 +1450,7 @@ struct SimT {
       u64 mm = c ? m23 : m01; u32 ii = c ? i23 : i01;
       if (mm < m) { m = mm; mi = ii; }
     }
-    if (qstr == 1u) {
+    if (WUNI || qstr == 1u) {  // (WUNI: at compile time -- the other exit's per-lane result would make every later value count as divergent)
       // ONE network in the wavefront: a DPP reduction (row shifts, then the two row broadcasts) leaves the minimum in lane 63 -- no LDS
       // crossbar round trips at all --, a scalar read hands it to every lane, and the lane holding it names the slot
       u32 lo = (u32)m, hi = (u32)(m >> 32);
@@ -1669,13 +1697,13 @@ struct SimT {
     if (QUAD && LBFT_QUAD_LDS_ROUND_TABLES) {  // (no rotation: shift == 0; a 4-node run to clock 1000 stays far below the table's 1 024 rounds)
       if (LBFT_LIKELY(round < leader_lds_len)) return leader_lds[round];
       if (round < P.leader_len) return P.leader_tab[round];
-      return compute_leader(P.weights, NN(), P.total_votes, round, shift);
+      return wuni(compute_leader(P.weights, NN(), P.total_votes, round, shift));
     }
     if (LBFT_LIKELY(round < P.leader_len)) {
       const u8* tab = (round < leader_lds_len && shift == 0) ? leader_lds : P.leader_tab + (size_t)shift * P.leader_len;
-      return tab[round];
+      return wuni((u32)tab[round]);  // (a flat load counts as a source of divergence)
     }
-    return compute_leader(P.weights, NN(), P.total_votes, round, shift);
+    return wuni(compute_leader(P.weights, NN(), P.total_votes, round, shift));
   }
 
   // ---- SimulatedContext (simulated_context.rs:102-158): is the ledger state `blk` available? ----
@@ -1997,7 +2025,7 @@ struct SimT {
       return P.dur_tab[k];
     }
     const i64* tab = k < dur_lds_len ? dur_lds : P.dur_tab;  // (a selected pointer: see leader())
-    return tab[k];
+    return (i64)wuni((u64)tab[k]);
   }
   LBFT_HD PmActions update_pacemaker(u32 node, i64 lqat, i64 lclock) {
     PmActions a;
@@ -2201,7 +2229,7 @@ struct SimT {
       if (LBFT_UNLIKELY((u64)depth >= ((u64)nf(node, NF_EPOCH) + 1) * P.cpe)) {
         // the epoch switch itself (node.rs:331-348) runs once process_commits has returned (update_node: epoch_switch) -- ONE site, and
         // one with few live registers, instead of a copy inside each commit path
-        sw_epoch = (u32)udiv64((u64)depth, P.cpe) + 1u;
+        sw_epoch = (u32)wuni(udiv64((u64)depth, P.cpe)) + 1u;
         sw_blk = y;
         return true;
       }
@@ -3434,7 +3462,7 @@ struct SimT {
   LBFT_HD bool run_popc(bool leader, const u64* kw) {
     u32 steps = 0;
     u32 max_steps = P.max_steps ? P.max_steps : 0xffffffffu;  // (>= 1)
-    LBFT_PIN_VGPR(max_steps);
+    if (!WUNI) LBFT_PIN_VGPR(max_steps);
     bool go = leader && qlen != 0, drained = true;
     bulk = 0;
     // (tested at the bottom: with the exit in the middle of the body the compiler kept two copies of the loop-carried state -- the one the

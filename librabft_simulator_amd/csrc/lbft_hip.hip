@@ -173,6 +173,52 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
       atomicAdd(&p.prof[31], (unsigned long long)(__builtin_readcyclecounter() - t_begin));
     }
 #endif
+  } else if constexpr (SimT<CLS>::WUNI) {
+    // ONE network per wavefront as wavefront-uniform code (SimT<12>, lbft_k_run0u; p.lpw == 1): nothing below depends on the lane -- the
+    // network's index, rows and LDS columns come from the wavefront's index through readfirstlane -- so all 64 lanes run the event loop
+    // with the same values and the compiler keeps the protocol logic on the scalar unit (lbft_core.h, SimT::WUNI); only the pop's scan
+    // (coop_find) reads per-lane slots.  Stores / LDS writes: the same address and value in every lane.
+    const u32 uwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const u32 ui = __builtin_amdgcn_readfirstlane(blockIdx.x * nwaves + uwave);  // (p.lpw == 1: the wavefront's network)
+    u64* ukeys = lds + LBFT_TABLE_U64 + (size_t)uwave * p.ql;
+    SimT<CLS> s(p, tile, 0u, 0);
+    bool lead = false;
+    if (ui < p.m) lead = s.ld(I_DONE) == 0;
+    s.attach_queue(ukeys, nullptr, 1u, p.ql);
+    s.attach_tables(t_zx, t_zf, t_et);
+    s.attach_round_tables(t_leader, n_leader, t_dur, n_dur);
+    s.attach_weights(t_weights);
+    if (p.n <= 4) {  // the nodes' hcbr buffers
+      u32* hcb = reinterpret_cast<u32*>(reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, 1u, 8u, nwaves));
+      s.attach_hcbr(hcb + (size_t)uwave * LBFT_LDS_HCBR_WORDS);
+    }
+    s.qlen = 0;
+    if (lead) {
+      s.load_scalars();
+      s.queue_to_lds();
+      s.hcbr_to_lds();
+    }
+#if defined(LBFT_PHASE_TIMERS)
+    u64* wprof = reinterpret_cast<u64*>(reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)nwaves * qslots * qcols) +
+                                        (size_t)meta_words + (meta_words & 1u)) + uwave * LBFT_NPHASES;
+    if (lane == 0) { for (int k = 0; k < LBFT_NPHASES; k++) wprof[k] = 0; wprof[31] = __builtin_readcyclecounter(); }
+    s.wprof = wprof;
+    u64 t_begin = __builtin_readcyclecounter();
+#endif
+    bool drained = s.run_popc(lead, ukeys);
+    if (lead) {
+      done = drained;
+      s.queue_from_lds();
+      s.hcbr_from_lds();
+      s.store_scalars(done);
+    }
+#if defined(LBFT_PHASE_TIMERS)
+    if (p.prof && lane == 0) {
+      for (int k = 0; k < 31; k++) atomicAdd(&p.prof[k], (unsigned long long)s.wprof[k]);
+      atomicAdd(&p.prof[31], (unsigned long long)(__builtin_readcyclecounter() - t_begin));
+    }
+#endif
+    active = lane == 0 && ui < p.m;  // (one report per wavefront below)
   } else if constexpr (SimT<CLS>::POPC) {
     // Class 0 with the wavefront-wide pop (SimT::run_popc): every lane runs the event loop and scans the wavefront's queue columns;
     // the lanes that carry a network execute its events.
@@ -274,6 +320,12 @@ void lbft_k_run0q(Params p, u32* __restrict__ state, u32* __restrict__ unfinishe
 // ... and for small batches (at most LBFT_POPC_MAX_LPW networks per wavefront): the pop's scan by all 64 lanes (SimT<8>)
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run0s(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(8) run_body<8>(p, state, unfinished); }
+// ... and for ONE network per wavefront, as wavefront-uniform code on the scalar unit (SimT<12>; opt-in: LBFT_UNI=1 -- built in round 4 without GPU
+// time left to measure it: bit-exactness and timing are the first call of round 5)
+#if defined(LBFT_WITH_UNI)  // (not in the product build: the shipped code object stays the one profiles/r04 was taken with)
+__global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
+void lbft_k_run0u(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(12) run_body<12>(p, state, unfinished); }
+#endif
 // Large networks without record exchange / trace / lossy network (sim_lean()): also two wavefronts per SIMD (4 spilled registers)
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run2l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(5) run_body<5>(p, state, unfinished); }
@@ -525,6 +577,16 @@ static bool quad_kernel(const Params& p) {
   // (its LDS queue columns are 32 lanes apart at compile time, LBFT_QUAD_STRIDE32: 64 networks per wavefront -- batches beyond 131 072
   // networks, or a forced lanes_per_wavefront -- run the generic class-0 kernel)
   return LBFT_C0_QUAD && sim_quad(p) && !small_batch_kernel(p) && !(LBFT_QUAD_STRIDE32 && p.lpw > 32) && !(e && atoi(e));
+}
+// (builds with -DLBFT_WITH_UNI only) LBFT_UNI=1: a small batch with ONE network per wavefront runs lbft_k_run0u (wavefront-uniform code)
+static bool uni_kernel(const Params& p) {
+#if defined(LBFT_WITH_UNI)
+  const char* e = getenv("LBFT_UNI");
+  return small_batch_kernel(p) && p.lpw == 1 && e && atoi(e);
+#else
+  (void)p;
+  return false;
+#endif
 }
 static bool lean_allowed() { const char* e = getenv("LBFT_NO_LEAN"); return !(e && atoi(e)); }
 static bool lean2_allowed() { const char* e = getenv("LBFT_LEAN2"); return lean_allowed() && !(e && !atoi(e)); }
@@ -1265,7 +1327,12 @@ static int launch_run(lbft_batch* b) {
   const bool leanq = lean && sim_lean_q1(p);
   const bool small0 = small_batch_kernel(p);
   const bool quad0 = quad_kernel(p);
-  const void* run_fn = leanq ? reinterpret_cast<const void*>(lbft_k_run2q) : lean ? reinterpret_cast<const void*>(lbft_k_run2l) : lean1 ? reinterpret_cast<const void*>(lbft_k_run1l) : (cls == 0 && small0) ? reinterpret_cast<const void*>(lbft_k_run0s) : (cls == 0 && quad0) ? reinterpret_cast<const void*>(lbft_k_run0q) : cls == 0 ? reinterpret_cast<const void*>(lbft_k_run0)
+  const bool uni0 = cls == 0 && uni_kernel(p);
+  const void* run_fn = leanq ? reinterpret_cast<const void*>(lbft_k_run2q) : lean ? reinterpret_cast<const void*>(lbft_k_run2l) : lean1 ? reinterpret_cast<const void*>(lbft_k_run1l) :
+#if defined(LBFT_WITH_UNI)
+                       uni0 ? reinterpret_cast<const void*>(lbft_k_run0u) :
+#endif
+                       (cls == 0 && small0) ? reinterpret_cast<const void*>(lbft_k_run0s) : (cls == 0 && quad0) ? reinterpret_cast<const void*>(lbft_k_run0q) : cls == 0 ? reinterpret_cast<const void*>(lbft_k_run0)
                      : cls == 1 ? reinterpret_cast<const void*>(lbft_k_run<1>) : reinterpret_cast<const void*>(lbft_k_run<2>);
   HIP_TRY(hipFuncSetAttribute(run_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
   const u32 nwaves = b->run_waves, block = 64u * nwaves;
@@ -1275,6 +1342,9 @@ static int launch_run(lbft_batch* b) {
   if (leanq) lbft_k_run2q<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (lean) lbft_k_run2l<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (lean1) lbft_k_run1l<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+#if defined(LBFT_WITH_UNI)
+  else if (uni0) lbft_k_run0u<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+#endif
   else if (cls == 0 && small0) lbft_k_run0s<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (cls == 0 && quad0) lbft_k_run0q<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (cls == 0) lbft_k_run0<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);

@@ -142,6 +142,23 @@ def test_run_kernels_keep_their_state_in_registers(hiplib):
         assert len(lean2) == 1 and lean2[0]["vgpr_count"] <= 256 and lean2[0]["vgpr_spill_count"] <= cap, (name, lean2)
 
 
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"), reason="needs the ROCm LLVM binutils")
+def test_uniform_kernel_compiles_to_scalar_code(tmp_path):
+    """lbft_k_run0u (SimT<12>, opt-in: -DLBFT_WITH_UNI builds + LBFT_UNI=1; built in round 4, unmeasured): one network per wavefront with
+    nothing depending on the lane, so that the compiler keeps the step on the scalar unit.  One source of divergence slipping in -- an
+    inline-asm pin, a flat load, the return value of an out-of-line helper -- silently turns the whole loop back into masked vector code:
+    the register budget tells (99 VGPRs when uniform, ~200 as vector code) and so do the s_and_saveexec sites (9 against 336)."""
+    import subprocess
+    from librabft_simulator_amd import build
+    out = str(tmp_path / "dev12.so")
+    subprocess.check_call([build.hipcc_path()] + build.HIPCC_FLAGS + ["-DLBFT_WITH_UNI", "-DLBFT_DEV_ONLY_CLASS=12", build.SRC, "-o", out],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    k = [v for name, v in _kernel_metadata(out).items() if "lbft_k_run0u" in name]
+    assert len(k) == 1 and k[0]["vgpr_count"] <= 128 and k[0]["private_segment_fixed_size"] == 0, k
+    # the product library does not contain it (its machine code stays the profiled one)
+    assert not any("lbft_k_run0u" in name for name in _kernel_metadata(build.OUT))
+
+
 def test_kernel_hash_reads_the_code_object(hiplib):
     """build.kernel_hash(): the stamp that ties profiles/current/pmc_traffic.json to the kernels bench.py runs (sha256 of the
     gfx950 machine code in the built library; parsed without binutils so that it works on the GPU box)."""

@@ -447,10 +447,11 @@ def _prefix_consistent(cc, hist):
 
 
 def _oracle_sample(m, count):
-    """Strided sample of `count` of the m instances of a full-size batch for the bit-exact oracle comparison.  Defaults (round 3): the
-    whole batch for configuration 4 (137 s of oracle time on the GPU box's 256 host threads), 1 024 for c4live, 512 for c5 / c5live --
-    sized so that the whole -m gpu suite stays under ten minutes.  LBFT_FULL_CHECK_FRACTION scales the sample: 4 gives the 2 048
-    instances each of profiles/r03/full_size_checks_2048.txt (17 minutes, all equal), 0.25 suits a small host."""
+    """Strided sample of `count` of the m instances of a full-size batch for the bit-exact oracle comparison.  Defaults (round 4): the
+    whole batch for configuration 4 (137 s of oracle time on the GPU box's 256 host threads), 2 048 for c4live (181 s), 1 024 for c5live (173 s),
+    512 for c5 -- sized so that the whole -m gpu suite stays around twelve minutes (round 3: 1 024 / 512 / 512, under ten).  LBFT_FULL_CHECK_FRACTION
+    scales the sample: 2 gives 2 048 instances of c5live, 4 of c5 (profiles/r03/full_size_checks_2048.txt: 17 minutes, all equal), 0.25
+    suits a small host."""
     count = max(256, min(m, int(count * float(os.environ.get("LBFT_FULL_CHECK_FRACTION", "1")))))
     return np.unique(np.linspace(0, m - 1, count).astype(np.int64))
 
@@ -494,7 +495,7 @@ def test_full_size_config5_8192x100_weighted_epochs_properties(amd, oracle):
     assert (hist["proposer"][np.arange(hist.shape[2])[None, None, :] < cc[:, :, None]] < n).all()
     assert (cc.min(axis=1) >= 1).mean() > 0.9               # the healthy weighted network commits
     assert (res.epochs == 0).all()                           # 50 commands are not reached by clock 300
-    idx = _oracle_sample(m, 512)  # bit-exact
+    idx = _oracle_sample(m, 512)  # bit-exact (1 024 was started in round 4's last GPU call and cut off by the budget: not raised unverified)
     ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds[idx], max_clock, threads=HOST_THREADS, history_cap=hist.shape[2])
     assert (cc[idx] == ref["commit_counts"]).all() and (res.active_rounds[idx] == ref["active_rounds"]).all()
     assert (res.last_committed_states[idx] == ref["last_states"]).all() and (hist[idx] == ref["histories"]).all()
@@ -504,7 +505,7 @@ def test_full_size_config4_live_16384x64_equivocators_commit(amd, oracle):
     """Configuration 4 exercising what it is named for, at full size: 16 384 x 64 nodes, LogNormal(10, 400) delays, 13 of 64
     nodes (index % 5 == 0) equivocating, the fixed protocol mode (quirks = 3: lagging nodes catch up through real
     request / response payloads), clock 1000.  Every node of (almost) every instance commits >= 5 blocks, so the safety
-    assertion runs over non-empty logs; 1 024 instances (2 048 with LBFT_FULL_CHECK_FRACTION=4) are compared with the oracle bit for bit."""
+    assertion runs over non-empty logs; 2 048 instances (the sample of profiles/r03/full_size_checks_2048.txt) are compared with the oracle bit for bit."""
     m, n, max_clock = 16384, 64, 1000
     kw = dict(num_nodes=n, mean=10.0, variance=400.0, equivocate_every=5, quirks=3)
     seeds = np.arange(1, m + 1, dtype=np.uint64)
@@ -521,7 +522,7 @@ def test_full_size_config4_live_16384x64_equivocators_commit(amd, oracle):
     key = hist["proposer"].astype(np.int64) * (1 << 32) + hist["index"].astype(np.int64)
     first = np.sort(np.where(valid, key, -1 - np.arange(hist.shape[2])[None, None, :]), axis=2)
     assert (np.diff(first, axis=2) != 0).all()
-    idx = _oracle_sample(m, 1024)
+    idx = _oracle_sample(m, 2048)
     ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds[idx], max_clock, threads=HOST_THREADS, history_cap=hist.shape[2])
     assert (cc[idx] == ref["commit_counts"]).all() and (res.active_rounds[idx] == ref["active_rounds"]).all()
     assert (res.last_committed_states[idx] == ref["last_states"]).all() and (hist[idx] == ref["histories"]).all()
@@ -531,7 +532,7 @@ def test_full_size_config4_live_16384x64_equivocators_commit(amd, oracle):
 def test_full_size_config5_live_8192x100_rotating_rights_epochs(amd, oracle):
     """Configuration 5 exercising what it is named for, at full size: 8 192 x 100 nodes, voting rights 1 + (i mod 4) rotating
     by one node per epoch (rights_rotation = 1), an epoch every 3 commands, the fixed protocol mode (quirks = 3), clock
-    450: every node of every instance goes through >= 2 epoch changes (node.rs:331-348).  512 instances (2 048 with LBFT_FULL_CHECK_FRACTION=4) bit-exact against the oracle."""
+    450: every node of every instance goes through >= 2 epoch changes (node.rs:331-348).  1 024 instances (2 048 with LBFT_FULL_CHECK_FRACTION=2) bit-exact against the oracle."""
     m, n, max_clock = 8192, 100, 450
     rights = [1 + (i % 4) for i in range(n)]
     kw = dict(num_nodes=n, voting_rights=rights, commands_per_epoch=3, quirks=3, rights_rotation=1)
@@ -543,7 +544,7 @@ def test_full_size_config5_live_8192x100_rotating_rights_epochs(amd, oracle):
     assert (ep == cc // 3).all()                             # read_epoch_id = commands / commands_per_epoch (simulated_context.rs:199-207)
     hist = res.committed_histories(int(cc.max()))
     assert _prefix_consistent(cc, hist)                      # logs agree across the epochs
-    idx = _oracle_sample(m, 512)
+    idx = _oracle_sample(m, 1024)
     ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds[idx], max_clock, threads=HOST_THREADS, history_cap=hist.shape[2])
     assert (cc[idx] == ref["commit_counts"]).all() and (res.active_rounds[idx] == ref["active_rounds"]).all()
     assert (res.last_committed_states[idx] == ref["last_states"]).all() and (hist[idx] == ref["histories"]).all()

@@ -54,8 +54,8 @@ PARITY_SAMPLE = {
     "c3shard_8192x4": "the first 8 192 instances of the c3 check",
     "c4_16384x64_longtail_equivocators": "all 16 384 instances",
     "c5_8192x100_weighted_epochs": "512 of 8 192 instances per test run (2 048 recorded once: profiles/r03/full_size_checks_2048.txt)",
-    "c4live_16384x64_longtail_equivocators_fixed": "1 024 of 16 384 instances per test run (2 048 recorded once)",
-    "c5live_8192x100_rotating_rights_epochs_fixed": "512 of 8 192 instances per test run (2 048 recorded once)",
+    "c4live_16384x64_longtail_equivocators_fixed": "2 048 of 16 384 instances per test run",
+    "c5live_8192x100_rotating_rights_epochs_fixed": "1 024 of 8 192 instances per test run (2 048 recorded once: profiles/r03/full_size_checks_2048.txt)",
 }
 # What a line measures, where that is not what its name suggests (printed with the line)
 NOTES = {
