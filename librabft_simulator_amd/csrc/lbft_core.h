@@ -72,6 +72,13 @@ typedef int64_t i64;
 #ifndef LBFT_BLK_CACHE_LEAN2
 #define LBFT_BLK_CACHE_LEAN2 1
 #endif
+// (opt-in build, round 4, UNMEASURED) the two-wavefront large-network kernels keep the event's node -- its 41 fixed words -- in a lane-private
+// LDS column instead of registers: with one cached block record and without the staged author sets lbft_k_run2l / lbft_k_run2q then fit 168
+// registers with 24 / 44 spilled dwords (104 / 124 without; tools/kernel_regs.py), i.e. THREE wavefronts per SIMD for kernels that spend 58-67 %
+// of their cycles waiting for memory.  Built as liblbft_hip_w3.so (tools/gpu_w3_ab.sh); the product library is compiled without it.
+#ifndef LBFT_LEAN_NODE_LDS
+#define LBFT_LEAN_NODE_LDS 0
+#endif
 #ifndef LBFT_BLK_CACHE_LEAN5
 #define LBFT_BLK_CACHE_LEAN5 3  // lbft_k_run2l (SimT<5>): three records fit since the scalar / record accesses stopped holding a register per field
                                 // (round 4: 22 spilled registers; c4 354.6 -> 351.6 ms, c5 1.931 -> 1.897 s; two records 386 ms / 2.12 s; the kernel with
@@ -692,8 +699,12 @@ struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at
 // sim_class() picks the class a batch runs with.
 //   5  class 2 without the record exchange of quirks bit 0, the round-switch trace and the lossy network (sim_lean()): the
 //      plain large-network path fits 256 registers (21 spilled) and runs two wavefronts per SIMD with half the lanes each
+// (LBFT_LEAN_NODE_LDS) the LDS column of the event's node: members of the classes that use it only -- an empty base elsewhere, so that every other
+// class keeps its layout (and the product library its machine code)
+template <bool ON> struct NodeCacheLds { };
+template <> struct NodeCacheLds<true> { u32* cwl = nullptr; };
 template <int CLS>
-struct SimT {
+struct SimT : NodeCacheLds<(CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0> {
   static constexpr bool LEAN2 = CLS == 5 || CLS == 7;  // 7 = 5 plus the record exchange of quirks bit 0 (24 spilled registers; a kernel of its own: with
                                                        // that code compiled in, the runs without it lose 10 %)
   static constexpr bool BIG = CLS == 2 || LEAN2;       // multi-word node / author sets
@@ -956,6 +967,18 @@ struct SimT {
   // reorder row loads across row stores) and the modified ones are written back by end_node().
   // `f` is a compile-time constant at every call site, so cw[] lives in VGPRs.
   mutable u32 cw[NF_FIXED_WORDS];
+  // ... or (LBFT_LEAN_NODE_LDS, the two-wavefront large-network kernels) in this lane's LDS column: word f at cwl[f << CWSH]
+  static constexpr bool CWLDS = LEAN2 && LBFT_LEAN_NODE_LDS != 0;  // (cwl: NodeCacheLds<true>)
+  // the columns of a wavefront are 32 words apart whatever its lanes per wavefront: a compile-time stride makes word f an immediate offset of ONE
+  // address (with the stride in a register the compiler keeps `f << stride` for every f it meets: 40 registers, the spills this is here to remove)
+#if defined(__HIP_DEVICE_COMPILE__)
+  static constexpr u32 CWSH = 5;
+#else
+  static constexpr u32 CWSH = 0;  // (the host model passes one plain array per network)
+#endif
+  LBFT_HD void attach_node_cache(u32* column) { if constexpr (CWLDS) this->cwl = column; else (void)column; }
+  LBFT_HD u32 cwg(u32 f) const { if constexpr (CWLDS) return this->cwl[f << CWSH]; else return cw[f]; }
+  LBFT_HD void cws(u32 f, u32 v) const { if constexpr (CWLDS) this->cwl[f << CWSH] = v; else cw[f] = v; }
   // rows are written back by groups of fields that change together: 6 tests instead of 41 (A/B on the 65536 x 4 batch in one GPU call:
   // 24.6 ms vs 25.1 ms per row; writing all rows unconditionally had measured 9 % slower).  cdirty holds one bit per GROUP.
   static constexpr u32 NGROUPS = 6;
@@ -975,9 +998,9 @@ struct SimT {
   static_assert(NF_FIXED_WORDS == 41 && (group_mask(0) | group_mask(1) | group_mask(2) | group_mask(3) | group_mask(4) | group_mask(5)) == (1ULL << 41) - 1,
                 "every fixed word belongs to a write-back group");
   mutable u32 cdirty;
-  LBFT_HD u32 nf(u32 node, u32 f) const { return f < NF_FIXED_WORDS ? cw[f] : ld(nfw(node, f)); }
+  LBFT_HD u32 nf(u32 node, u32 f) const { return f < NF_FIXED_WORDS ? cwg(f) : ld(nfw(node, f)); }
   LBFT_HD void nfs(u32 node, u32 f, u32 v) const {
-    if (f < NF_FIXED_WORDS) { cw[f] = v; if (!(C0I && LBFT_WB_ALL)) cdirty |= 1u << group_of(f); }
+    if (f < NF_FIXED_WORDS) { cws(f, v); if (!(C0I && LBFT_WB_ALL)) cdirty |= 1u << group_of(f); }
     else st(nfw(node, f), v);
   }
   LBFT_HD void begin_node(u32 node) const {
@@ -986,7 +1009,7 @@ struct SimT {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (u32 f = 0; f < NF_FIXED_WORDS; f++) cw[f] = ldf(nb, f);
+    for (u32 f = 0; f < NF_FIXED_WORDS; f++) cws(f, ldf(nb, f));
     cdirty = 0;
     hc_load(nb);
     ax_load(node);
@@ -1000,7 +1023,7 @@ struct SimT {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-      for (u32 f = 0; f < NF_FIXED_WORDS; f++) stf(nb, f, cw[f]);
+      for (u32 f = 0; f < NF_FIXED_WORDS; f++) stf(nb, f, cwg(f));
       return;
     }
     hc_store(nb);
@@ -1013,7 +1036,7 @@ struct SimT {
 #pragma unroll
 #endif
         for (u32 f = 0; f < NF_FIXED_WORDS; f++)
-          if ((group_mask(g) >> f) & 1ULL) stf(nb, f, cw[f]);
+          if ((group_mask(g) >> f) & 1ULL) stf(nb, f, cwg(f));
       }
   }
   LBFT_HD u32 bfw(u32 b, u32 f) const { return OFFBLK() + (b - 1) * BWORDS() + f; }
@@ -2203,7 +2226,7 @@ struct SimT {
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (u32 f = 0; f < NF_FIXED_WORDS; f++) st(base + f, cw[f]);
+    for (u32 f = 0; f < NF_FIXED_WORDS; f++) st(base + f, cwg(f));
     ax_store(node);
     axdirty = 0;
     const u32 row = nfw(node, NF_FIXED_WORDS), tail = P.rarch_words - NF_FIXED_WORDS;

@@ -89,6 +89,14 @@ static inline size_t run_lds_bytes(u32 ql, u32 lpw, u32 n, u32 slot_bytes, u32 n
 __device__ __forceinline__ size_t run_lds_bytes_dev(u32 ql, u32 lpw, u32 slot_bytes, u32 nwaves) {  // = run_lds_bytes(ql, lpw, 0, ..): where the receiver lists start
   return (size_t)LBFT_TABLE_U64 * 8 + (size_t)nwaves * (ql + LBFT_QPAD(slot_bytes)) * lpw * slot_bytes + (size_t)nwaves * LBFT_NPHASES * 8 + 8;
 }
+// (opt-in builds, round 4, UNMEASURED: liblbft_hip_w3.so = -DLBFT_LEAN2_WAVES_PER_SIMD=3 -DLBFT_LEAN2_RUN_WAVES=12 -DLBFT_LEAN_NODE_LDS=1
+// -DLBFT_BLK_CACHE_LEAN5=1 -DLBFT_LEAN_AX=0) wavefronts per SIMD / per workgroup of the two large-network kernels lbft_k_run2l / lbft_k_run2q
+#ifndef LBFT_LEAN2_WAVES_PER_SIMD
+#define LBFT_LEAN2_WAVES_PER_SIMD 2
+#endif
+#ifndef LBFT_LEAN2_RUN_WAVES
+#define LBFT_LEAN2_RUN_WAVES LBFT_RUN_WAVES
+#endif
 #ifndef LBFT_RUN_WAVES_PER_SIMD
 #define LBFT_RUN_WAVES_PER_SIMD 2  // register budget of the class-0 run kernel: 512 / 2 = 256 VGPRs + AGPRs per lane (the
                                    // large-network classes run one 8- or 16-lane wavefront per SIMD and may use all 512)
@@ -132,7 +140,19 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
     // cooperate on the bulk sends of those networks (SimT::run_coop / coop_bulk).
     // (tw may be narrower than the lanes that carry a network: lane j's instance then sits j / tw tiles behind the wavefront's
     // first tile -- folded into the lane's 32-bit column offset, the tile base stays wavefront-uniform)
-    const u32 li = active ? (i - ((blockIdx.x * nwaves + wave) * p.lpw)) : (lane & (p.lpw - 1u));
+#if LBFT_LEAN2_WAVES_PER_SIMD != 2
+    // (three wavefronts per SIMD: 3 072 resident wavefronts make the natural lanes per wavefront a non-power of two -- 16 384 networks: 6 --;
+    // LDS columns are then strided by the next power of two, and a lane that carries no network borrows a valid column)
+    u32 lpwp_ = 1;
+    while (lpwp_ < p.lpw) lpwp_ <<= 1;
+    const u32 lcol_ = lane < p.lpw ? lane : lane % p.lpw;
+#define LBFT_LPWP lpwp_
+#define LBFT_LCOL lcol_
+#else
+#define LBFT_LPWP p.lpw                      /* (the product build: textually the expressions it always had -- its machine code is the profiled one) */
+#define LBFT_LCOL (lane & (p.lpw - 1u))
+#endif
+    const u32 li = active ? (i - ((blockIdx.x * nwaves + wave) * p.lpw)) : LBFT_LCOL;
     SimT<CLS> s(p, tile, (li / tw) * (p.total_words * 4u * tw) + (li & (tw - 1u)) * 4u, 0);
     bool lead = false;
     if (active) lead = s.ld(I_DONE) == 0;
@@ -142,11 +162,16 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
     s.attach_weights(t_weights);
     {  // [receiver lists: nwaves * lpw * LBFT_MAX_NODES bytes][block-record windows: lane-private columns per wavefront]
       u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 12u, nwaves);
-      u32* win = reinterpret_cast<u32*>(lists + (size_t)nwaves * p.lpw * LBFT_MAX_NODES) + (size_t)wave * p.lpw * p.blw * (1u + BC_WORDS);
+      u32* win = reinterpret_cast<u32*>(lists + (size_t)nwaves * p.lpw * LBFT_MAX_NODES) + (size_t)wave * LBFT_LPWP * p.blw * (1u + BC_WORDS);
       u32 wsh = 0;
       while ((1u << wsh) < p.lpw) wsh++;
-      s.attach_blk_window(win + (lane & (p.lpw - 1u)), p.blw, wsh);
+      s.attach_blk_window(win + LBFT_LCOL, p.blw, wsh);
       if (lane < p.lpw) s.blw_reset();
+      if constexpr (SimT<CLS>::CWLDS) {  // [.. windows][the event's node: NF_FIXED_WORDS words per network, lane-private columns per wavefront]
+        u32* nc = reinterpret_cast<u32*>(lists + (size_t)nwaves * p.lpw * LBFT_MAX_NODES) + (size_t)nwaves * LBFT_LPWP * p.blw * (1u + BC_WORDS) +
+                  (size_t)wave * 32u * NF_FIXED_WORDS;  // (columns 32 words apart: SimT::CWSH)
+        s.attach_node_cache(nc + LBFT_LCOL);
+      }
     }
     if (lead) {
       u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 12u, nwaves);
@@ -327,10 +352,10 @@ __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(
 void lbft_k_run0u(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(12) run_body<12>(p, state, unfinished); }
 #endif
 // Large networks without record exchange / trace / lossy network (sim_lean()): also two wavefronts per SIMD (4 spilled registers)
-__global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
+__global__ __launch_bounds__(64 * LBFT_LEAN2_RUN_WAVES) __attribute__((amdgpu_waves_per_eu(LBFT_LEAN2_WAVES_PER_SIMD, LBFT_LEAN2_WAVES_PER_SIMD)))
 void lbft_k_run2l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(5) run_body<5>(p, state, unfinished); }
 // ... and with the record exchange of quirks bit 0 (sim_lean_q1(): requests answered by the peer, responses inserted): 24 spilled registers
-__global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
+__global__ __launch_bounds__(64 * LBFT_LEAN2_RUN_WAVES) __attribute__((amdgpu_waves_per_eu(LBFT_LEAN2_WAVES_PER_SIMD, LBFT_LEAN2_WAVES_PER_SIMD)))
 void lbft_k_run2q(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(7) run_body<7>(p, state, unfinished); }
 // ... and class 1 without them (networks of <= 32 nodes with equivocators, a heap / calendar queue, ...): 22 spilled registers
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
@@ -1225,10 +1250,15 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
     // wavefront-step costs the union of its lanes' paths (65536 x 4 nodes, r01_s3 build: 27.0 ms at 64 lanes = one wavefront
     // per SIMD, 24.4 ms at 32 = two per SIMD, 40.1 ms at 16 = two rounds; 1024 x 4 nodes: 22.9 ms at 8 lanes, 17.6 at 4,
     // 13.2 at 2, 9.4 ms at ONE network per wavefront; 8192 x 100 nodes: 9.0 s at 16 lanes, 5.9 s at 8, 7.8 s at 4 = two rounds).
-    u64 resident = (sim_class(p) == 0 || (sim_lean(p) && lean2_allowed()) || (sim_lean1(p) && lean_allowed())) ? 2048 : 1024 * LBFT_BIG_WAVES_PER_SIMD;
+    const bool lean2k = sim_lean(p) && lean2_allowed();
+    u64 resident = lean2k ? 1024 * LBFT_LEAN2_WAVES_PER_SIMD : (sim_class(p) == 0 || (sim_lean1(p) && lean_allowed())) ? 2048 : 1024 * LBFT_BIG_WAVES_PER_SIMD;
     u64 want = (b->m + resident - 1) / resident;
     lpw = 1;
     while (lpw < want && lpw < 32) lpw <<= 1;
+#if LBFT_LEAN2_WAVES_PER_SIMD != 2
+    // (3 072 resident wavefronts: the fewest lanes that fit the batch are rarely a power of two; the calendar queue has no LDS columns to stride)
+    if (lean2k && p.qcal) lpw = want < 1 ? 1u : want > 32 ? 32u : (u32)want;
+#endif
   }
   p.lpw = lpw;
   // Tile width of the HBM layout (lbft_core.h "HBM layout"): 64 for the small-network classes 0 and 1, 1 (instance-major) for large networks
@@ -1248,7 +1278,7 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   // wavefronts per workgroup of the kernel this batch runs on: 8 = both wavefront slots of a CU's four SIMDs for the kernels compiled
   // for two wavefronts per SIMD, 4 for the full-register ones
   const bool two_wave_kernel = sim_class(p) == 0 || (sim_lean(p) && lean2_allowed()) || (sim_lean1(p) && lean_allowed());
-  const u32 nwaves = two_wave_kernel ? LBFT_RUN_WAVES : LBFT_RUN_WAVES_FULL;
+  const u32 nwaves = (sim_lean(p) && lean2_allowed()) ? LBFT_LEAN2_RUN_WAVES : two_wave_kernel ? LBFT_RUN_WAVES : LBFT_RUN_WAVES_FULL;
   b->run_waves = nwaves;
   // LDS queue slots per instance: what one CU's LDS affords when it hosts 64/lpw workgroups
   u32 wg_per_cu = (64 / lpw) * 4 / nwaves;  // workgroups that make up a CU's 256 instances
@@ -1257,7 +1287,7 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   // (the kernels compiled for two wavefronts per SIMD run as 8-wavefront workgroups: one of them fills a CU's wavefront slots at 256
   // registers per lane, so the whole LDS is that one workgroup's whatever its lanes per wavefront -- round 4: with the budget of two the
   // 16-lane form of lbft_k_run0q kept 24 queue slots in LDS and spilled the rest to HBM)
-  if (two_wave_kernel && nwaves == 8) wg_per_cu = 1;
+  if (two_wave_kernel && nwaves >= 8) wg_per_cu = 1;
   size_t budget = (160u * 1024u) / wg_per_cu;
   // 2 KiB slack per workgroup: with less, two workgroups of 32-lane wavefronts do not become co-resident on a CU
   u32 slot_bytes = p.qpack ? 8u : 12u;  // kernel class 0 keeps one-word entries
@@ -1279,12 +1309,16 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   p.blw = 0;
   // (measured, round 4: c4live 2.77 -> 2.76 s, c5live 4.72 -> 4.60 s with 32 entries, 4.58 s with 64; the kernel without the record exchange
   // LOSES with it -- c4 346 -> 357 ms, c5 1.90 -> 1.98 s, its three register records already serve it -- and does not get one)
+  u32 lpwp = 1;  // LDS columns per wavefront of the large-network kernels: lpw padded to a power of two (equal to it in the product build)
+  while (lpwp < lpw) lpwp <<= 1;
+  const size_t node_cache_bytes = (LBFT_LEAN_NODE_LDS && sim_lean(p) && lean2_allowed()) ? (size_t)nwaves * 32u * NF_FIXED_WORDS * 4u : 0;  // (columns 32 words apart: SimT::CWSH)
   if (sim_lean_q1(p) && lean2_allowed() && blk_window_allowed()) {
     u32 e = blk_window_max();
-    while (e && b->lds_bytes + blk_window_bytes(e, lpw, nwaves) > 150u * 1024u) e >>= 1;
+    while (e && b->lds_bytes + node_cache_bytes + blk_window_bytes(e, lpwp, nwaves) > 150u * 1024u) e >>= 1;
     p.blw = e;
-    b->lds_bytes += blk_window_bytes(e, lpw, nwaves);
+    b->lds_bytes += blk_window_bytes(e, lpwp, nwaves);
   }
+  b->lds_bytes += node_cache_bytes;  // (behind the windows: run_body)
   p.prof = b->d_prof;
   return LBFT_OK;
 }

@@ -159,6 +159,21 @@ def test_uniform_kernel_compiles_to_scalar_code(tmp_path):
     assert not any("lbft_k_run0u" in name for name in _kernel_metadata(build.OUT))
 
 
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"), reason="needs the ROCm LLVM binutils")
+def test_three_wavefront_variant_of_the_large_network_kernel_fits_its_registers(tmp_path):
+    """liblbft_hip_w3.so (opt-in build, round 4, unmeasured; tools/gpu_w3_ab.sh): lbft_k_run2l compiled for THREE wavefronts per SIMD with the event's
+    node in an LDS column, one cached block record and no staged author sets must stay near 28 spilled dwords at 168 registers (104 without the LDS
+    column; 64 when the column stride was a run-time value: one register per field)."""
+    import subprocess
+    from librabft_simulator_amd import build
+    out = str(tmp_path / "dev5_w3.so")
+    subprocess.check_call([build.hipcc_path()] + build.HIPCC_FLAGS + ["-DLBFT_DEV_ONLY_CLASS=5", "-DLBFT_LEAN2_WAVES_PER_SIMD=3", "-DLBFT_LEAN2_RUN_WAVES=12",
+                                                                      "-DLBFT_LEAN_NODE_LDS=1", "-DLBFT_BLK_CACHE_LEAN5=1", "-DLBFT_LEAN_AX=0", build.SRC, "-o", out],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    k = [v for name, v in _kernel_metadata(out).items() if "lbft_k_run2l" in name]
+    assert len(k) == 1 and k[0]["vgpr_count"] <= 168 and k[0]["private_segment_fixed_size"] <= 160, k
+
+
 def test_kernel_hash_reads_the_code_object(hiplib):
     """build.kernel_hash(): the stamp that ties profiles/current/pmc_traffic.json to the kernels bench.py runs (sha256 of the
     gfx950 machine code in the built library; parsed without binutils so that it works on the GPU box)."""
