@@ -1069,7 +1069,10 @@ struct SimT : NodeCacheLds<(CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0> {
     LBFT_HD u32 epoch() const { return w[B_EPOCH]; }
     LBFT_HD u32 depth() const { return w[B_DEPTH]; }
   };
-  static constexpr u32 BCN = CLS == 9 ? LBFT_BLK_CACHE_QUAD : CLS == 5 ? LBFT_BLK_CACHE_LEAN5 : LEAN2 ? LBFT_BLK_CACHE_LEAN2 : LBFT_BLK_CACHE;
+#ifndef LBFT_BLK_CACHE_UNI
+#define LBFT_BLK_CACHE_UNI LBFT_BLK_CACHE  // (lbft_k_run0u, opt-in build: its state lives in SGPRs / VGPR lanes -- fewer cached records, fewer v_readlane / v_writelane: to be measured)
+#endif
+  static constexpr u32 BCN = CLS == 9 ? LBFT_BLK_CACHE_QUAD : CLS == 12 ? LBFT_BLK_CACHE_UNI : CLS == 5 ? LBFT_BLK_CACHE_LEAN5 : LEAN2 ? LBFT_BLK_CACHE_LEAN2 : LBFT_BLK_CACHE;
   mutable u32 bc_id[BCN];
   mutable u32 bc_w[BCN][BC_WORDS];
   mutable u32 bc_next, bc_ref;  // FIFO hand (+ "recently used" bits of the second-chance variant, LBFT_BLK_PLAIN_FIFO=0)
