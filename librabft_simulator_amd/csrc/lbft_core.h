@@ -79,6 +79,12 @@ typedef int64_t i64;
 #ifndef LBFT_LEAN_NODE_LDS
 #define LBFT_LEAN_NODE_LDS 0
 #endif
+// ... and the same for the small-batch kernel lbft_k_run0s (opt-in build liblbft_hip_s4.so, round 4, UNMEASURED): with the node in LDS and one cached block
+// record it fits 128 registers with 28 spilled dwords (84 as shipped), i.e. FOUR wavefronts per SIMD with half the lanes each for batches of 2 049..16 384
+// networks -- 8 192 (one GPU's share of the headline batch on an 8-GPU node) as 4 096 wavefronts of 2 instead of 2 048 of 4 (tools/gpu_s4_ab.sh)
+#ifndef LBFT_SMALL_NODE_LDS
+#define LBFT_SMALL_NODE_LDS 0
+#endif
 #ifndef LBFT_BLK_CACHE_LEAN5
 #define LBFT_BLK_CACHE_LEAN5 3  // lbft_k_run2l (SimT<5>): three records fit since the scalar / record accesses stopped holding a register per field
                                 // (round 4: 22 spilled registers; c4 354.6 -> 351.6 ms, c5 1.931 -> 1.897 s; two records 386 ms / 2.12 s; the kernel with
@@ -704,7 +710,7 @@ struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at
 template <bool ON> struct NodeCacheLds { };
 template <> struct NodeCacheLds<true> { u32* cwl = nullptr; };
 template <int CLS>
-struct SimT : NodeCacheLds<(CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0> {
+struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) || (CLS == 8 && LBFT_SMALL_NODE_LDS != 0)> {
   static constexpr bool LEAN2 = CLS == 5 || CLS == 7;  // 7 = 5 plus the record exchange of quirks bit 0 (24 spilled registers; a kernel of its own: with
                                                        // that code compiled in, the runs without it lose 10 %)
   static constexpr bool BIG = CLS == 2 || LEAN2;       // multi-word node / author sets
@@ -968,7 +974,7 @@ struct SimT : NodeCacheLds<(CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0> {
   // `f` is a compile-time constant at every call site, so cw[] lives in VGPRs.
   mutable u32 cw[NF_FIXED_WORDS];
   // ... or (LBFT_LEAN_NODE_LDS, the two-wavefront large-network kernels) in this lane's LDS column: word f at cwl[f << CWSH]
-  static constexpr bool CWLDS = LEAN2 && LBFT_LEAN_NODE_LDS != 0;  // (cwl: NodeCacheLds<true>)
+  static constexpr bool CWLDS = (LEAN2 && LBFT_LEAN_NODE_LDS != 0) || (CLS == 8 && LBFT_SMALL_NODE_LDS != 0);  // (cwl: NodeCacheLds<true>)
   // the columns of a wavefront are 32 words apart whatever its lanes per wavefront: a compile-time stride makes word f an immediate offset of ONE
   // address (with the stride in a register the compiler keeps `f << stride` for every f it meets: 40 registers, the spills this is here to remove)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1072,7 +1078,10 @@ struct SimT : NodeCacheLds<(CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0> {
 #ifndef LBFT_BLK_CACHE_UNI
 #define LBFT_BLK_CACHE_UNI LBFT_BLK_CACHE  // (lbft_k_run0u, opt-in build: its state lives in SGPRs / VGPR lanes -- fewer cached records, fewer v_readlane / v_writelane: to be measured)
 #endif
-  static constexpr u32 BCN = CLS == 9 ? LBFT_BLK_CACHE_QUAD : CLS == 12 ? LBFT_BLK_CACHE_UNI : CLS == 5 ? LBFT_BLK_CACHE_LEAN5 : LEAN2 ? LBFT_BLK_CACHE_LEAN2 : LBFT_BLK_CACHE;
+#ifndef LBFT_BLK_CACHE_SMALL
+#define LBFT_BLK_CACHE_SMALL LBFT_BLK_CACHE  // (lbft_k_run0s; the four-wavefront build uses 1)
+#endif
+  static constexpr u32 BCN = CLS == 9 ? LBFT_BLK_CACHE_QUAD : CLS == 12 ? LBFT_BLK_CACHE_UNI : CLS == 8 ? LBFT_BLK_CACHE_SMALL : CLS == 5 ? LBFT_BLK_CACHE_LEAN5 : LEAN2 ? LBFT_BLK_CACHE_LEAN2 : LBFT_BLK_CACHE;
   mutable u32 bc_id[BCN];
   mutable u32 bc_w[BCN][BC_WORDS];
   mutable u32 bc_next, bc_ref;  // FIFO hand (+ "recently used" bits of the second-chance variant, LBFT_BLK_PLAIN_FIFO=0)

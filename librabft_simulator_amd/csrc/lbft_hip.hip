@@ -97,6 +97,14 @@ __device__ __forceinline__ size_t run_lds_bytes_dev(u32 ql, u32 lpw, u32 slot_by
 #ifndef LBFT_LEAN2_RUN_WAVES
 #define LBFT_LEAN2_RUN_WAVES LBFT_RUN_WAVES
 #endif
+// ... and of the small-batch kernel lbft_k_run0s (opt-in build liblbft_hip_s4.so = -DLBFT_SMALL_WAVES_PER_SIMD=4 -DLBFT_SMALL_RUN_WAVES=16 -DLBFT_SMALL_NODE_LDS=1
+// -DLBFT_BLK_CACHE_SMALL=1: batches of 2 049..16 384 networks spread over 4 096 wavefronts)
+#ifndef LBFT_SMALL_WAVES_PER_SIMD
+#define LBFT_SMALL_WAVES_PER_SIMD 2
+#endif
+#ifndef LBFT_SMALL_RUN_WAVES
+#define LBFT_SMALL_RUN_WAVES LBFT_RUN_WAVES
+#endif
 #ifndef LBFT_RUN_WAVES_PER_SIMD
 #define LBFT_RUN_WAVES_PER_SIMD 2  // register budget of the class-0 run kernel: 512 / 2 = 256 VGPRs + AGPRs per lane (the
                                    // large-network classes run one 8- or 16-lane wavefront per SIMD and may use all 512)
@@ -258,6 +266,11 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
       u32* hcb = reinterpret_cast<u32*>(reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 8u, nwaves));
       s.attach_hcbr(hcb + (size_t)wave * LBFT_LDS_HCBR_WORDS * p.lpw + lane);
     }
+    if constexpr (SimT<CLS>::CWLDS) {  // [.. hcbr buffers (n <= 4)][the event's node: lane-private columns per wavefront, 32 words apart (SimT::CWSH)]
+      u32* nc = reinterpret_cast<u32*>(reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 8u, nwaves)) +
+                (p.n <= 4 ? (size_t)nwaves * LBFT_LDS_HCBR_WORDS * p.lpw : 0) + (size_t)wave * 32u * NF_FIXED_WORDS;
+      s.attach_node_cache(nc + (lane & 31u));
+    }
     s.qlen = 0;
     if (lead) {
       s.load_scalars();
@@ -343,7 +356,7 @@ void lbft_k_run0(Params p, u32* __restrict__ state, u32* __restrict__ unfinished
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run0q(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(9) run_body<9>(p, state, unfinished); }
 // ... and for small batches (at most LBFT_POPC_MAX_LPW networks per wavefront): the pop's scan by all 64 lanes (SimT<8>)
-__global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
+__global__ __launch_bounds__(64 * LBFT_SMALL_RUN_WAVES) __attribute__((amdgpu_waves_per_eu(LBFT_SMALL_WAVES_PER_SIMD, LBFT_SMALL_WAVES_PER_SIMD)))
 void lbft_k_run0s(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(8) run_body<8>(p, state, unfinished); }
 // ... and for ONE network per wavefront, as wavefront-uniform code on the scalar unit (SimT<12>; opt-in: LBFT_UNI=1 -- built in round 4 without GPU
 // time left to measure it: bit-exactness and timing are the first call of round 5)
@@ -1259,6 +1272,14 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
     // (3 072 resident wavefronts: the fewest lanes that fit the batch are rarely a power of two; the calendar queue has no LDS columns to stride)
     if (lean2k && p.qcal) lpw = want < 1 ? 1u : want > 32 ? 32u : (u32)want;
 #endif
+#if LBFT_SMALL_WAVES_PER_SIMD != 2
+    // (the small-batch kernel compiled for more wavefronts per SIMD: batches that fit its residency with at most 4 lanes per wavefront are spread over it)
+    if (sim_class(p) == 0 && LBFT_C0_POPC && !LBFT_C0_QLANE && b->m <= 1024ull * LBFT_SMALL_WAVES_PER_SIMD * 4ull) {
+      u64 want_s = (b->m + 1024ull * LBFT_SMALL_WAVES_PER_SIMD - 1) / (1024ull * LBFT_SMALL_WAVES_PER_SIMD);
+      lpw = 1;
+      while (lpw < want_s) lpw <<= 1;
+    }
+#endif
   }
   p.lpw = lpw;
   // Tile width of the HBM layout (lbft_core.h "HBM layout"): 64 for the small-network classes 0 and 1, 1 (instance-major) for large networks
@@ -1278,7 +1299,7 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   // wavefronts per workgroup of the kernel this batch runs on: 8 = both wavefront slots of a CU's four SIMDs for the kernels compiled
   // for two wavefronts per SIMD, 4 for the full-register ones
   const bool two_wave_kernel = sim_class(p) == 0 || (sim_lean(p) && lean2_allowed()) || (sim_lean1(p) && lean_allowed());
-  const u32 nwaves = (sim_lean(p) && lean2_allowed()) ? LBFT_LEAN2_RUN_WAVES : two_wave_kernel ? LBFT_RUN_WAVES : LBFT_RUN_WAVES_FULL;
+  const u32 nwaves = (sim_lean(p) && lean2_allowed()) ? LBFT_LEAN2_RUN_WAVES : small_batch_kernel(p) ? LBFT_SMALL_RUN_WAVES : two_wave_kernel ? LBFT_RUN_WAVES : LBFT_RUN_WAVES_FULL;
   b->run_waves = nwaves;
   // LDS queue slots per instance: what one CU's LDS affords when it hosts 64/lpw workgroups
   u32 wg_per_cu = (64 / lpw) * 4 / nwaves;  // workgroups that make up a CU's 256 instances
@@ -1319,6 +1340,7 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
     b->lds_bytes += blk_window_bytes(e, lpwp, nwaves);
   }
   b->lds_bytes += node_cache_bytes;  // (behind the windows: run_body)
+  if (LBFT_SMALL_NODE_LDS && small_batch_kernel(p)) b->lds_bytes += (size_t)nwaves * 32u * NF_FIXED_WORDS * 4u;  // (behind the hcbr buffers: run_body)
   p.prof = b->d_prof;
   return LBFT_OK;
 }

@@ -22,7 +22,7 @@ def one(out):
     res = sim.loop_until(1000)
     c = res.counters
     # the same batch advanced in bounded launches (137 events per instance and launch) must end in the same state
-    sim2 = BatchSimulator.new(seeds[:8192], 4, RandomDelay.new(10.0, 4.0), lanes_per_wavefront=32)
+    sim2 = BatchSimulator.new(seeds[:8192], 4, RandomDelay.new(10.0, 4.0), lanes_per_wavefront=int(os.environ.get("LPW2", "32")))  # (LPW2=0: the batch's own kernel)
     r2 = None
     for _ in range(100):
         left, r2 = sim2.run_steps(1000, 137)
