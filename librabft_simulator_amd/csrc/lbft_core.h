@@ -80,7 +80,7 @@ typedef int64_t i64;
 #define LBFT_LEAN_NODE_LDS 0
 #endif
 // ... and the same for the small-batch kernel lbft_k_run0s (opt-in build liblbft_hip_s4.so, round 4, UNMEASURED): with the node in LDS and one cached block
-// record it fits 128 registers with 28 spilled dwords (84 as shipped), i.e. FOUR wavefronts per SIMD with half the lanes each for batches of 2 049..16 384
+// record it fits 128 registers with 28 spilled dwords (84 as shipped), i.e. FOUR wavefronts per SIMD with half the lanes each for batches of 2 049..32 768
 // networks -- 8 192 (one GPU's share of the headline batch on an 8-GPU node) as 4 096 wavefronts of 2 instead of 2 048 of 4 (tools/gpu_s4_ab.sh)
 #ifndef LBFT_SMALL_NODE_LDS
 #define LBFT_SMALL_NODE_LDS 0

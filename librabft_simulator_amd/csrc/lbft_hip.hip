@@ -98,7 +98,7 @@ __device__ __forceinline__ size_t run_lds_bytes_dev(u32 ql, u32 lpw, u32 slot_by
 #define LBFT_LEAN2_RUN_WAVES LBFT_RUN_WAVES
 #endif
 // ... and of the small-batch kernel lbft_k_run0s (opt-in build liblbft_hip_s4.so = -DLBFT_SMALL_WAVES_PER_SIMD=4 -DLBFT_SMALL_RUN_WAVES=16 -DLBFT_SMALL_NODE_LDS=1
-// -DLBFT_BLK_CACHE_SMALL=1: batches of 2 049..16 384 networks spread over 4 096 wavefronts)
+// -DLBFT_BLK_CACHE_SMALL=1: batches of 2 049..32 768 networks spread over 4 096 wavefronts)
 #ifndef LBFT_SMALL_WAVES_PER_SIMD
 #define LBFT_SMALL_WAVES_PER_SIMD 2
 #endif
@@ -1273,8 +1273,8 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
     if (lean2k && p.qcal) lpw = want < 1 ? 1u : want > 32 ? 32u : (u32)want;
 #endif
 #if LBFT_SMALL_WAVES_PER_SIMD != 2
-    // (the small-batch kernel compiled for more wavefronts per SIMD: batches that fit its residency with at most 4 lanes per wavefront are spread over it)
-    if (sim_class(p) == 0 && LBFT_C0_POPC && !LBFT_C0_QLANE && b->m <= 1024ull * LBFT_SMALL_WAVES_PER_SIMD * 4ull) {
+    // (the small-batch kernel compiled for more wavefronts per SIMD: batches that fit its residency within its lanes per wavefront are spread over it)
+    if (sim_class(p) == 0 && LBFT_C0_POPC && !LBFT_C0_QLANE && b->m <= 1024ull * LBFT_SMALL_WAVES_PER_SIMD * LBFT_POPC_MAX_LPW) {
       u64 want_s = (b->m + 1024ull * LBFT_SMALL_WAVES_PER_SIMD - 1) / (1024ull * LBFT_SMALL_WAVES_PER_SIMD);
       lpw = 1;
       while (lpw < want_s) lpw <<= 1;
@@ -1316,14 +1316,16 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   const bool quadk = quad_kernel(p);  // (the kernel choice only depends on the layout and lpw)
   const bool hcbr_lds = !(LBFT_C0_IMAJOR && LBFT_C0_HCREG && quadk);
   const u32 qcols = (quadk && LBFT_QUAD_STRIDE32) ? 32u : lpw;  // queue columns per wavefront in LDS (SimT::QS32)
-  u32 ql_auto = (u32)((budget - run_lds_bytes(0, qcols, n, slot_bytes, nwaves, hcbr_lds) - 2048) / (slot_bytes * nwaves * qcols));  // (run_lds_bytes(0, ..) includes the lane padding)
+  // (opt-in four-wavefront build of the small-batch kernel: the LDS columns of the event's node come out of the queue's budget)
+  const size_t small_nc_bytes = (LBFT_SMALL_NODE_LDS && small_batch_kernel(p)) ? (size_t)nwaves * 32u * NF_FIXED_WORDS * 4u : 0;
+  u32 ql_auto = (u32)((budget - small_nc_bytes - run_lds_bytes(0, qcols, n, slot_bytes, nwaves, hcbr_lds) - 2048) / (slot_bytes * nwaves * qcols));  // (run_lds_bytes(0, ..) includes the lane padding)
   const u32 ql_max = quadk ? LBFT_PACKED_QL_QUAD : LBFT_PACKED_QL_MAX, pop_batch = quadk ? LBFT_POP_BATCH_QUAD : LBFT_POP_BATCH;
   if (p.qpack && ql_auto > ql_max) ql_auto = ql_max;
   u32 ql = b->ql < 0 ? ql_auto : (u32)b->ql;
   if (ql > qcap) ql = qcap;
   if (p.qpack) ql -= ql % pop_batch;  // scanned in batches (SimT::PB)
   if (p.qcal) ql = 0;  // the calendar lives in HBM rows
-  if (run_lds_bytes(ql, qcols, n, slot_bytes, nwaves, hcbr_lds) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
+  if (run_lds_bytes(ql, qcols, n, slot_bytes, nwaves, hcbr_lds) + small_nc_bytes > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
   p.ql = ql;
   b->lds_bytes = run_lds_bytes(ql, qcols, n, slot_bytes, nwaves, hcbr_lds);
   // large networks: the LDS that the calendar queue leaves unused holds a window of block records per network (SimT::attach_blk_window)
@@ -1340,7 +1342,7 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
     b->lds_bytes += blk_window_bytes(e, lpwp, nwaves);
   }
   b->lds_bytes += node_cache_bytes;  // (behind the windows: run_body)
-  if (LBFT_SMALL_NODE_LDS && small_batch_kernel(p)) b->lds_bytes += (size_t)nwaves * 32u * NF_FIXED_WORDS * 4u;  // (behind the hcbr buffers: run_body)
+  b->lds_bytes += small_nc_bytes;  // (behind the hcbr buffers: run_body)
   p.prof = b->d_prof;
   return LBFT_OK;
 }
