@@ -25,7 +25,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (default: the launcher's WORLD_SIZE, else 1); without a launcher `--gpus N` starts N ranks itself")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--instances", type=int, default=65536, help="instances per GPU (weak scaling: the default mode)")
@@ -40,6 +41,9 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses HIP device 0")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the oracle sample")
+    ap.add_argument("--measure-traffic", action="store_true",
+                    help="(N = 1, rocprofv3 on the box) re-collect FETCH_SIZE / WRITE_SIZE of the run kernel in two child runs of this command and report "
+                         "them as roofline.traffic_measured_here beside the value replayed from the committed profile")
     ap.add_argument("--native-collective", action="store_true",
                     help="also aggregate the counters through the C ABI's own collective (lbft_batch_counters_allreduce: ncclAllGather on a "
                          "communicator built with ncclCommInitRank, one device per rank) and check it against the torch.distributed aggregate")
@@ -47,16 +51,53 @@ def parse():
 
 
 def self_launch(args):
-    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run with N ranks on this node."""
-    import socket
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run with N ranks on this node.  `--standalone` lets the
+    launcher pick its own free rendezvous port (no bind-close-reuse race here); `--local-addr 127.0.0.1` because the container's hostname may not
+    resolve.  HSA_ENABLE_IPC_MODE_LEGACY=0 is only set when the caller's environment has no opinion: the host driver of this pool supports dmabuf IPC
+    only, and without it RCCL's buffer exchange between the ranks fails with `hipIpcGetMemHandle: invalid argument`."""
     import subprocess
-    with socket.socket() as sk:  # a free rendezvous port
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
+
+
+def traffic_measured_here(argv):
+    """--measure-traffic: FETCH_SIZE and WRITE_SIZE of the run kernel collected NOW, each in its own rocprofv3 child run of this command
+    (--kernel-trace only, as gpurun requires) -- per launch, with MI355X_MICROARCH.md's gfx950 correction (FETCH_SIZE counts a 128-byte
+    request as 64 bytes: doubled).  None when rocprofv3 is not on the box or a pass fails."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if not prof:
+        return {"error": "rocprofv3 not found"}
+    child = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--measure-traffic"] + ["--no-cpu-baseline", "--parity-instances", "0"]
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="lbft_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([prof, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--output-format", "csv", "--"] + child,
+                               env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp", capture_output=True, text=True, timeout=600)
+            per = collections.defaultdict(float)
+            for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if "lbft_k_run" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                            per[row["Dispatch_Id"]] += float(row["Counter_Value"])
+            if r.returncode != 0 or not per:
+                return {"error": "%s pass failed (rc %d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-300:])}
+            vals[counter] = sum(per.values()) / len(per)
+        except Exception as e:  # noqa: BLE001 -- a profiler hiccup must not cost the bench line
+            return {"error": "%s pass: %r" % (counter, e)}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"fetch_kb_raw": vals["FETCH_SIZE"], "write_kb_raw": vals["WRITE_SIZE"], "gb_corrected": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / 1e9,
+            "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, one child run each"}
 
 
 def algorithmic_bytes_per_event(layout, counters):
@@ -228,7 +269,7 @@ def run_kernel_name(kc):
     """The run kernel a batch executes, from lbft_batch_layout's flag word (include/lbft.h)."""
     cls = kc & 255
     if cls == 0:
-        return "lbft_k_run0s" if kc & 8192 else "lbft_k_run0q" if kc & 16384 else "lbft_k_run0"
+        return "lbft_k_run0u" if kc & 32768 else "lbft_k_run0s" if kc & 8192 else "lbft_k_run0q" if kc & 16384 else "lbft_k_run0"
     if kc & 1024:  # the two-wavefronts-per-SIMD kernels
         return ("lbft_k_run2q" if kc & 4096 else "lbft_k_run2l") if cls == 2 else "lbft_k_run1l"
     return "lbft_k_run<%d>" % cls
@@ -238,11 +279,14 @@ def main():
     args = parse()
     import numpy as np
     import torch
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    under_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ  # (a scheduler that merely exports WORLD_SIZE is not one)
+    if args.gpus is None:  # left at its default: adopt the launcher's size (`torchrun --nproc-per-node N bench.py` with no --gpus)
+        args.gpus = int(os.environ["WORLD_SIZE"]) if under_launcher else 1
+    if args.gpus > 1 and not under_launcher:
         sys.exit(self_launch(args))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0")) if under_launcher else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if under_launcher else 0
+    world = int(os.environ.get("WORLD_SIZE", "1")) if under_launcher else 1
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); start it as `python bench.py --gpus N` "
                          "or under torch.distributed.run --nproc-per-node N with the same N" % (args.gpus, world))
@@ -339,6 +383,11 @@ def main():
             # SURVEY 8(d) figure charged to every reference-equivalent event stands beside it as `frac_reference_equivalent`.
             "roofline": {"bound": "hbm", "achieved": achieved_ex, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_ex / HBM_PEAK_GBS,
                          "traffic": traffic["gb_corrected"] if traffic else None, "traffic_unit": "GB per launch",
+                         # where `traffic` comes from: PMC counters cannot be read from inside this process, so the line REPLAYS the committed
+                         # profile of the same kernels (stamped with the hash of their machine code; null when the stamp is stale)
+                         "traffic_source": ("committed profile %s (kernel hash %s): replayed, not measured in this run" % (traffic.get("profile"), traffic.get("source_hash")))
+                                           if traffic else "none: no committed profile matches the built kernels",
+                         "traffic_measured_here": traffic_measured_here(sys.argv[1:]) if (args.measure_traffic and world == 1) else None,
                          "traffic_detail": traffic, "kernel": run_kernel_name(layout.get("kernel_class", 0)), "kernel_ms": k_ms,
                          "algorithmic_gb_per_launch": ex_bytes / 1e9,
                          "queue_pops_per_launch": pops, "node_updates_per_launch": c.get("node_updates"),
@@ -350,7 +399,9 @@ def main():
                          # (kept for readers of earlier rounds' lines: the same numbers under their old names)
                          "executed": {"achieved": achieved_ex, "frac": achieved_ex / HBM_PEAK_GBS, "gb_per_launch": ex_bytes / 1e9},
                          # the bound that binds ("report both ... events/s per CU"): instruction issue under divergence
-                         "issue": dict(issue or {}, pops_per_s_per_cu=pops / (k_ms * 1e-3) / 256.0,
+                         "issue": dict(issue or {}, source=("committed profile %s (kernel hash %s): replayed, not measured in this run" % (issue.get("profile"), issue.get("source_hash")))
+                                       if issue else "none: no committed profile matches the built kernels",
+                                       pops_per_s_per_cu=pops / (k_ms * 1e-3) / 256.0,
                                        events_per_s_per_cu=local_events / (k_ms * 1e-3) / 256.0,
                                        note="VALU-issue / divergence bound: see DESIGN.md section 5; counters from the stamped PMC profile (null when stale)"),
                          "layout": layout},

@@ -219,7 +219,8 @@ size_t lbft_batch_device_bytes(const lbft_batch* b);
  * cooperative-bulk-send flag << 11 (large networks on the calendar queue: all lanes of a wavefront execute a network's broadcasts) |
  * (lean kernel with the record exchange of quirks bit 0, lbft_k_run2q) << 12 | (small-batch class-0 kernel lbft_k_run0s: the pop's scan
  * of the LDS event queues by all lanes of the wavefront) << 13 | (class-0 kernel with the headline network -- 4 nodes, unit voting rights,
- * log-normal delays -- fixed at compile time, lbft_k_run0q) << 14. */
+ * log-normal delays -- fixed at compile time, lbft_k_run0q) << 14 | (small-batch kernel with ONE network per wavefront executed as
+ * wavefront-uniform code on the scalar unit, lbft_k_run0u -- set together with bit 13) << 15. */
 int lbft_batch_layout(const lbft_batch* b, uint32_t* out);
 /* Events processed per run-kernel launch (0 = whole simulation in one launch). */
 int lbft_batch_set_max_steps(lbft_batch* b, uint32_t max_steps);

@@ -72,19 +72,6 @@ typedef int64_t i64;
 #ifndef LBFT_BLK_CACHE_LEAN2
 #define LBFT_BLK_CACHE_LEAN2 1
 #endif
-// (opt-in build, round 4, UNMEASURED) the two-wavefront large-network kernels keep the event's node -- its 41 fixed words -- in a lane-private
-// LDS column instead of registers: with one cached block record and without the staged author sets lbft_k_run2l / lbft_k_run2q then fit 168
-// registers with 24 / 44 spilled dwords (104 / 124 without; tools/kernel_regs.py), i.e. THREE wavefronts per SIMD for kernels that spend 58-67 %
-// of their cycles waiting for memory.  Built as liblbft_hip_w3.so (tools/gpu_w3_ab.sh); the product library is compiled without it.
-#ifndef LBFT_LEAN_NODE_LDS
-#define LBFT_LEAN_NODE_LDS 0
-#endif
-// ... and the same for the small-batch kernel lbft_k_run0s (opt-in build liblbft_hip_s4.so, round 4, UNMEASURED): with the node in LDS and one cached block
-// record it fits 128 registers with 28 spilled dwords (84 as shipped), i.e. FOUR wavefronts per SIMD with half the lanes each for batches of 2 049..32 768
-// networks -- 8 192 (one GPU's share of the headline batch on an 8-GPU node) as 4 096 wavefronts of 2 instead of 2 048 of 4 (tools/gpu_s4_ab.sh)
-#ifndef LBFT_SMALL_NODE_LDS
-#define LBFT_SMALL_NODE_LDS 0
-#endif
 #ifndef LBFT_BLK_CACHE_LEAN5
 #define LBFT_BLK_CACHE_LEAN5 3  // lbft_k_run2l (SimT<5>): three records fit since the scalar / record accesses stopped holding a register per field
                                 // (round 4: 22 spilled registers; c4 354.6 -> 351.6 ms, c5 1.931 -> 1.897 s; two records 386 ms / 2.12 s; the kernel with
@@ -98,9 +85,6 @@ typedef int64_t i64;
 #ifndef LBFT_C0_IMAJOR
 #define LBFT_C0_IMAJOR 1
 #endif
-#ifndef LBFT_C0_ALIGN
-#define LBFT_C0_ALIGN 0   // (with LBFT_C0_IMAJOR) records padded and aligned so that none straddles a 128-byte line needlessly
-#endif
 #ifndef LBFT_C0_HCREG
 #define LBFT_C0_HCREG 1   // (lbft_k_run0q, with LBFT_C0_IMAJOR) the node's hcbr buffers ride in the node burst and live in registers
 #endif
@@ -113,33 +97,20 @@ typedef int64_t i64;
 #ifndef LBFT_C0_HOT_FIRST
 #define LBFT_C0_HOT_FIRST 1
 #endif
-#ifndef LBFT_QUAD_CONST_OFFSETS
-#define LBFT_QUAD_CONST_OFFSETS 0  // (measured: 19.1 ms against 18.2 with run-time offsets -- the literals cost registers: 85 against 37 spilled)
-#endif
 #ifndef LBFT_QUAD_PAIR
 #define LBFT_QUAD_PAIR 1
 #endif
-#define LBFT_QUAD_SCAP 32u  // snapshot slots of a 4-node batch as the host sizes them by default (lbft_k_run0q needs exactly these)
 #ifndef LBFT_C0_QUAD
 #define LBFT_C0_QUAD 1   // large class-0 batches of 4-node networks with unit rights and log-normal delays run lbft_k_run0q (SimT<9>)
 #endif
 // (round 4 built and measured a "light-event drain" -- requests and cancelled timers finished right after the pop, the lane popping again
 // before the heavy part of the step: -18 % wavefront-steps, +-0 time in seven variants; EXPERIMENTS.md.  The code is in the history:
 // commit "Light-event drain + snapshot hoist as measured variants".)
-// (kernel class 0) the notification snapshot of an event is allocated and written BEFORE the send loop, at one site that every sending
-// lane reaches together, instead of inside the loop at the first notification whose time lies within the horizon (a different
-// iteration for lanes whose list starts behind a sync request); a snapshot that ends up with no reference is freed as before.
-#ifndef LBFT_C0_SNAP_HOIST
-#define LBFT_C0_SNAP_HOIST 0
-#endif
 #ifndef LBFT_C0_NO_TRACE_STATE
 #define LBFT_C0_NO_TRACE_STATE 1  // (class 0 never traces) the round trace's bookkeeping -- last_node, vd_time / vd_stamp -- is not maintained in class 0
 #endif
 #ifndef LBFT_QUAD_LDS_ROUND_TABLES
 #define LBFT_QUAD_LDS_ROUND_TABLES 1  // (with the line above: 65 536 x 4 16.43 -> 16.26 ms) lbft_k_run0q: leader / duration lookups that the LDS tables cover are plain LDS reads (not a load through a selected pointer)
-#endif
-#ifndef LBFT_WB_ALL
-#define LBFT_WB_ALL 0  // (class 0, instance-major) end_node writes the node's whole burst back unconditionally: no dirty-group tracking
 #endif
 #ifndef LBFT_COMMIT_CHAIN
 #define LBFT_COMMIT_CHAIN 1  // (round 4: 65 536 x 4 15.79 -> 15.57 ms) (n <= 32) a commit that does not extend the last one directly: the chain of blocks to commit (nearly always 2-3) is
@@ -149,10 +120,6 @@ typedef int64_t i64;
 #define LBFT_POPC_MAX_LPW 8u  // networks per wavefront up to which lbft_k_run0s is used (measured: 1 024 x 4: 6.3 against 7.5 ms, 8 192: 10.9 against 12.1,
                               // 16 384 (8 per wavefront): 14.8 against 15.9; 32 per wavefront: the lane-private scan stops at the queue's length and wins)
 #endif
-#ifndef LBFT_C0_QLANE
-#define LBFT_C0_QLANE 0
-#endif
-#define LBFT_QLANE_PAD 2u  // (u64 words)
 #ifndef LBFT_POP_BATCH
 #define LBFT_POP_BATCH 16u // packed LDS queue front (class 0): independent loads in flight per batch of the pop's scan
 #endif
@@ -332,23 +299,6 @@ enum InstField : u32 {
 // SimulatedContext simulated_context.rs:75-83).
 // Memory order = the groups of fields end_node writes back together (each group one contiguous run of words: with instance-major
 // rows a group is a few wide stores).
-#if defined(LBFT_NF_ORDER_OLD)
-enum NodeField : u32 {
-  NF_STARTUP = 0, NF_IGNORE_UNTIL, NF_EPOCH, NF_INIT_STATE_BLK, NF_PROPOSED_BLK, NF_HQC_ROUND, NF_HQC_BLK,
-  NF_HTC_ROUND, NF_CUR_ROUND, NF_HC_ROUND, NF_HCC_BLK, NF_TC_MASK, NF_TO_MASK, NF_TO_WEIGHT,
-  NF_ELECTION,
-  NF_BAL0_BLK, NF_BAL0_WEIGHT, NF_BAL0_AUTHORS, NF_BAL1_BLK, NF_BAL1_WEIGHT, NF_BAL1_AUTHORS,
-  NF_PM_EPOCH, NF_PM_ROUND, NF_PM_LEADER, NF_PM_START, NF_PM_DUR_LO, NF_PM_DUR_HI,
-  NF_LVR, NF_LOCKED, NF_LQAT, NF_TR_EPOCH, NF_TR_HCR, NF_TR_LCT,
-  NF_NEXT_CMD, NF_LAST_COMMITTED_BLK, NF_NCOMMITS,
-  NF_LAST_TIMER_T, NF_TIMER_DUPS,
-  NF_DUP_STAMP,
-  NF_PREV_EPOCH_HCC,
-  NF_TC_SEL,
-  NF_FIXED_WORDS
-};
-
-#else
 enum NodeField : u32 {
   // (set once per epoch)
   NF_STARTUP = 0, NF_EPOCH, NF_INIT_STATE_BLK,
@@ -372,7 +322,6 @@ enum NodeField : u32 {
   NF_FIXED_WORDS  // followed by hcbr[2][n]: highest_certified_block_round per timeout author
 };
 
-#endif
 // Block rows.  The first BC_WORDS rows are the "hot record" that the event loop works on (held in a small
 // register-resident cache, see Sim::blk_get): the block's round and links, the rounds of its parent and
 // grandparent (denormalised at proposal time, so the 3-chain commit rule record_store.rs:221-235 and the
@@ -386,16 +335,11 @@ enum BlockField : u32 {
   B_VOTERS,  // authors 0..31 whose votes the block's QuorumCertificate contains (written once, by the author, when it forms the QC)
   B_WORDS
 };
-#ifndef LBFT_BLK_PLAIN_FIFO
-#define LBFT_BLK_PLAIN_FIFO 1  // plain round-robin replacement of the cached block records (no "recently used" bits, no aging pass per insertion):
-                               // round 4, 65 536 x 4: 17.63 -> 17.05 ms -- the second-chance bookkeeping (a bit set per hit, three test-and-advance
-                               // steps per insertion, inlined at 22 lookup sites: 480 of the kernel's 6.8 k instructions) cost more than the few misses it saved
-#endif
 #ifndef LBFT_BLK_CACHE_QUAD
 #define LBFT_BLK_CACHE_QUAD 4  // lbft_k_run0q: four records fit since round 4 freed the registers (238 VGPRs, no spill): 15.50 -> 15.38 ms; two: 17.4
 #endif
 #ifndef LBFT_BLK_CACHE
-#define LBFT_BLK_CACHE 3  // register-resident block records per instance (FIFO; LBFT_BLK_PLAIN_FIFO=0: second chance); round 1: 2 -> 29.2 ms, 3 -> 27.9, 4 -> 28.0 (19 spilled registers), 5 -> 29.8
+#define LBFT_BLK_CACHE 3  // register-resident block records per instance (plain FIFO); round 1: 2 -> 29.2 ms, 3 -> 27.9, 4 -> 28.0 (19 spilled registers), 5 -> 29.8
 #endif
 
 // Snapshot (notification, data_sync.rs:16-39) rows; followed by tc_hcbr[n], to_hcbr[n].
@@ -406,6 +350,14 @@ enum SnapField : u32 { S_EPOCH = 0, S_CERTS /* hcc | hqc << 16 */, S_PROP_VOTE /
 #define LBFT_NO_LEADER 0xffu
 #define LBFT_NEVER INT64_MAX
 
+// Loop unrolling requests of the device build (the host build of the kernel logic leaves its loops to the host compiler)
+#if defined(__HIPCC__)
+#define LBFT_UNROLL _Pragma("unroll")
+#define LBFT_UNROLL4 _Pragma("unroll 4")
+#else
+#define LBFT_UNROLL
+#define LBFT_UNROLL4
+#endif
 // Branch hints: without them the compiler lays blocks out in source order, i.e. fault handling, capacity spills and once-per-epoch code
 // sit in the middle of the event loop; with them they move behind it and the loop's instruction-cache footprint shrinks.
 #if defined(LBFT_NO_HINTS)
@@ -705,12 +657,8 @@ struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at
 // sim_class() picks the class a batch runs with.
 //   5  class 2 without the record exchange of quirks bit 0, the round-switch trace and the lossy network (sim_lean()): the
 //      plain large-network path fits 256 registers (21 spilled) and runs two wavefronts per SIMD with half the lanes each
-// (LBFT_LEAN_NODE_LDS) the LDS column of the event's node: members of the classes that use it only -- an empty base elsewhere, so that every other
-// class keeps its layout (and the product library its machine code)
-template <bool ON> struct NodeCacheLds { };
-template <> struct NodeCacheLds<true> { u32* cwl = nullptr; };
 template <int CLS>
-struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) || (CLS == 8 && LBFT_SMALL_NODE_LDS != 0)> {
+struct SimT {
   static constexpr bool LEAN2 = CLS == 5 || CLS == 7;  // 7 = 5 plus the record exchange of quirks bit 0 (24 spilled registers; a kernel of its own: with
                                                        // that code compiled in, the runs without it lose 10 %)
   static constexpr bool BIG = CLS == 2 || LEAN2;       // multi-word node / author sets
@@ -762,11 +710,10 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
   LBFT_HD u32 SWORDS() const { return QUAD ? S_FIXED_WORDS + 8u : P.snap_words; }
   LBFT_HD u32 BWORDS() const { return QUAD ? (u32)B_WORDS : P.blk_words; }
   LBFT_HD u32 OFFNODE() const { return QUAD ? (u32)I_WORDS : P.off_node; }
-  // (hot-first layout, compute_layout: I_WORDS | 4 nodes | LBFT_QUAD_SCAP snapshots | reference counts | free stack | blocks)
-  LBFT_HD u32 OFFSNAP() const { return QUAD && LBFT_QUAD_CONST_OFFSETS ? (u32)I_WORDS + 4u * (NF_FIXED_WORDS + 8u) : P.off_snap; }
-  LBFT_HD u32 OFFSREF() const { return QUAD && LBFT_QUAD_CONST_OFFSETS ? (u32)I_WORDS + 4u * (NF_FIXED_WORDS + 8u) + LBFT_QUAD_SCAP * (S_FIXED_WORDS + 8u) : P.off_snap_ref; }
-  LBFT_HD u32 OFFSFREE() const { return QUAD && LBFT_QUAD_CONST_OFFSETS ? (u32)I_WORDS + 4u * (NF_FIXED_WORDS + 8u) + LBFT_QUAD_SCAP * (S_FIXED_WORDS + 8u) + LBFT_QUAD_SCAP : P.off_snap_free; }
-  LBFT_HD u32 OFFBLK() const { return QUAD && LBFT_QUAD_CONST_OFFSETS ? (u32)I_WORDS + 4u * (NF_FIXED_WORDS + 8u) + LBFT_QUAD_SCAP * (S_FIXED_WORDS + 8u) + 2u * LBFT_QUAD_SCAP : P.off_blk; }
+  LBFT_HD u32 OFFSNAP() const { return P.off_snap; }
+  LBFT_HD u32 OFFSREF() const { return P.off_snap_ref; }
+  LBFT_HD u32 OFFSFREE() const { return P.off_snap_free; }
+  LBFT_HD u32 OFFBLK() const { return P.off_blk; }
   LBFT_HD u32 UNITW() const { return QUAD ? 1u : P.unit_weights; }
   LBFT_HD u32 DMODEL() const { return QUAD ? 0u : P.delay_model; }
   LBFT_HD u32 QUORUM() const { return QUAD ? 3u : P.quorum; }
@@ -816,10 +763,6 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
   u32* qm;
   u32 qstr, qsh, ql;  // column stride (lanes per wavefront, a power of two) and its log2: element k of a column is [k << qsh]
   u32 hsh;            // the same for the hcbr column (attach_hcbr)
-  // LBFT_C0_QLANE (kernel class 0): the LDS queue front is lane-major instead -- a lane's slots are consecutive words (slot offsets are
-  // instruction immediates, two keys per ds_read_b128), lanes LBFT_QLANE_PAD words apart beyond the slots so that the lanes of a
-  // wavefront reading the same slot fall into different banks
-  static constexpr bool QLANE = C0 && LBFT_C0_QLANE != 0;
 #if defined(__HIP_DEVICE_COMPILE__)
   static constexpr bool QS32 = CLS == 9 && LBFT_QUAD_STRIDE32 != 0;
 #else
@@ -827,7 +770,7 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
 #endif
   LBFT_HD u32 QSH() const { return QS32 ? 5u : qsh; }
   LBFT_HD u32 QSTR() const { return QS32 ? 32u : qstr; }
-  LBFT_HD u32 qx(u32 k) const { return QLANE ? k : k << QSH(); }
+  LBFT_HD u32 qx(u32 k) const { return k << QSH(); }
   // read-only tables (LDS copies on the device)
   const u64 *zig_x, *zig_f, *exp_tab;
   const u8* leader_lds;   // first leader_lds_len rounds of the leader table
@@ -849,7 +792,7 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
     while ((1u << qsh) < stride) qsh++;  // (a shift instead of a quarter-rate 32-bit multiply per slot access)
     hsh = qsh;
     // (not in the wavefront-uniform kernel: an inline-asm result counts as divergent, and everything compared with it after it)
-    if (!QLANE && !WUNI) LBFT_PIN_VGPR(qsh);
+    if (!WUNI) LBFT_PIN_VGPR(qsh);
     if (!WUNI) LBFT_PIN_VGPR(ql);
   }
   // highest_certified_block_round buffers of the nodes' timeouts (hcbr[node][2][n], behind the fixed node rows): for
@@ -868,28 +811,20 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
     if (!hc_reg()) return;
     hcdirty = 0;
     if (NN() == 4) {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 k = 0; k < 8; k++) hcw[k] = ldf(nb, NF_FIXED_WORDS + k);
     } else {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 k = 0; k < 8; k++) hcw[k] = (k & 3u) < NN() ? ldf(nb, NF_FIXED_WORDS + (k >> 2) * NN() + (k & 3u)) : 0u;
     }
   }
   LBFT_HD void hc_store(u32 nb) const {
     if (!hc_reg() || !hcdirty) return;
     if (NN() == 4) {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 k = 0; k < 8; k++) stf(nb, NF_FIXED_WORDS + k, hcw[k]);
     } else {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 k = 0; k < 8; k++) if ((k & 3u) < NN()) stf(nb, NF_FIXED_WORDS + (k >> 2) * NN() + (k & 3u), hcw[k]);
     }
   }
@@ -906,9 +841,7 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
   LBFT_HD void hc_set(u32 node, u32 buf, u32 a, u32 v) const {
     if (hc_reg()) {
       u32 idx = buf * 4u + a;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 k = 0; k < 8; k++) hcw[k] = idx == k ? v : hcw[k];
       hcdirty = 1;
       return;
@@ -973,18 +906,8 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
   // reorder row loads across row stores) and the modified ones are written back by end_node().
   // `f` is a compile-time constant at every call site, so cw[] lives in VGPRs.
   mutable u32 cw[NF_FIXED_WORDS];
-  // ... or (LBFT_LEAN_NODE_LDS, the two-wavefront large-network kernels) in this lane's LDS column: word f at cwl[f << CWSH]
-  static constexpr bool CWLDS = (LEAN2 && LBFT_LEAN_NODE_LDS != 0) || (CLS == 8 && LBFT_SMALL_NODE_LDS != 0);  // (cwl: NodeCacheLds<true>)
-  // the columns of a wavefront are 32 words apart whatever its lanes per wavefront: a compile-time stride makes word f an immediate offset of ONE
-  // address (with the stride in a register the compiler keeps `f << stride` for every f it meets: 40 registers, the spills this is here to remove)
-#if defined(__HIP_DEVICE_COMPILE__)
-  static constexpr u32 CWSH = 5;
-#else
-  static constexpr u32 CWSH = 0;  // (the host model passes one plain array per network)
-#endif
-  LBFT_HD void attach_node_cache(u32* column) { if constexpr (CWLDS) this->cwl = column; else (void)column; }
-  LBFT_HD u32 cwg(u32 f) const { if constexpr (CWLDS) return this->cwl[f << CWSH]; else return cw[f]; }
-  LBFT_HD void cws(u32 f, u32 v) const { if constexpr (CWLDS) this->cwl[f << CWSH] = v; else cw[f] = v; }
+  LBFT_HD u32 cwg(u32 f) const { return cw[f]; }
+  LBFT_HD void cws(u32 f, u32 v) const { cw[f] = v; }
   // rows are written back by groups of fields that change together: 6 tests instead of 41 (A/B on the 65536 x 4 batch in one GPU call:
   // 24.6 ms vs 25.1 ms per row; writing all rows unconditionally had measured 9 % slower).  cdirty holds one bit per GROUP.
   static constexpr u32 NGROUPS = 6;
@@ -1006,15 +929,13 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
   mutable u32 cdirty;
   LBFT_HD u32 nf(u32 node, u32 f) const { return f < NF_FIXED_WORDS ? cwg(f) : ld(nfw(node, f)); }
   LBFT_HD void nfs(u32 node, u32 f, u32 v) const {
-    if (f < NF_FIXED_WORDS) { cws(f, v); if (!(C0I && LBFT_WB_ALL)) cdirty |= 1u << group_of(f); }
+    if (f < NF_FIXED_WORDS) { cws(f, v); cdirty |= 1u << group_of(f); }
     else st(nfw(node, f), v);
   }
   LBFT_HD void begin_node(u32 node) const {
     // one base pointer, then constant row offsets: the 38 loads become one burst with immediate offsets
     u32 nb = boff(OFFNODE() + node * NWORDS());
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 f = 0; f < NF_FIXED_WORDS; f++) cws(f, ldf(nb, f));
     cdirty = 0;
     hc_load(nb);
@@ -1023,24 +944,11 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
   LBFT_HD void end_node(u32 node) const {
     ax_store(node);
     u32 nb = boff(OFFNODE() + node * NWORDS());
-    if (C0I && LBFT_WB_ALL) {
-      if (hc_reg()) hcdirty = 1;
-      hc_store(nb);
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-      for (u32 f = 0; f < NF_FIXED_WORDS; f++) stf(nb, f, cwg(f));
-      return;
-    }
     hc_store(nb);
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 g = 0; g < NGROUPS; g++)
       if ((cdirty >> g) & 1u) {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+        LBFT_UNROLL
         for (u32 f = 0; f < NF_FIXED_WORDS; f++)
           if ((group_mask(g) >> f) & 1ULL) stf(nb, f, cwg(f));
       }
@@ -1076,41 +984,33 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
     LBFT_HD u32 depth() const { return w[B_DEPTH]; }
   };
 #ifndef LBFT_BLK_CACHE_UNI
-#define LBFT_BLK_CACHE_UNI LBFT_BLK_CACHE  // (lbft_k_run0u, opt-in build: its state lives in SGPRs / VGPR lanes -- fewer cached records, fewer v_readlane / v_writelane: to be measured)
+#define LBFT_BLK_CACHE_UNI 1  // lbft_k_run0u: its state lives in SGPRs / VGPR lanes (one v_readlane / v_writelane per access to a parked word), so every cached
+                              // record is paid at every access to the state behind it -- round 5, 1 024 x 4: 3 records 7.56 ms, 2: 7.33, 1: 4.88 (lbft_k_run0s: 5.27)
 #endif
-#ifndef LBFT_BLK_CACHE_SMALL
-#define LBFT_BLK_CACHE_SMALL LBFT_BLK_CACHE  // (lbft_k_run0s; the four-wavefront build uses 1)
-#endif
-  static constexpr u32 BCN = CLS == 9 ? LBFT_BLK_CACHE_QUAD : CLS == 12 ? LBFT_BLK_CACHE_UNI : CLS == 8 ? LBFT_BLK_CACHE_SMALL : CLS == 5 ? LBFT_BLK_CACHE_LEAN5 : LEAN2 ? LBFT_BLK_CACHE_LEAN2 : LBFT_BLK_CACHE;
+  static constexpr u32 BCN = CLS == 9 ? LBFT_BLK_CACHE_QUAD : CLS == 12 ? LBFT_BLK_CACHE_UNI : CLS == 5 ? LBFT_BLK_CACHE_LEAN5 : LEAN2 ? LBFT_BLK_CACHE_LEAN2 : LBFT_BLK_CACHE;
   mutable u32 bc_id[BCN];
   mutable u32 bc_w[BCN][BC_WORDS];
-  mutable u32 bc_next, bc_ref;  // FIFO hand (+ "recently used" bits of the second-chance variant, LBFT_BLK_PLAIN_FIFO=0)
+  mutable u32 bc_next;  // FIFO hand (plain round-robin replacement: the second-chance bookkeeping cost more than the misses it saved, EXPERIMENTS.md)
+#if !defined(LBFT_NO_BC_PAD)
+  mutable u32 bc_ref;   // (unused since the second-chance variant went; kept because WITHOUT this member the compiler emits 5 % more code for the
+                        // large-network kernels -- lbft_k_run2l 135 -> 142 KB -- which round 5 measured: see EXPERIMENTS.md)
+#endif
   LBFT_HD void blk_cache_reset() const {
     for (u32 e = 0; e < BCN; e++) bc_id[e] = 0;
-    bc_next = 0; bc_ref = 0;
+    bc_next = 0;
+#if !defined(LBFT_NO_BC_PAD)
+    bc_ref = 0;
+#endif
   }
   LBFT_HD void blk_cache_insert(u32 b, const Blk& r) const {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (u32 t = 0; t < (LBFT_BLK_PLAIN_FIFO ? 0u : BCN); t++) {  // skip (and age) entries used since the hand last passed
-      if ((bc_ref >> bc_next) & 1u) {
-        bc_ref &= ~(1u << bc_next);
-        bc_next = bc_next + 1 == BCN ? 0 : bc_next + 1;
-      }
-    }
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 e = 0; e < BCN; e++) {
       // value selects at fixed entries, NOT `if (hand == e) entry[e] = r`: the compiler sinks such conditional stores
       // into one store through a phi of entry addresses, and an array addressed that way is no longer promoted to
       // registers (the whole cache ended up in scratch memory: 32 scratch loads per lookup)
       bool take = bc_next == e;
       bc_id[e] = take ? b : bc_id[e];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 f = 0; f < BC_WORDS; f++) bc_w[e][f] = take ? r.w[f] : bc_w[e][f];
     }
     bc_next = bc_next + 1 == BCN ? 0 : bc_next + 1;
@@ -1119,9 +1019,7 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
     if (!BLW || !bl) return;
     const u32 e = b & (bl_n - 1u);
     bl[blx(e)] = b;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 f = 0; f < BC_WORDS; f++) bl[blx(bl_n + e * BC_WORDS + f)] = r.w[f];
   }
   mutable u32 cur_xk;  // extension word of the node sets that the current event's node lives in (0: node < 32 or n <= 32)
@@ -1131,22 +1029,15 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
     r.xk = 0; r.x[0] = r.x[1] = r.x[2] = 0;  // (node-set extension words: fetched by the first bm_* operation that needs them)
     // one select per further entry (the value of a miss is overwritten by the loads below): r = entry 0, then entry e where it is the hit
     bool he[BCN];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 e = 0; e < BCN; e++) {
       he[e] = bc_id[e] == b;
       hit = hit || he[e];
-      if (!LBFT_BLK_PLAIN_FIFO && he[e]) bc_ref |= 1u << e;
     }
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 f = 0; f < BC_WORDS; f++) {
       u32 v = bc_w[0][f];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 e = 1; e < BCN; e++) v = he[e] ? bc_w[e][f] : v;
       r.w[f] = v;
     }
@@ -1161,17 +1052,13 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
         const u32 e = b & (bl_n - 1u);
         if (bl[blx(e)] == b) {
           in_window = true;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+          LBFT_UNROLL
           for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = bl[blx(bl_n + e * BC_WORDS + f)];
         }
       }
       if (!in_window) {
         u32 bb = boff(bfw(b, 0));
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+        LBFT_UNROLL
         for (u32 f = 0; f < BC_WORDS; f++) r.w[f] = ldf(bb, f);  // one burst of independent loads
         LBFT_DRAIN_VMEM();
         blw_fill(b, r);
@@ -1221,9 +1108,7 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
       const u32 e = b & (bl_n - 1u);
       if (bl[blx(e)] == b) bl[blx(bl_n + e * BC_WORDS + f)] = v;
     }
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 e = 0; e < BCN; e++) {  // (value selects: see blk_cache_insert)
       bool hit = bc_id[e] == b;
       if (f == B_KNOWN) bc_w[e][B_KNOWN] = hit ? v : bc_w[e][B_KNOWN];
@@ -1533,7 +1418,7 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
     u64 m = ~0ULL; u32 mi = 0;
     for (u32 k0 = grp * PB; k0 < nl; k0 += groups * PB) {
       u64 kk[PB];
-#pragma unroll
+LBFT_UNROLL
       for (u32 j = 0; j < PB; j++) kk[j] = kw[((k0 + j) << QSH()) + col];
       u64 bm; u32 bi;
       qmin<0, PB>(kk, bm, bi);
@@ -1629,9 +1514,7 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
       // then a tree of compare-selects (a sequential min pays one LDS round trip per slot)
       for (u32 k0 = 0; k0 < nl; k0 += PB) {
         u64 kk[PB];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+        LBFT_UNROLL
         for (u32 j = 0; j < PB; j++) kk[j] = qk[qx(k0 + j)];
         u64 bm; u32 bi;
         qmin<0, PB>(kk, bm, bi);
@@ -1640,9 +1523,7 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
       pop_take(bkey, best, time, kind, meta);
       return true;
     }
-#if defined(__HIPCC__)
-#pragma unroll 4
-#endif
+    LBFT_UNROLL4
     for (u32 k = 0; k < nl; k++) {
       u64 key = qk[qx(k)];
       if (key < bkey) { bkey = key; best = k; }
@@ -1784,13 +1665,9 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
     axdirty = 0;
     if (!F_AX || !wide()) return;
     u32 base = nfw(node, NF_FIXED_WORDS + 2 * NN());
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 i = 0; i < 4; i++) {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 k = 0; k < 3; k++) {  // (unconditional loads of a clamped row, then a select: one burst with the fixed rows)
         u32 kk = k + 1 < MW() ? k : 0;
         u32 v = ld(base + i * (MW() - 1) + kk);
@@ -1800,38 +1677,26 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
   }
   LBFT_HD void ax_store(u32 node) const {
     if (!F_AX || !wide() || !axdirty) return;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 i = 0; i < 4; i++) {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 k = 0; k < 3; k++)
         if ((axdirty >> (i * 3 + k)) & 1u) st(nfw(node, NF_FIXED_WORDS + 2 * NN() + i * (MW() - 1) + k), ax[i][k]);
     }
   }
   LBFT_HD u32 ax_get(u32 i, u32 k) const {  // k = 1..3
     u32 v = 0;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 ii = 0; ii < 4; ii++) {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 kk = 0; kk < 3; kk++) v = (ii == i && kk + 1 == k) ? ax[ii][kk] : v;
     }
     return v;
   }
   LBFT_HD void ax_put(u32 i, u32 k, u32 v) const {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 ii = 0; ii < 4; ii++) {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 kk = 0; kk < 3; kk++) ax[ii][kk] = (ii == i && kk + 1 == k) ? v : ax[ii][kk];
     }
     axdirty |= 1u << (i * 3 + k - 1);
@@ -1971,16 +1836,12 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
     constexpr u32 TB = BIG ? 8 : 4;  // hcbr words in flight per round trip
     while (mask) {
       u32 a[TB], h[TB], k = 0;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 j = 0; j < TB; j++) {
         a[j] = 0; h[j] = 0;
         if (mask) { a[j] = author0 + ctz32(mask); mask &= mask - 1; h[j] = ld(word0 + a[j]); k = j + 1; }
       }
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 j = 0; j < TB; j++)
         if (j < k) insert_timeout(node, a[j], round, h[j]);
     }
@@ -2010,9 +1871,7 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
     }
     rb.w[B_EPOCH] = nf(node, NF_EPOCH);
     rb.w[B_KNOWN] = 0; rb.w[B_QC] = 0; rb.w[B_PEND] = 0;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 f = 0; f < BC_WORDS; f++) bfs(b, f, rb.w[f]);
     bfs(b, B_TIME, (u32)(i32)local_clock);
     bfs(b, B_CMD, cmd);
@@ -2149,9 +2008,7 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
       if (base0 == nf(node, NF_LAST_COMMITTED_BLK)) { LBFT_STAT(12); commit_block(node, start, rh.depth() - 2); return; }
     }
     Blk r0;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 f = 0; f < BC_WORDS; f++) r0.w[f] = 0;
     r0.xk = 0; r0.x[0] = r0.x[1] = r0.x[2] = 0;
     if (LBFT_COMMIT_CHAIN && !wide()) {
@@ -2159,9 +2016,7 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
       u32 cid[CAP], clink[CAP], cdep[CAP], cpend[CAP];
       u32 kk = 0, x = start;
       bool more = true;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 i = 0; i < CAP; i++) {
         cid[i] = 0; clink[i] = 0; cdep[i] = 0; cpend[i] = 0;
         if (more) {
@@ -2235,9 +2090,7 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
     u32 base = P.off_rarch + (node * P.ecap + old_epoch) * P.rarch_words;
     // (the fixed words come from the register copy, everything behind them from the node's rows: the hcbr buffers -- LDS-resident for
     // networks of <= 4 nodes in class 0 -- and the set extension words, which are flushed first)
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 f = 0; f < NF_FIXED_WORDS; f++) st(base + f, cwg(f));
     ax_store(node);
     axdirty = 0;
@@ -2363,16 +2216,12 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
     constexpr u32 B = BIG ? 8 : 4;  // loads in flight per round trip (large networks copy dozens of words per notification)
     while (mask) {
       u32 a[B], h[B], k = 0;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 j = 0; j < B; j++) {
         a[j] = 0; h[j] = 0;
         if (mask) { a[j] = author0 + ctz32(mask); mask &= mask - 1; h[j] = hc_get(node, buf, a[j]); k = j + 1; }
       }
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 j = 0; j < B; j++)
         if (j < k) st(dst_word0 + a[j], h[j]);
     }
@@ -2580,13 +2429,9 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
     u32 tc_sel = nf(node, NF_TC_SEL);
     if (hc_reg()) {
       // both buffers whole, no loop over the sets: a receiver only reads the words of authors in the sets
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 a = 0; a < 4; a++) if (a < NN()) stf(sb0, S_FIXED_WORDS + a, tc_sel ? hcw[4 + a] : hcw[a]);
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 a = 0; a < 4; a++) if (a < NN()) stf(sb0, S_FIXED_WORDS + NN() + a, tc_sel ? hcw[a] : hcw[4 + a]);
     } else
     if (!skip_hcbr) {
@@ -2613,24 +2458,18 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
     if (is_k) {
       u32 htc = nf(node, NF_HTC_ROUND);
       sel_k = nf(node, NF_TC_SEL);
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 q = 0; q < 4; q++) { tw_[q] = (q < MW() && htc) ? am_word(node, NF_TC_MASK, q) : 0u; ow_[q] = q < MW() ? am_word(node, NF_TO_MASK, q) : 0u; }
     }
     const u32 tc_sel = LBFT_UNI(sel_k, k);
     u32 tcw[4], tow[4];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 q = 0; q < 4; q++) { tcw[q] = LBFT_UNI(tw_[q], k); tow[q] = LBFT_UNI(ow_[q], k); }
     const u32 src_tc = nfw(node, NF_FIXED_WORDS + tc_sel * NN()), src_to = nfw(node, NF_FIXED_WORDS + (1u - tc_sel) * NN());
     const u32 dst_tc = base + S_FIXED_WORDS, dst_to = base + S_FIXED_WORDS + NN();
     // (at most two passes of 64 authors: unrolled, so that the set words are picked with compile-time indices -- indexed by the loop
     // variable the two four-word arrays went through scratch memory, a store + a dependent load per pass in every lane of the wavefront)
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 pass = 0; pass < (LBFT_MAX_NODES + 63) / 64; pass++) {
       const u32 a0 = pass * 64u, q0 = pass * 2u;
       if (a0 >= NN()) break;
@@ -2658,20 +2497,14 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
   LBFT_HD Snap load_snapshot(u32 slot) const {
     Snap sn;
     u32 sb = boff(OFFSNAP() + slot * SWORDS());
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 f = 0; f < S_FIXED_WORDS; f++) sn.w[f] = ldf(sb, f);
     sn.refs = ld(OFFSREF() + slot);
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+    LBFT_UNROLL
     for (u32 a = 0; a < 4; a++) sn.to_hcbr[a] = 0;
     if (small_sets()) {
       u32 hb = boff(OFFSNAP() + slot * SWORDS() + S_FIXED_WORDS + NN());
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 a = 0; a < 4; a++) sn.to_hcbr[a] = ldf(hb, a < NN() ? a : 0);
     }
     return sn;
@@ -2888,10 +2721,6 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
     i32 slot = -1, slot_twin = -1, rs = 0;
     u32 refs = 0, refs_twin = 0, rrefs = 0;
     bool equivocal = false;
-    if (C0 && LBFT_C0_SNAP_HOIST && n_a) {
-      slot = snap_alloc();
-      if (slot < 0) slot = -2; else write_snapshot(node, (u32)slot);
-    }
     for (u32 j = 0; j < total; j++) {
       // receivers.shuffle(rng) (simulator.rs:343) / create_request + senders.shuffle(rng) (simulator.rs:365-370): each
       // drawn right before the delays of its list; one site for both lists (they never start at the same j)
@@ -3378,9 +3207,7 @@ struct SimT : NodeCacheLds<((CLS == 5 || CLS == 7) && LBFT_LEAN_NODE_LDS != 0) |
       sp.response = 0; sp.resp_slot = 0; sp.sync = 0; sp.sync_stamp = 0; sp.sync_epoch = 0; sp.sync_certs = 0; sp.have_actions = 0;
       begin_node((q1() && kind == 1) ? sender : node);  // Q1 fixed: a request is processed on the peer it was sent to
       Snap sn;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
+      LBFT_UNROLL
       for (u32 f = 0; f < S_FIXED_WORDS; f++) sn.w[f] = 0;
       sn.refs = 0; sn.to_hcbr[0] = sn.to_hcbr[1] = sn.to_hcbr[2] = sn.to_hcbr[3] = 0;
       if (kind == 0) sn = load_snapshot(slot);
@@ -3585,11 +3412,9 @@ inline int sim_class(const Params& p) {
 
 // Does a class-0 batch qualify for the kernel with the headline network fixed at compile time (SimT<9>)?
 inline bool sim_quad(const Params& p) {
-  return sim_class(p) == 0 && p.n == 4 && p.unit_weights && p.delay_model == 0 && (LBFT_QUAD_CONST_OFFSETS ? p.scap == LBFT_QUAD_SCAP : p.scap <= 64) && p.rot == 0 && p.rarch_words == 0 &&
-         LBFT_C0_IMAJOR && !LBFT_C0_ALIGN && p.off_node == I_WORDS && p.node_words == NF_FIXED_WORDS + 8u && p.snap_words == S_FIXED_WORDS + 8u &&
-         p.blk_words == B_WORDS &&
-         (!LBFT_QUAD_CONST_OFFSETS || (p.off_snap == I_WORDS + 4u * (NF_FIXED_WORDS + 8u) && p.off_snap_ref == p.off_snap + LBFT_QUAD_SCAP * (S_FIXED_WORDS + 8u) &&
-                                       p.off_snap_free == p.off_snap_ref + LBFT_QUAD_SCAP && p.off_blk == p.off_snap_free + LBFT_QUAD_SCAP));
+  return sim_class(p) == 0 && p.n == 4 && p.unit_weights && p.delay_model == 0 && p.scap <= 64 && p.rot == 0 && p.rarch_words == 0 &&
+         LBFT_C0_IMAJOR && p.off_node == I_WORDS && p.node_words == NF_FIXED_WORDS + 8u && p.snap_words == S_FIXED_WORDS + 8u &&
+         p.blk_words == B_WORDS;
 }
 // Does a class-2 / class-1 batch qualify for the lean kernel of its class (SimT<5> / SimT<6>)?
 inline bool sim_lean_features(const Params& p) { return (!(p.quirks & 1u) || (LBFT_LEAN_Q1 && p.n > 32)) && !p.rcap && !p.drop_ppm && !p.part_size; }
@@ -3606,13 +3431,7 @@ inline u32 layout_tile_width(const Params& p) { return sim_class(p) == 0 ? (LBFT
 inline u64 compute_layout(Params& p) {
   u64 w = I_WORDS;
   p.mw = (p.n + 31) / 32;
-  // (class 0, instance-major, LBFT_C0_ALIGN: node rows start on a 128-byte line and are padded to whole lines; snapshots and
-  // block records are padded to 64 bytes and aligned to them; every instance starts on a line)
-  const bool c0a = LBFT_C0_IMAJOR && LBFT_C0_ALIGN && sim_class(p) == 0;
-  auto up = [](u64 x, u64 a) { return (x + a - 1) / a * a; };
-  if (c0a) w = up(w, 32);
   p.off_node = (u32)w; p.node_words = NF_FIXED_WORDS + 2 * p.n + 4 * (p.mw - 1);
-  if (c0a) p.node_words = (u32)up(p.node_words, 32);
   w += (u64)p.n * p.node_words;
   p.snap_words = S_FIXED_WORDS + 2 * p.n + 2 * (p.mw - 1) + ((p.quirks & 1u) ? 2 : 0);  // + the request's (epoch, certificates)
   p.blk_words = B_WORDS + 4 * (p.mw - 1);  // + extension words (nodes / authors >= 32) of KNOWN, QC, PEND and VOTERS
@@ -3621,11 +3440,9 @@ inline u64 compute_layout(Params& p) {
   // compile time (SimT<9>) turns into immediates
   const bool hot_first = LBFT_C0_IMAJOR && LBFT_C0_HOT_FIRST && sim_class(p) == 0;
   auto snaps_blocks = [&]() {
-    if (c0a) { p.snap_words = (u32)up(p.snap_words, 16); w = up(w, 16); }
     p.off_snap = (u32)w; w += (u64)p.scap * p.snap_words;
     p.off_snap_ref = (u32)w; w += p.scap;
     p.off_snap_free = (u32)w; w += p.scap;
-    if (c0a) { p.blk_words = (u32)up(p.blk_words, 16); w = up(w, 16); }
     p.off_blk = (u32)w; w += (u64)p.bcap * p.blk_words;
   };
   if (hot_first) snaps_blocks();
@@ -3645,7 +3462,6 @@ inline u64 compute_layout(Params& p) {
   p.off_rarch = (u32)w; w += (u64)p.n * p.ecap * p.rarch_words;
   p.off_sync = (u32)w; w += (p.quirks & 1u) ? p.bcap : 0;
   p.off_ring = (u32)w; w += 2ULL * p.ring;
-  if (c0a) w = up(w, 32);
   p.total_words = w > 0xffffffffULL ? 0xffffffffu : (u32)w;
   p.qpack = sim_class(p) == 0 ? 1u : 0u;
   return w;

@@ -74,37 +74,19 @@ __global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_init(Params p, u32* __restr
 
 // [tables][queue keys][queue metas][diagnostics: LBFT_NPHASES u64 per wavefront][n > 16: one 128-byte receiver list per instance]
 // `slot_bytes`: 12 (key + meta) or 8 (packed one-word entries, kernel class 0)
-// (class 0 with a lane-major queue front, LBFT_C0_QLANE: LBFT_QLANE_PAD more words per lane)
-#define LBFT_QPAD(slot_bytes) ((slot_bytes) == 8 && LBFT_C0_QLANE ? LBFT_QLANE_PAD : 0u)
 // `hcbr_lds`: class 0 with networks of <= 4 nodes keeps the nodes' hcbr buffers in LDS -- except lbft_k_run0q, which carries them in
 // registers with the node burst (LBFT_C0_HCREG)
 // the LDS window of block records of the large-network kernels (SimT::attach_blk_window): `entries` records + tags per network
 static inline size_t blk_window_bytes(u32 entries, u32 lpw, u32 nwaves) { return (size_t)nwaves * lpw * entries * (1u + BC_WORDS) * 4u; }
 static inline size_t run_lds_bytes(u32 ql, u32 lpw, u32 n, u32 slot_bytes, u32 nwaves, bool hcbr_lds = true) {
-  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)nwaves * (ql + LBFT_QPAD(slot_bytes)) * lpw * slot_bytes + (size_t)nwaves * LBFT_NPHASES * 8 + 8 +
+  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)nwaves * ql * lpw * slot_bytes + (size_t)nwaves * LBFT_NPHASES * 8 + 8 +
          (n > 16 ? (size_t)nwaves * lpw * LBFT_MAX_NODES : 0) +
          (n <= 4 && slot_bytes == 8 && hcbr_lds ? (size_t)nwaves * lpw * LBFT_LDS_HCBR_WORDS * 4 : 0);  // class 0, n <= 4: hcbr buffers
 }
 
 __device__ __forceinline__ size_t run_lds_bytes_dev(u32 ql, u32 lpw, u32 slot_bytes, u32 nwaves) {  // = run_lds_bytes(ql, lpw, 0, ..): where the receiver lists start
-  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)nwaves * (ql + LBFT_QPAD(slot_bytes)) * lpw * slot_bytes + (size_t)nwaves * LBFT_NPHASES * 8 + 8;
+  return (size_t)LBFT_TABLE_U64 * 8 + (size_t)nwaves * ql * lpw * slot_bytes + (size_t)nwaves * LBFT_NPHASES * 8 + 8;
 }
-// (opt-in builds, round 4, UNMEASURED: liblbft_hip_w3.so = -DLBFT_LEAN2_WAVES_PER_SIMD=3 -DLBFT_LEAN2_RUN_WAVES=12 -DLBFT_LEAN_NODE_LDS=1
-// -DLBFT_BLK_CACHE_LEAN5=1 -DLBFT_LEAN_AX=0) wavefronts per SIMD / per workgroup of the two large-network kernels lbft_k_run2l / lbft_k_run2q
-#ifndef LBFT_LEAN2_WAVES_PER_SIMD
-#define LBFT_LEAN2_WAVES_PER_SIMD 2
-#endif
-#ifndef LBFT_LEAN2_RUN_WAVES
-#define LBFT_LEAN2_RUN_WAVES LBFT_RUN_WAVES
-#endif
-// ... and of the small-batch kernel lbft_k_run0s (opt-in build liblbft_hip_s4.so = -DLBFT_SMALL_WAVES_PER_SIMD=4 -DLBFT_SMALL_RUN_WAVES=16 -DLBFT_SMALL_NODE_LDS=1
-// -DLBFT_BLK_CACHE_SMALL=1: batches of 2 049..32 768 networks spread over 4 096 wavefronts)
-#ifndef LBFT_SMALL_WAVES_PER_SIMD
-#define LBFT_SMALL_WAVES_PER_SIMD 2
-#endif
-#ifndef LBFT_SMALL_RUN_WAVES
-#define LBFT_SMALL_RUN_WAVES LBFT_RUN_WAVES
-#endif
 #ifndef LBFT_RUN_WAVES_PER_SIMD
 #define LBFT_RUN_WAVES_PER_SIMD 2  // register budget of the class-0 run kernel: 512 / 2 = 256 VGPRs + AGPRs per lane (the
                                    // large-network classes run one 8- or 16-lane wavefront per SIMD and may use all 512)
@@ -128,9 +110,9 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
   for (u32 t = threadIdx.x; t < p.n; t += blockDim.x) t_weights[t] = p.weights[t];
   __syncthreads();
   u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const u32 qslots = p.ql + (SimT<CLS>::QLANE ? LBFT_QLANE_PAD : 0u);  // u64 words per instance in the key area
+  const u32 qslots = p.ql;  // u64 words per instance in the key area
   const u32 qcols = SimT<CLS>::QS32 ? 32u : p.lpw;  // queue columns per wavefront (lbft_k_run0q: always 32, see LBFT_QUAD_STRIDE32)
-  u64* keys = SimT<CLS>::QLANE ? lds + LBFT_TABLE_U64 + ((size_t)wave * p.lpw + lane) * qslots : lds + LBFT_TABLE_U64 + (size_t)wave * p.ql * qcols + lane;
+  u64* keys = lds + LBFT_TABLE_U64 + (size_t)wave * p.ql * qcols + lane;
   u32* metas = reinterpret_cast<u32*>(lds + LBFT_TABLE_U64 + (size_t)nwaves * qslots * qcols) + (size_t)wave * p.ql * qcols + lane;  // (CLS 0: unused, not allocated)
   const u32 meta_words = SimT<CLS>::C0 ? 0u : nwaves * p.ql * p.lpw;
   // Only the first p.lpw lanes of a wavefront carry an instance (occupancy vs lane-utilisation knob).
@@ -148,19 +130,7 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
     // cooperate on the bulk sends of those networks (SimT::run_coop / coop_bulk).
     // (tw may be narrower than the lanes that carry a network: lane j's instance then sits j / tw tiles behind the wavefront's
     // first tile -- folded into the lane's 32-bit column offset, the tile base stays wavefront-uniform)
-#if LBFT_LEAN2_WAVES_PER_SIMD != 2
-    // (three wavefronts per SIMD: 3 072 resident wavefronts make the natural lanes per wavefront a non-power of two -- 16 384 networks: 6 --;
-    // LDS columns are then strided by the next power of two, and a lane that carries no network borrows a valid column)
-    u32 lpwp_ = 1;
-    while (lpwp_ < p.lpw) lpwp_ <<= 1;
-    const u32 lcol_ = lane < p.lpw ? lane : lane % p.lpw;
-#define LBFT_LPWP lpwp_
-#define LBFT_LCOL lcol_
-#else
-#define LBFT_LPWP p.lpw                      /* (the product build: textually the expressions it always had -- its machine code is the profiled one) */
-#define LBFT_LCOL (lane & (p.lpw - 1u))
-#endif
-    const u32 li = active ? (i - ((blockIdx.x * nwaves + wave) * p.lpw)) : LBFT_LCOL;
+    const u32 li = active ? (i - ((blockIdx.x * nwaves + wave) * p.lpw)) : (lane & (p.lpw - 1u));
     SimT<CLS> s(p, tile, (li / tw) * (p.total_words * 4u * tw) + (li & (tw - 1u)) * 4u, 0);
     bool lead = false;
     if (active) lead = s.ld(I_DONE) == 0;
@@ -170,16 +140,11 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
     s.attach_weights(t_weights);
     {  // [receiver lists: nwaves * lpw * LBFT_MAX_NODES bytes][block-record windows: lane-private columns per wavefront]
       u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 12u, nwaves);
-      u32* win = reinterpret_cast<u32*>(lists + (size_t)nwaves * p.lpw * LBFT_MAX_NODES) + (size_t)wave * LBFT_LPWP * p.blw * (1u + BC_WORDS);
+      u32* win = reinterpret_cast<u32*>(lists + (size_t)nwaves * p.lpw * LBFT_MAX_NODES) + (size_t)wave * p.lpw * p.blw * (1u + BC_WORDS);
       u32 wsh = 0;
       while ((1u << wsh) < p.lpw) wsh++;
-      s.attach_blk_window(win + LBFT_LCOL, p.blw, wsh);
+      s.attach_blk_window(win + (lane & (p.lpw - 1u)), p.blw, wsh);
       if (lane < p.lpw) s.blw_reset();
-      if constexpr (SimT<CLS>::CWLDS) {  // [.. windows][the event's node: NF_FIXED_WORDS words per network, lane-private columns per wavefront]
-        u32* nc = reinterpret_cast<u32*>(lists + (size_t)nwaves * p.lpw * LBFT_MAX_NODES) + (size_t)nwaves * LBFT_LPWP * p.blw * (1u + BC_WORDS) +
-                  (size_t)wave * 32u * NF_FIXED_WORDS;  // (columns 32 words apart: SimT::CWSH)
-        s.attach_node_cache(nc + LBFT_LCOL);
-      }
     }
     if (lead) {
       u8* lists = reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 12u, nwaves);
@@ -266,11 +231,6 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
       u32* hcb = reinterpret_cast<u32*>(reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 8u, nwaves));
       s.attach_hcbr(hcb + (size_t)wave * LBFT_LDS_HCBR_WORDS * p.lpw + lane);
     }
-    if constexpr (SimT<CLS>::CWLDS) {  // [.. hcbr buffers (n <= 4)][the event's node: lane-private columns per wavefront, 32 words apart (SimT::CWSH)]
-      u32* nc = reinterpret_cast<u32*>(reinterpret_cast<u8*>(lds) + run_lds_bytes_dev(p.ql, p.lpw, 8u, nwaves)) +
-                (p.n <= 4 ? (size_t)nwaves * LBFT_LDS_HCBR_WORDS * p.lpw : 0) + (size_t)wave * 32u * NF_FIXED_WORDS;
-      s.attach_node_cache(nc + (lane & 31u));
-    }
     s.qlen = 0;
     if (lead) {
       s.load_scalars();
@@ -356,19 +316,17 @@ void lbft_k_run0(Params p, u32* __restrict__ state, u32* __restrict__ unfinished
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run0q(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(9) run_body<9>(p, state, unfinished); }
 // ... and for small batches (at most LBFT_POPC_MAX_LPW networks per wavefront): the pop's scan by all 64 lanes (SimT<8>)
-__global__ __launch_bounds__(64 * LBFT_SMALL_RUN_WAVES) __attribute__((amdgpu_waves_per_eu(LBFT_SMALL_WAVES_PER_SIMD, LBFT_SMALL_WAVES_PER_SIMD)))
+__global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run0s(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(8) run_body<8>(p, state, unfinished); }
-// ... and for ONE network per wavefront, as wavefront-uniform code on the scalar unit (SimT<12>; opt-in: LBFT_UNI=1 -- built in round 4 without GPU
-// time left to measure it: bit-exactness and timing are the first call of round 5)
-#if defined(LBFT_WITH_UNI)  // (not in the product build: the shipped code object stays the one profiles/r04 was taken with)
+// ... and for ONE network per wavefront (batches of <= 2 048 networks), as wavefront-uniform code on the scalar unit (SimT<12>; round 5, measured: 256 / 1 024 / 2 048 x 4
+// networks 4.77 / 4.88 / 4.91 ms against 5.81 / 5.27 / 5.28 ms on lbft_k_run0s; LBFT_NO_UNI=1 falls back to that kernel)
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run0u(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(12) run_body<12>(p, state, unfinished); }
-#endif
 // Large networks without record exchange / trace / lossy network (sim_lean()): also two wavefronts per SIMD (4 spilled registers)
-__global__ __launch_bounds__(64 * LBFT_LEAN2_RUN_WAVES) __attribute__((amdgpu_waves_per_eu(LBFT_LEAN2_WAVES_PER_SIMD, LBFT_LEAN2_WAVES_PER_SIMD)))
+__global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run2l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(5) run_body<5>(p, state, unfinished); }
 // ... and with the record exchange of quirks bit 0 (sim_lean_q1(): requests answered by the peer, responses inserted): 24 spilled registers
-__global__ __launch_bounds__(64 * LBFT_LEAN2_RUN_WAVES) __attribute__((amdgpu_waves_per_eu(LBFT_LEAN2_WAVES_PER_SIMD, LBFT_LEAN2_WAVES_PER_SIMD)))
+__global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
 void lbft_k_run2q(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(7) run_body<7>(p, state, unfinished); }
 // ... and class 1 without them (networks of <= 32 nodes with equivocators, a heap / calendar queue, ...): 22 spilled registers
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
@@ -599,7 +557,7 @@ static thread_local std::string g_err;
 // class-0 batches with few networks per wavefront run lbft_k_run0s (wavefront-wide pop); LBFT_NO_POPC=1: lbft_k_run0 for every batch size
 static bool small_batch_kernel(const Params& p) {
   const char* e = getenv("LBFT_NO_POPC");
-  return LBFT_C0_POPC && !LBFT_C0_QLANE && sim_class(p) == 0 && p.lpw <= LBFT_POPC_MAX_LPW && !(e && atoi(e));
+  return LBFT_C0_POPC && sim_class(p) == 0 && p.lpw <= LBFT_POPC_MAX_LPW && !(e && atoi(e));
 }
 // ... and large batches of the headline network (4 nodes, unit rights, log-normal delays) lbft_k_run0q; LBFT_NO_QUAD=1: lbft_k_run0
 // LBFT_BLK_WINDOW=n: entries (a power of two, default 32; 0 = off) of the large-network kernels' LDS window of block records
@@ -616,15 +574,10 @@ static bool quad_kernel(const Params& p) {
   // networks, or a forced lanes_per_wavefront -- run the generic class-0 kernel)
   return LBFT_C0_QUAD && sim_quad(p) && !small_batch_kernel(p) && !(LBFT_QUAD_STRIDE32 && p.lpw > 32) && !(e && atoi(e));
 }
-// (builds with -DLBFT_WITH_UNI only) LBFT_UNI=1: a small batch with ONE network per wavefront runs lbft_k_run0u (wavefront-uniform code)
+// ... and among them the batches with ONE network per wavefront lbft_k_run0u (wavefront-uniform code on the scalar unit); LBFT_NO_UNI=1: lbft_k_run0s
 static bool uni_kernel(const Params& p) {
-#if defined(LBFT_WITH_UNI)
-  const char* e = getenv("LBFT_UNI");
-  return small_batch_kernel(p) && p.lpw == 1 && e && atoi(e);
-#else
-  (void)p;
-  return false;
-#endif
+  const char* e = getenv("LBFT_NO_UNI");
+  return small_batch_kernel(p) && p.lpw == 1 && !(e && atoi(e));
 }
 static bool lean_allowed() { const char* e = getenv("LBFT_NO_LEAN"); return !(e && atoi(e)); }
 static bool lean2_allowed() { const char* e = getenv("LBFT_LEAN2"); return lean_allowed() && !(e && !atoi(e)); }
@@ -1153,7 +1106,7 @@ int lbft_batch_layout(const lbft_batch* b, uint32_t* out) {
   out[6] = p.lpw;             // lanes per wavefront carrying an instance
   out[7] = (uint32_t)sim_class(p) | (p.qheap << 8) | (p.qcal << 9) | ((((sim_lean(p) && lean2_allowed()) || (sim_lean1(p) && lean_allowed())) ? 1u : 0u) << 10) | ((p.ring ? 1u : 0u) << 11) |
            (((sim_lean_q1(p) && lean2_allowed()) ? 1u : 0u) << 12) | ((small_batch_kernel(p) ? 1u : 0u) << 13) |
-           ((quad_kernel(p) ? 1u : 0u) << 14);
+           ((quad_kernel(p) ? 1u : 0u) << 14) | ((uni_kernel(p) ? 1u : 0u) << 15);
   return LBFT_OK;
 }
 
@@ -1264,22 +1217,10 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
     // per SIMD, 24.4 ms at 32 = two per SIMD, 40.1 ms at 16 = two rounds; 1024 x 4 nodes: 22.9 ms at 8 lanes, 17.6 at 4,
     // 13.2 at 2, 9.4 ms at ONE network per wavefront; 8192 x 100 nodes: 9.0 s at 16 lanes, 5.9 s at 8, 7.8 s at 4 = two rounds).
     const bool lean2k = sim_lean(p) && lean2_allowed();
-    u64 resident = lean2k ? 1024 * LBFT_LEAN2_WAVES_PER_SIMD : (sim_class(p) == 0 || (sim_lean1(p) && lean_allowed())) ? 2048 : 1024 * LBFT_BIG_WAVES_PER_SIMD;
+    u64 resident = (lean2k || sim_class(p) == 0 || (sim_lean1(p) && lean_allowed())) ? 2048 : 1024 * LBFT_BIG_WAVES_PER_SIMD;
     u64 want = (b->m + resident - 1) / resident;
     lpw = 1;
     while (lpw < want && lpw < 32) lpw <<= 1;
-#if LBFT_LEAN2_WAVES_PER_SIMD != 2
-    // (3 072 resident wavefronts: the fewest lanes that fit the batch are rarely a power of two; the calendar queue has no LDS columns to stride)
-    if (lean2k && p.qcal) lpw = want < 1 ? 1u : want > 32 ? 32u : (u32)want;
-#endif
-#if LBFT_SMALL_WAVES_PER_SIMD != 2
-    // (the small-batch kernel compiled for more wavefronts per SIMD: batches that fit its residency within its lanes per wavefront are spread over it)
-    if (sim_class(p) == 0 && LBFT_C0_POPC && !LBFT_C0_QLANE && b->m <= 1024ull * LBFT_SMALL_WAVES_PER_SIMD * LBFT_POPC_MAX_LPW) {
-      u64 want_s = (b->m + 1024ull * LBFT_SMALL_WAVES_PER_SIMD - 1) / (1024ull * LBFT_SMALL_WAVES_PER_SIMD);
-      lpw = 1;
-      while (lpw < want_s) lpw <<= 1;
-    }
-#endif
   }
   p.lpw = lpw;
   // Tile width of the HBM layout (lbft_core.h "HBM layout"): 64 for the small-network classes 0 and 1, 1 (instance-major) for large networks
@@ -1299,7 +1240,7 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   // wavefronts per workgroup of the kernel this batch runs on: 8 = both wavefront slots of a CU's four SIMDs for the kernels compiled
   // for two wavefronts per SIMD, 4 for the full-register ones
   const bool two_wave_kernel = sim_class(p) == 0 || (sim_lean(p) && lean2_allowed()) || (sim_lean1(p) && lean_allowed());
-  const u32 nwaves = (sim_lean(p) && lean2_allowed()) ? LBFT_LEAN2_RUN_WAVES : small_batch_kernel(p) ? LBFT_SMALL_RUN_WAVES : two_wave_kernel ? LBFT_RUN_WAVES : LBFT_RUN_WAVES_FULL;
+  const u32 nwaves = two_wave_kernel ? LBFT_RUN_WAVES : LBFT_RUN_WAVES_FULL;
   b->run_waves = nwaves;
   // LDS queue slots per instance: what one CU's LDS affords when it hosts 64/lpw workgroups
   u32 wg_per_cu = (64 / lpw) * 4 / nwaves;  // workgroups that make up a CU's 256 instances
@@ -1316,33 +1257,26 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   const bool quadk = quad_kernel(p);  // (the kernel choice only depends on the layout and lpw)
   const bool hcbr_lds = !(LBFT_C0_IMAJOR && LBFT_C0_HCREG && quadk);
   const u32 qcols = (quadk && LBFT_QUAD_STRIDE32) ? 32u : lpw;  // queue columns per wavefront in LDS (SimT::QS32)
-  // (opt-in four-wavefront build of the small-batch kernel: the LDS columns of the event's node come out of the queue's budget)
-  const size_t small_nc_bytes = (LBFT_SMALL_NODE_LDS && small_batch_kernel(p)) ? (size_t)nwaves * 32u * NF_FIXED_WORDS * 4u : 0;
-  u32 ql_auto = (u32)((budget - small_nc_bytes - run_lds_bytes(0, qcols, n, slot_bytes, nwaves, hcbr_lds) - 2048) / (slot_bytes * nwaves * qcols));  // (run_lds_bytes(0, ..) includes the lane padding)
+  u32 ql_auto = (u32)((budget - run_lds_bytes(0, qcols, n, slot_bytes, nwaves, hcbr_lds) - 2048) / (slot_bytes * nwaves * qcols));  // (run_lds_bytes(0, ..) includes the lane padding)
   const u32 ql_max = quadk ? LBFT_PACKED_QL_QUAD : LBFT_PACKED_QL_MAX, pop_batch = quadk ? LBFT_POP_BATCH_QUAD : LBFT_POP_BATCH;
   if (p.qpack && ql_auto > ql_max) ql_auto = ql_max;
   u32 ql = b->ql < 0 ? ql_auto : (u32)b->ql;
   if (ql > qcap) ql = qcap;
   if (p.qpack) ql -= ql % pop_batch;  // scanned in batches (SimT::PB)
   if (p.qcal) ql = 0;  // the calendar lives in HBM rows
-  if (run_lds_bytes(ql, qcols, n, slot_bytes, nwaves, hcbr_lds) + small_nc_bytes > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
+  if (run_lds_bytes(ql, qcols, n, slot_bytes, nwaves, hcbr_lds) > 160u * 1024u) { g_err = "LDS queue slots do not fit the CU's 160 KiB"; return LBFT_ERR_INVALID; }
   p.ql = ql;
   b->lds_bytes = run_lds_bytes(ql, qcols, n, slot_bytes, nwaves, hcbr_lds);
   // large networks: the LDS that the calendar queue leaves unused holds a window of block records per network (SimT::attach_blk_window)
   p.blw = 0;
   // (measured, round 4: c4live 2.77 -> 2.76 s, c5live 4.72 -> 4.60 s with 32 entries, 4.58 s with 64; the kernel without the record exchange
   // LOSES with it -- c4 346 -> 357 ms, c5 1.90 -> 1.98 s, its three register records already serve it -- and does not get one)
-  u32 lpwp = 1;  // LDS columns per wavefront of the large-network kernels: lpw padded to a power of two (equal to it in the product build)
-  while (lpwp < lpw) lpwp <<= 1;
-  const size_t node_cache_bytes = (LBFT_LEAN_NODE_LDS && sim_lean(p) && lean2_allowed()) ? (size_t)nwaves * 32u * NF_FIXED_WORDS * 4u : 0;  // (columns 32 words apart: SimT::CWSH)
   if (sim_lean_q1(p) && lean2_allowed() && blk_window_allowed()) {
     u32 e = blk_window_max();
-    while (e && b->lds_bytes + node_cache_bytes + blk_window_bytes(e, lpwp, nwaves) > 150u * 1024u) e >>= 1;
+    while (e && b->lds_bytes + blk_window_bytes(e, lpw, nwaves) > 150u * 1024u) e >>= 1;
     p.blw = e;
-    b->lds_bytes += blk_window_bytes(e, lpwp, nwaves);
+    b->lds_bytes += blk_window_bytes(e, lpw, nwaves);
   }
-  b->lds_bytes += node_cache_bytes;  // (behind the windows: run_body)
-  b->lds_bytes += small_nc_bytes;  // (behind the hcbr buffers: run_body)
   p.prof = b->d_prof;
   return LBFT_OK;
 }
@@ -1387,9 +1321,7 @@ static int launch_run(lbft_batch* b) {
   const bool quad0 = quad_kernel(p);
   const bool uni0 = cls == 0 && uni_kernel(p);
   const void* run_fn = leanq ? reinterpret_cast<const void*>(lbft_k_run2q) : lean ? reinterpret_cast<const void*>(lbft_k_run2l) : lean1 ? reinterpret_cast<const void*>(lbft_k_run1l) :
-#if defined(LBFT_WITH_UNI)
                        uni0 ? reinterpret_cast<const void*>(lbft_k_run0u) :
-#endif
                        (cls == 0 && small0) ? reinterpret_cast<const void*>(lbft_k_run0s) : (cls == 0 && quad0) ? reinterpret_cast<const void*>(lbft_k_run0q) : cls == 0 ? reinterpret_cast<const void*>(lbft_k_run0)
                      : cls == 1 ? reinterpret_cast<const void*>(lbft_k_run<1>) : reinterpret_cast<const void*>(lbft_k_run<2>);
   HIP_TRY(hipFuncSetAttribute(run_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
@@ -1400,9 +1332,7 @@ static int launch_run(lbft_batch* b) {
   if (leanq) lbft_k_run2q<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (lean) lbft_k_run2l<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (lean1) lbft_k_run1l<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
-#if defined(LBFT_WITH_UNI)
   else if (uni0) lbft_k_run0u<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
-#endif
   else if (cls == 0 && small0) lbft_k_run0s<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (cls == 0 && quad0) lbft_k_run0q<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (cls == 0) lbft_k_run0<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);

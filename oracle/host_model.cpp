@@ -125,8 +125,6 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
     if (p.ql) s.attach_hcbr(hcbr.data());
     std::vector<u32> window(32 * (1 + BC_WORDS), 0);  // the large-network kernels' LDS window of block records (32 entries, as the device's default)
     if (p.n > 32) s.attach_blk_window(window.data(), 32, 0);
-    std::vector<u32> node_cache(NF_FIXED_WORDS, 0);  // (-DLBFT_LEAN_NODE_LDS=1 builds: the device's LDS column of the event's node)
-    s.attach_node_cache(node_cache.data());
     s.load_scalars();
     s.queue_to_lds();
     s.hcbr_to_lds();

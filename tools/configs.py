@@ -70,7 +70,7 @@ def kernel_name(layout):
     k = layout["kernel_class"]
     cls, lean = k & 255, bool(k & 1024)
     if cls == 0:
-        return "lbft_k_run0s" if k & 8192 else "lbft_k_run0q" if k & 16384 else "lbft_k_run0"
+        return "lbft_k_run0u" if k & 32768 else "lbft_k_run0s" if k & 8192 else "lbft_k_run0q" if k & 16384 else "lbft_k_run0"
     if lean:
         return ("lbft_k_run2q" if k & 4096 else "lbft_k_run2l") if cls == 2 else "lbft_k_run1l"
     return "lbft_k_run<%d>" % cls
