@@ -45,7 +45,7 @@ def parse():
                     help="(N = 1, rocprofv3 on the box) re-collect FETCH_SIZE / WRITE_SIZE of the run kernel in two child runs of this command and report "
                          "them as roofline.traffic_measured_here beside the value replayed from the committed profile")
     ap.add_argument("--native-collective", action="store_true",
-                    help="also aggregate the counters through the C ABI's own collective (lbft_batch_counters_allreduce: ncclAllGather on a "
+                    help="also aggregate the counters through the C ABI's own collective (lbft_batch_counters_allgather_reduce: ncclAllGather on a "
                          "communicator built with ncclCommInitRank, one device per rank) and check it against the torch.distributed aggregate")
     return ap.parse_args()
 
@@ -166,7 +166,7 @@ def measured_issue():
 
 def native_collective(res, rank, world, local_rank):
     """The C ABI's own collective on N ranks: a RCCL communicator built here with ncclCommInitRank (the unique id travels through
-    torch.distributed's object broadcast), then lbft_batch_counters_allreduce = ONE ncclAllGather on the batch's stream."""
+    torch.distributed's object broadcast), then lbft_batch_counters_allgather_reduce = ONE ncclAllGather on the batch's stream."""
     import ctypes
     import torch.distributed as dist
     rccl = ctypes.CDLL("librccl.so.1")
@@ -187,7 +187,7 @@ def native_collective(res, rank, world, local_rank):
     if rc != 0:
         raise RuntimeError("ncclCommInitRank failed: %d" % rc)
     try:
-        return res.counters_allreduce(comm.value)
+        return res.counters_allgather_reduce(comm.value)
     finally:
         rccl.ncclCommDestroy(comm)
 

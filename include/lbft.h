@@ -177,7 +177,8 @@ int lbft_batch_save_node(const lbft_batch* b, size_t inst, uint32_t node, void* 
  * is refused with LBFT_ERR_STATE ("refusing to restore saved state from the future") and nothing is written.  Records are identified
  * by their hashes among the records of the instance's block pool: an image saved from this instance (any node, now or earlier), from
  * another batch run with the same seed and configuration, or by the reference / the oracle for the same run loads; an image that names
- * a record the pool does not hold is LBFT_ERR_UNSUPPORTED, one saved under another configuration (nodes, voting rights, NodeConfig) or
+ * a record the pool does not hold is LBFT_ERR_UNSUPPORTED (and so is an image with retired record stores loaded into a batch created without
+ * lbft_batch_keep_retired_stores: they would be dropped silently and the node could not be saved again), one saved under another configuration (nodes, voting rights, NodeConfig) or
  * malformed is LBFT_ERR_INVALID -- in every failing case the node is left untouched.  Written: the NodeState (record store with the
  * node's blocks / certificates / timeouts / votes / election, pacemaker, epoch, voting constraints, commit tracker, retired record
  * stores).  Not written: what the reference keeps outside NodeState -- the simulator's timer bookkeeping and startup time
@@ -191,6 +192,8 @@ int lbft_batch_load_node(lbft_batch* b, size_t inst, uint32_t node, const void* 
  * gather_rows).  `nccl_comm` is the caller's ncclComm_t for this batch's device (any
  * host language: the library loads librccl itself, on first use); the collective runs on the batch's stream.  `out` receives the
  * aggregate; launches is this rank's.  Every rank of the communicator must call it. */
+int lbft_batch_counters_allgather_reduce(lbft_batch* b, void* nccl_comm, lbft_counters* out);
+/* The same call under the name it had through round 4 (it never issued an all-reduce); kept for existing bindings. */
 int lbft_batch_counters_allreduce(lbft_batch* b, void* nccl_comm, lbft_counters* out);
 /* past_record_stores kept in full: at every epoch change the node's rows (record-store fields, timeouts, votes, election) are copied
  * into an archive entry of the epoch being left -- num_nodes x epochs x one node's rows of device memory per instance.  Call before

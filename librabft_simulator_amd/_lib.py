@@ -122,7 +122,7 @@ ABI_SYMBOLS = [
     "lbft_batch_device_bytes", "lbft_batch_set_max_steps", "lbft_batch_set_lanes_per_wavefront",
     "lbft_batch_set_lds_queue_slots", "lbft_batch_set_calendar_queue", "lbft_batch_phase_cycles", "lbft_batch_layout",
     "lbft_batch_run_steps", "lbft_batch_checkpoint_bytes", "lbft_batch_checkpoint_save", "lbft_batch_checkpoint_load",
-    "lbft_batch_enable_round_trace", "lbft_batch_keep_retired_stores", "lbft_batch_counters_allreduce", "lbft_node_calls", "lbft_batch_round_switches", "lbft_batch_manual_begin", "lbft_batch_manual_finalize", "lbft_node_update", "lbft_node_create_notification",
+    "lbft_batch_enable_round_trace", "lbft_batch_keep_retired_stores", "lbft_batch_counters_allreduce", "lbft_batch_counters_allgather_reduce", "lbft_node_calls", "lbft_batch_round_switches", "lbft_batch_manual_begin", "lbft_batch_manual_finalize", "lbft_node_update", "lbft_node_create_notification",
     "lbft_node_handle_notification", "lbft_node_release_notification", "lbft_node_create_request", "lbft_node_handle_request",
     "lbft_node_handle_response", "lbft_node_view_get", "lbft_device_leaders", "lbft_device_sample_delays",
     "lbft_device_exp_log", "lbft_last_error", "lbft_build_info",
@@ -139,25 +139,40 @@ class LbftError(RuntimeError):
 
 def _needed_hip_soname(path, tag_wanted=1):
     """DT_NEEDED entry of `path` that names the HIP runtime (e.g. "libamdhip64.so.7"; tag_wanted = 14: the file's own DT_SONAME), or
-    None (pure-Python ELF walk)."""
+    None.  Pure-Python ELF walk that reads only the ELF header, the section headers and the .dynamic / .dynstr sections (seek + read:
+    torch's libamdhip64.so is tens of MB).  A file that cannot be parsed raises ValueError: the caller must not guess."""
     import struct
-    try:
-        blob = open(path, "rb").read()
-        shoff, = struct.unpack_from("<Q", blob, 0x28)
-        shentsize, shnum, _ = struct.unpack_from("<HHH", blob, 0x3A)
-        secs = [struct.unpack_from("<IIQQQQII", blob, shoff + i * shentsize) for i in range(shnum)]
-        for name, typ, flags, addr, off, size, link, info in secs:
-            if typ == 6:  # SHT_DYNAMIC
-                _, _, _, _, stroff, strsize, _, _ = secs[link]
-                for k in range(size // 16):
-                    tag, val = struct.unpack_from("<qQ", blob, off + 16 * k)
-                    if tag == tag_wanted:  # DT_NEEDED = 1, DT_SONAME = 14
-                        s = blob[stroff + val:blob.index(b"\0", stroff + val)].decode()
-                        if s.startswith("libamdhip64"):
-                            return s
-    except Exception:
-        pass
+    with open(path, "rb") as f:
+        head = f.read(0x40)
+        if len(head) < 0x40 or head[:4] != b"\x7fELF" or head[4] != 2 or head[5] != 1:
+            raise ValueError("%s: not a little-endian 64-bit ELF file" % path)
+        shoff, = struct.unpack_from("<Q", head, 0x28)
+        shentsize, shnum, _ = struct.unpack_from("<HHH", head, 0x3A)
+        if shentsize < 0x40 or shnum == 0 or shnum > 65535:
+            raise ValueError("%s: no section headers" % path)
+        f.seek(shoff)
+        table = f.read(shentsize * shnum)
+        secs = [struct.unpack_from("<IIQQQQII", table, i * shentsize) for i in range(shnum)]
+        for _name, typ, _flags, _addr, off, size, link, _info in secs:
+            if typ != 6:  # SHT_DYNAMIC
+                continue
+            if link >= shnum:
+                raise ValueError("%s: .dynamic without a string table" % path)
+            stroff, strsize = secs[link][4], secs[link][5]
+            f.seek(off)
+            dyn = f.read(size)
+            f.seek(stroff)
+            strtab = f.read(strsize)
+            for k in range(len(dyn) // 16):
+                tag, val = struct.unpack_from("<qQ", dyn, 16 * k)
+                if tag == tag_wanted and val < len(strtab):  # DT_NEEDED = 1, DT_SONAME = 14
+                    s = strtab[val:strtab.index(b"\0", val)].decode()
+                    if s.startswith("libamdhip64"):
+                        return s
     return None
+
+
+from struct import error as struct_error  # noqa: E402
 
 
 def _one_hip_runtime():
@@ -181,7 +196,15 @@ def _one_hip_runtime():
     path = os.path.join(libdir, "libamdhip64.so")
     if not os.path.exists(path):
         return
-    want, have = _needed_hip_soname(LIB_PATH), _needed_hip_soname(path, 14)
+    try:
+        want, have = _needed_hip_soname(LIB_PATH), _needed_hip_soname(path, 14)
+    except (OSError, ValueError, struct_error) as e:
+        # (round-4 advisor: a parse failure used to fall through to "map torch's runtime whatever its version")  Unknown sonames = no
+        # evidence that torch's copy is the runtime this library was linked against: leave the choice to the dynamic loader and say so.
+        import warnings
+        warnings.warn("librabft_simulator_amd: could not read the HIP runtime sonames (%s); torch's bundled libamdhip64 is NOT pre-loaded -- import torch "
+                      "before this package if both are used in one process" % e)
+        return
     if want and have and want != have:
         return  # torch bundles a runtime of another soname than this library needs: leave it to the loader (/opt/rocm)
     C.CDLL(path, mode=C.RTLD_GLOBAL)
@@ -247,8 +270,9 @@ def lib():
     L.lbft_batch_checkpoint_load.restype = C.c_int
     L.lbft_node_calls.argtypes = [vp, C.POINTER(LbftNodeCall), C.c_size_t, C.POINTER(LbftNodeResult)]
     L.lbft_node_calls.restype = C.c_int
-    L.lbft_batch_counters_allreduce.argtypes = [vp, vp, C.POINTER(LbftCounters)]
-    L.lbft_batch_counters_allreduce.restype = C.c_int
+    for fn in (L.lbft_batch_counters_allreduce, L.lbft_batch_counters_allgather_reduce):
+        fn.argtypes = [vp, vp, C.POINTER(LbftCounters)]
+        fn.restype = C.c_int
     L.lbft_batch_keep_retired_stores.argtypes = [vp, C.c_int]
     L.lbft_batch_keep_retired_stores.restype = C.c_int
     L.lbft_batch_enable_round_trace.argtypes = [vp, C.c_uint32]

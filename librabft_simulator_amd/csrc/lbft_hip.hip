@@ -555,9 +555,19 @@ static thread_local std::string g_err;
 // 451 ms; with the staging 476-511 ms; the full-register kernel with twice the lanes 503 ms; 8 192 x 100 nodes: 2.49 / 2.75-2.85 / 2.85 s).
 // Tuning knobs: LBFT_NO_LEAN=1 = always the full-register kernels; LBFT_LEAN2=0 = the full-register kernel for large networks.
 // class-0 batches with few networks per wavefront run lbft_k_run0s (wavefront-wide pop); LBFT_NO_POPC=1: lbft_k_run0 for every batch size
+static bool quad_eligible(const Params& p) {
+  const char* e = getenv("LBFT_NO_QUAD");
+  // (its LDS queue columns are 32 lanes apart at compile time, LBFT_QUAD_STRIDE32: 64 networks per wavefront -- batches beyond 131 072
+  // networks, or a forced lanes_per_wavefront -- run the generic class-0 kernel)
+  return LBFT_C0_QUAD && sim_quad(p) && !(LBFT_QUAD_STRIDE32 && p.lpw > 32) && !(e && atoi(e));
+}
+// (round 5: since round 4's work on lbft_k_run0q the lane-private kernel beats the wavefront-wide pop at EVERY batch size of the headline network --
+// 2 048 / 4 096 / 8 192 / 16 384 x 4: 4.78 / 6.48 / 8.23 / 10.36 ms against 4.90 / 7.41 / 9.42 / 12.19 -- so lbft_k_run0s / lbft_k_run0u now serve the
+// class-0 batches that kernel does not take: other sizes, weighted rights, uniform delays -- 4 096 / 8 192 / 16 384 x 4 uniform: 7.23 / 9.40 / 11.94 ms against
+// 8.37 / 10.82 / 13.85 on lbft_k_run0; 1 024 x 4 uniform on lbft_k_run0u: 4.71 against 5.11)
 static bool small_batch_kernel(const Params& p) {
   const char* e = getenv("LBFT_NO_POPC");
-  return LBFT_C0_POPC && sim_class(p) == 0 && p.lpw <= LBFT_POPC_MAX_LPW && !(e && atoi(e));
+  return LBFT_C0_POPC && sim_class(p) == 0 && p.lpw <= LBFT_POPC_MAX_LPW && !quad_eligible(p) && !(e && atoi(e));
 }
 // ... and large batches of the headline network (4 nodes, unit rights, log-normal delays) lbft_k_run0q; LBFT_NO_QUAD=1: lbft_k_run0
 // LBFT_BLK_WINDOW=n: entries (a power of two, default 32; 0 = off) of the large-network kernels' LDS window of block records
@@ -568,12 +578,7 @@ static u32 blk_window_max() {
   return v > 256u ? 256u : v;
 }
 static bool blk_window_allowed() { return blk_window_max() != 0; }
-static bool quad_kernel(const Params& p) {
-  const char* e = getenv("LBFT_NO_QUAD");
-  // (its LDS queue columns are 32 lanes apart at compile time, LBFT_QUAD_STRIDE32: 64 networks per wavefront -- batches beyond 131 072
-  // networks, or a forced lanes_per_wavefront -- run the generic class-0 kernel)
-  return LBFT_C0_QUAD && sim_quad(p) && !small_batch_kernel(p) && !(LBFT_QUAD_STRIDE32 && p.lpw > 32) && !(e && atoi(e));
-}
+static bool quad_kernel(const Params& p) { return quad_eligible(p); }
 // ... and among them the batches with ONE network per wavefront lbft_k_run0u (wavefront-uniform code on the scalar unit); LBFT_NO_UNI=1: lbft_k_run0s
 static bool uni_kernel(const Params& p) {
   const char* e = getenv("LBFT_NO_UNI");
@@ -1680,7 +1685,7 @@ nccl_commcount_fn g_nccl_commcount = nullptr;
 const int kNcclUint64 = 5;  // rccl.h: ncclUint64 = 5
 const size_t kCounterWords = 14;
 }
-int lbft_batch_counters_allreduce(lbft_batch* b, void* nccl_comm, lbft_counters* out) {
+int lbft_batch_counters_allgather_reduce(lbft_batch* b, void* nccl_comm, lbft_counters* out) {
   if (!b || !nccl_comm || !out) return LBFT_ERR_INVALID;
   if (!b->ran) { g_err = "run the batch first"; return LBFT_ERR_STATE; }
   if (!g_nccl_allgather) {
@@ -1707,14 +1712,17 @@ int lbft_batch_counters_allreduce(lbft_batch* b, void* nccl_comm, lbft_counters*
   std::vector<unsigned long long> all((size_t)world * kCounterWords);
   int st = LBFT_OK;
   do {
-    if (hipMemcpyAsync(d, mine, sizeof(mine), hipMemcpyHostToDevice, b->stream) != hipSuccess) { st = LBFT_ERR_HIP; break; }
+    hipError_t he = hipMemcpyAsync(d, mine, sizeof(mine), hipMemcpyHostToDevice, b->stream);
+    if (he != hipSuccess) { st = hip_fail(he, "hipMemcpyAsync (counters to device)"); break; }
     rc = g_nccl_allgather(d, d + kCounterWords, kCounterWords, kNcclUint64, nccl_comm, b->stream);
     if (rc != 0) { g_err = "ncclAllGather failed with ncclResult_t " + std::to_string(rc); st = LBFT_ERR_HIP; break; }
-    if (hipMemcpyAsync(all.data(), d + kCounterWords, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream) != hipSuccess) { st = LBFT_ERR_HIP; break; }
-    if (hipStreamSynchronize(b->stream) != hipSuccess) { st = LBFT_ERR_HIP; break; }
+    he = hipMemcpyAsync(all.data(), d + kCounterWords, all.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream);
+    if (he != hipSuccess) { st = hip_fail(he, "hipMemcpyAsync (gathered counters to host)"); break; }
+    he = hipStreamSynchronize(b->stream);
+    if (he != hipSuccess) { st = hip_fail(he, "hipStreamSynchronize (after ncclAllGather)"); break; }
   } while (0);
   if (d_big) hipFree(d_big);
-  if (st != LBFT_OK) { if (st == LBFT_ERR_HIP && g_err.empty()) g_err = "HIP error in lbft_batch_counters_allreduce"; return st; }
+  if (st != LBFT_OK) return st;  // (every failing path above set the error text itself)
   unsigned long long h[kCounterWords] = {0};
   for (int r = 0; r < world; r++)
     for (size_t k = 0; k < kCounterWords; k++) {
@@ -1727,6 +1735,8 @@ int lbft_batch_counters_allreduce(lbft_batch* b, void* nccl_comm, lbft_counters*
   out->timers_folded = h[9]; out->node_updates = h[10]; out->max_queue = h[11]; out->max_snapshots = h[12]; out->max_blocks = h[13];
   return LBFT_OK;
 }
+// (the name the entry point had through round 4: it never was an all-reduce -- kept so that existing bindings keep linking)
+int lbft_batch_counters_allreduce(lbft_batch* b, void* nccl_comm, lbft_counters* out) { return lbft_batch_counters_allgather_reduce(b, nccl_comm, out); }
 
 int lbft_batch_faults(const lbft_batch* b, uint32_t* out) {
   if (!b || !out) return LBFT_ERR_INVALID;

@@ -442,6 +442,13 @@ inline int load_node_image(const Params& dp, u32* hw, u32 node, const u32* weigh
     }
     return hcc;
   };
+  // The reference's load_node restores past_record_stores in full (node.rs:43).  A batch created without lbft_batch_keep_retired_stores has nowhere to
+  // put them: loading such an image there would drop them silently and the node could not be saved again (save_node needs the archive) -- refused.
+  if (!past.empty() && hp.rarch_words == 0) {
+    err = "load_node: the image carries retired record stores (past_record_stores, node.rs:43) and this batch does not archive them: create it with "
+          "lbft_batch_keep_retired_stores(batch, 1) before the run";
+    return -3;
+  }
   // every epoch the image has no store for: the node holds none of its records
   {
     std::vector<u64> have;

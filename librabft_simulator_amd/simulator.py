@@ -138,8 +138,15 @@ class BatchResult:
     def __init__(self, sim):
         self._sim = sim
         self._cache = {}
+        self._gen = getattr(sim, "_state_generation", 0)
 
     def _get(self, key, fn):
+        # what was read back belongs to the device state it was read from: BatchSimulator.load_node rewrites a node's rows (pacemaker round,
+        # epoch, certificates ...) after the run, and a result object created before it must not serve the pre-load values
+        gen = getattr(self._sim, "_state_generation", 0)
+        if gen != self._gen:
+            self._cache.clear()
+            self._gen = gen
         if key not in self._cache:
             self._cache[key] = fn()
         return self._cache[key]
@@ -152,12 +159,15 @@ class BatchResult:
             return c.as_dict()
         return self._get("counters", f)
 
-    def counters_allreduce(self, nccl_comm):
-        """The run's one collective, natively: RCCL ncclAllReduce of the throughput counters over the caller's communicator (an
-        ncclComm_t as an integer / ctypes pointer; every rank calls it).  Returns the aggregate as a dict."""
+    def counters_allgather_reduce(self, nccl_comm):
+        """The run's one collective, natively: ONE RCCL ncclAllGather of the fourteen counter words per rank over the caller's communicator
+        (an ncclComm_t as an integer / ctypes pointer; every rank calls it), reduced locally -- sums and high-water marks.  Returns the
+        aggregate as a dict."""
         c = LbftCounters()
-        check(_lib.lib().lbft_batch_counters_allreduce(self._sim._h, C.c_void_p(int(nccl_comm)), C.byref(c)))
+        check(_lib.lib().lbft_batch_counters_allgather_reduce(self._sim._h, C.c_void_p(int(nccl_comm)), C.byref(c)))
         return c.as_dict()
+
+    counters_allreduce = counters_allgather_reduce  # (the name through round 4)
 
     def _node_array(self, name, dtype):
         def f():
@@ -387,6 +397,7 @@ class BatchSimulator:
         for an image naming records this instance's block pool does not hold.  The node is untouched when it raises."""
         buf = np.frombuffer(bytes(image), dtype=np.uint8)
         check(_lib.lib().lbft_batch_load_node(self._h, int(instance), int(node), buf.ctypes.data, len(buf), int(node_time)))
+        self._state_generation = getattr(self, "_state_generation", 0) + 1  # (BatchResult objects drop what they read back before)
 
     def reset(self):
         check(_lib.lib().lbft_batch_reset(self._h))

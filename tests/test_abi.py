@@ -147,10 +147,10 @@ def test_uniform_kernel_compiles_to_scalar_code(hiplib):
     """lbft_k_run0u (SimT<12>: batches with one network per wavefront; round 5: 1 024 x 4 networks 4.88 ms against 5.27 on lbft_k_run0s): nothing in
     its event loop depends on the lane, so that the compiler keeps the step on the scalar unit.  One source of divergence slipping in -- an
     inline-asm pin, a flat load, the return value of an out-of-line helper -- silently turns the whole loop back into masked vector code:
-    the register budget tells (~100 VGPRs when uniform, ~200 as vector code)."""
+    the register budget tells (162 VGPRs in the product build -- most of them lanes that park scalar state --, 215+ as vector code: lbft_k_run0s)."""
     from librabft_simulator_amd import build
     k = [v for name, v in _kernel_metadata(build.OUT).items() if "lbft_k_run0u" in name]
-    assert len(k) == 1 and k[0]["vgpr_count"] <= 128 and k[0]["private_segment_fixed_size"] == 0, k
+    assert len(k) == 1 and k[0]["vgpr_count"] <= 176 and k[0]["private_segment_fixed_size"] == 0, k
 
 
 def test_kernel_hash_reads_the_code_object(hiplib):
@@ -176,6 +176,16 @@ def test_kernel_names_from_the_layout_flag_word():
                      (2 | 256 | 512 | 1024 | 2048, "lbft_k_run2l"), (2 | 256 | 512 | 1024 | 2048 | 4096, "lbft_k_run2q")):
         assert bench.run_kernel_name(kc) == name
         assert configs.kernel_name({"kernel_class": kc}) == name
+
+
+def test_hip_soname_reader_reads_only_the_dynamic_section_and_refuses_garbage(hiplib, tmp_path):
+    """_lib._needed_hip_soname: the HIP runtime this library was linked against / the soname of torch's bundled copy, read with seeks (not
+    by slurping tens of MB); a file that is not an ELF object raises instead of letting the caller guess (round-4 advisor)."""
+    assert hiplib._needed_hip_soname(hiplib.LIB_PATH).startswith("libamdhip64.so")
+    junk = tmp_path / "junk.so"
+    junk.write_bytes(b"not an elf file" * 100)
+    with pytest.raises(ValueError):
+        hiplib._needed_hip_soname(str(junk))
 
 
 def test_one_hip_runtime_whichever_of_torch_and_the_library_comes_first(hiplib):

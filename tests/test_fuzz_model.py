@@ -113,7 +113,7 @@ def test_random_large_configurations_on_the_cooperative_loop(oracle, chunk):
 
 # LBFT_FUZZ_GPU_CHUNKS=n widens the device run (10 configurations per chunk; the default keeps `pytest -m gpu` short)
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_CHUNKS", "5"))))
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_CHUNKS", "8"))))
 def test_random_configurations_on_the_device_match_the_oracle(oracle, chunk):
     import librabft_simulator_amd as amd
     rng = np.random.default_rng(777 + chunk)
@@ -150,10 +150,10 @@ def test_random_configurations_on_the_device_match_the_oracle(oracle, chunk):
 
 # The headline network's own kernel (lbft_k_run0q: 4 nodes, unit voting rights, log-normal delays, <= 64 snapshot slots, fixed at
 # compile time; pairs of lanes scanning a queue): everything else about the configuration drawn at random -- pacemaker parameters,
-# epoch lengths, delay mean / variance, equivocators, loss, partitions, Q2 -- with 16 / 32 / 64 networks per wavefront and launches
+# epoch lengths, delay mean / variance, equivocators, loss, partitions, Q2 -- with 1 .. 64 networks per wavefront and launches
 # cut into pieces.  At least half of the draws must have run on that kernel (the rest: the general small-network kernel).
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_QUAD_CHUNKS", "2"))))
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_QUAD_CHUNKS", "5"))))
 def test_random_headline_network_configurations_on_the_device_match_the_oracle(oracle, chunk):
     import librabft_simulator_amd as amd
     rng = np.random.default_rng(31337 + chunk)
@@ -184,7 +184,7 @@ def test_random_headline_network_configurations_on_the_device_match_the_oracle(o
         sim = amd.BatchSimulator.new(seeds, n, amd.RandomDelay.new(kw["mean"], kw["variance"]), nc, commands_per_epoch=kw.get("commands_per_epoch", 30000),
                                      equivocate_every=kw.get("equivocate_every", 0), drop_per_million=kw.get("drop_per_million", 0), partition=part,
                                      quirks=kw.get("quirks", 0), calendar_queue=bool(rng.random() < 0.3), max_steps_per_launch=int(rng.choice([0, 0, 173])),
-                                     lanes_per_wavefront=int(rng.choice([16, 32, 64])), block_capacity=max_clock + 64)
+                                     lanes_per_wavefront=int(rng.choice([1, 2, 4, 8, 16, 32, 64])), block_capacity=max_clock + 64)  # (1..32: lbft_k_run0q since round 5)
         res = sim.loop_until(max_clock, allow_faults=True)
         on_quad += bool(sim.layout()["kernel_class"] & 16384)
         if res.faults.any() and not (res.faults & ~np.uint32(1)).any():
@@ -205,7 +205,7 @@ def test_random_headline_network_configurations_on_the_device_match_the_oracle(o
 
 # the same for networks of 33..128 nodes: the cooperative large-network kernel (lanes per wavefront 1..32, multi-launch)
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_LARGE_CHUNKS", "3"))))
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_LARGE_CHUNKS", "4"))))
 def test_random_large_configurations_on_the_device_match_the_oracle(oracle, chunk):
     import librabft_simulator_amd as amd
     rng = np.random.default_rng(4242 + chunk)

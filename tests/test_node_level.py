@@ -368,9 +368,9 @@ def test_batched_node_calls_reject_two_calls_on_one_instance():
 
 
 @pytest.mark.gpu
-def test_counters_allreduce_through_rccl():
-    """lbft_batch_counters_allreduce: the run's one collective, natively (ncclAllReduce on the batch's stream).  One GPU here, so the
-    communicator has one rank: the call goes through librccl and must return the batch's own counters."""
+def test_counters_allgather_reduce_through_rccl():
+    """lbft_batch_counters_allgather_reduce: the run's one collective, natively (ONE ncclAllGather on the batch's stream, reduced locally).  One GPU
+    here, so the communicator has one rank: the call goes through librccl and must return the batch's own counters -- under its round-4 name too."""
     import ctypes
     import librabft_simulator_amd as amd
     try:
@@ -389,7 +389,8 @@ def test_counters_allreduce_through_rccl():
     res = amd.BatchSimulator.new(np.arange(1, 513, dtype=np.uint64), 4, amd.RandomDelay.new(10.0, 4.0)).loop_until(500)
     assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, u, 0) == 0
     try:
-        agg = res.counters_allreduce(comm.value)
+        agg = res.counters_allgather_reduce(comm.value)
+        assert res.counters_allreduce(comm.value) == agg  # (the alias: lbft_batch_counters_allreduce)
     finally:
         rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
         rccl.ncclCommDestroy(comm)

@@ -246,6 +246,14 @@ def test_device_load_node_round_trips_images_of_two_points_in_time(oracle, name)
     with pytest.raises(amd.LbftError) as e:
         sim.load_node(1, 0, img2[0][:-5], far)
     assert e.value.code == -1
+    # an image with retired record stores needs a batch that archives them (round-4 advisor: it used to load, dropping past_record_stores silently, and
+    # the node then failed save_node): refused with LBFT_ERR_UNSUPPORTED, the node untouched
+    if node_state(img2[0])["past_record_stores"]:
+        plain = amd.BatchSimulator.new(seeds, n, amd.RandomDelay.new(10.0, 4.0), **kwd)
+        plain.loop_until(max_clock)
+        with pytest.raises(amd.LbftError) as e:
+            plain.load_node(1, 0, img2[0], far)
+        assert e.value.code == -3 and "keep_retired_stores" in str(e.value)
     assert [sim.save_node(1, node) for node in range(n)] == img2  # every refusal left the node untouched
 
 

@@ -5,7 +5,7 @@
 #   bash tools/gpu_configs_profile.sh r02 "c4_16384x64_longtail_equivocators c4live_16384x64_longtail_equivocators_fixed"
 set -u
 TAG=${1:-rXX}
-PROF_CONFIGS=${2:-"c2_1024x4_lognormal c3_65536x4 c3shard_8192x4 c4_16384x64_longtail_equivocators c5_8192x100_weighted_epochs c4live_16384x64_longtail_equivocators_fixed c5live_8192x100_rotating_rights_epochs_fixed"}
+PROF_CONFIGS=${2:-"c2_1024x4_lognormal c2_1024x4_uniform c3_65536x4 c3shard_8192x4 c4_16384x64_longtail_equivocators c5_8192x100_weighted_epochs c4live_16384x64_longtail_equivocators_fixed c5live_8192x100_rotating_rights_epochs_fixed"}
 OUT=gpurun_out/configs_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
