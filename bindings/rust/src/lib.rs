@@ -122,7 +122,7 @@ extern "C" {
     /// many trait calls (each on another instance) in one launch + one synchronisation: see include/lbft.h `lbft_node_calls`
     pub fn lbft_node_calls(b: *mut c_void, calls: *const LbftNodeCall, n: usize, results: *mut LbftNodeResult) -> c_int;
     /// the run's one collective, natively: ONE ncclAllGather of the 14 counter words per rank on the caller's ncclComm_t, reduced locally
-    pub fn lbft_batch_counters_allreduce(b: *mut c_void, nccl_comm: *mut c_void, out: *mut LbftCounters) -> c_int;
+    pub fn lbft_batch_counters_allgather_reduce(b: *mut c_void, nccl_comm: *mut c_void, out: *mut LbftCounters) -> c_int;
     /// past_record_stores (node.rs:43) kept in full on the device: save_node then also serves nodes that have changed epoch
     pub fn lbft_batch_keep_retired_stores(b: *mut c_void, enable: c_int) -> c_int;
     fn lbft_batch_commit_counts(b: *const c_void, out: *mut u32) -> c_int;

@@ -19,6 +19,8 @@ def main():
     rank, path = int(sys.argv[1]), sys.argv[2]
     import numpy as np
     import librabft_simulator_amd as amd
+    from librabft_simulator_amd import _lib
+    _lib.lib()  # the HIP library (and with it ONE HIP runtime: _lib._one_hip_runtime) before librccl brings its own dependencies
     rccl = ctypes.CDLL("librccl.so.1")
 
     class UniqueId(ctypes.Structure):

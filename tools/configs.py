@@ -53,7 +53,7 @@ PARITY_SAMPLE = {
     "c3_65536x4": "all 65 536 instances (262 144 nodes), math_mode 0; 1 024 in every bench line",
     "c3shard_8192x4": "the first 8 192 instances of the c3 check",
     "c4_16384x64_longtail_equivocators": "all 16 384 instances",
-    "c5_8192x100_weighted_epochs": "1 024 of 8 192 instances per test run; ALL 8 192 once, offline against the oracle: profiles/r05/full_size_c5_all_8192.txt",
+    "c5_8192x100_weighted_epochs": "512 of 8 192 instances per test run; ALL 8 192 once, offline against the oracle: profiles/r05/full_size_c5_all_8192.txt",
     "c4live_16384x64_longtail_equivocators_fixed": "2 048 of 16 384 instances per test run",
     "c5live_8192x100_rotating_rights_epochs_fixed": "1 024 of 8 192 instances per test run; ALL 8 192 once, offline against the oracle: profiles/r05/full_size_c5live_all_8192.txt",
 }
