@@ -356,12 +356,16 @@ enum CounterSlot { C_EV0 = 0, C_EV1, C_EV2, C_EV3, C_DRAWS, C_ROUNDS, C_COMMITS,
 
 // Per-node State hash (simulated_context.rs:51-55) and the batch counters (wavefront shuffle
 // reductions, one atomic per wavefront and counter).
-__global__ __launch_bounds__(LBFT_BLOCK) void lbft_k_finalize(Params p, const u32* __restrict__ state, u64* __restrict__ states_out,
-                                                              unsigned long long* __restrict__ counters) {
-  // grid = (instances / 64, nodes): lane = instance (row accesses stay coalesced), blockIdx.y = the node whose State is hashed;
-  // the y == 0 blocks also reduce the batch counters.
-  u32 i = blockIdx.x * LBFT_BLOCK + threadIdx.x;
-  u32 n = blockIdx.y;
+#define LBFT_FINAL_WAVES 4  // wavefronts per workgroup of lbft_k_finalize = the nodes of the SAME 64 instances that are hashed side by side
+__global__ __launch_bounds__(LBFT_BLOCK * LBFT_FINAL_WAVES) void lbft_k_finalize(Params p, const u32* __restrict__ state, u64* __restrict__ states_out,
+                                                                                 unsigned long long* __restrict__ counters) {
+  // grid = (instances / 64, nodes / 4), workgroup = 4 wavefronts: lane = instance, wavefront w of block (x, y) hashes node 4 y + w of the block's 64
+  // instances.  The nodes of an instance committed (nearly) the same chain, so the four wavefronts of a workgroup read the same block records at the same
+  // time on one CU: three of four reads hit its vector cache / the XCD's L2 (round 4 launched one wavefront per (64 instances, node) -- the four readers of a
+  // record ran on different XCDs, 1 024 workgroups apart: 0.25 ms; round 5: EXPERIMENTS.md).  The wavefronts of node 0 also reduce the batch counters.
+  u32 i = blockIdx.x * LBFT_BLOCK + (threadIdx.x & 63u);
+  u32 n = blockIdx.y * LBFT_FINAL_WAVES + (threadIdx.x >> 6);
+  if (n >= p.n) return;
   if (i < p.m) {
     Sim s(p, const_cast<u32*>(state), i);
     u32 nc = s.nfm(n, NF_NCOMMITS);
@@ -1461,7 +1465,7 @@ int lbft_batch_checkpoint_load(lbft_batch* b, const void* buf, size_t len) {
 static int finalize_run(lbft_batch* b, u32 grid_full, u64 launches) {
   Params& p = b->p;
   HIP_TRY(hipMemsetAsync(b->d_counters, 0, C_WORDS * sizeof(unsigned long long), b->stream));
-  lbft_k_finalize<<<dim3(grid_full, p.n), LBFT_BLOCK, 0, b->stream>>>(p, b->d_state, b->d_states_out, b->d_counters);
+  lbft_k_finalize<<<dim3(grid_full, (p.n + LBFT_FINAL_WAVES - 1) / LBFT_FINAL_WAVES), LBFT_BLOCK * LBFT_FINAL_WAVES, 0, b->stream>>>(p, b->d_state, b->d_states_out, b->d_counters);
   HIP_TRY(hipGetLastError());
   unsigned long long hc[C_WORDS];
   HIP_TRY(hipMemcpyAsync(hc, b->d_counters, sizeof(hc), hipMemcpyDeviceToHost, b->stream));
