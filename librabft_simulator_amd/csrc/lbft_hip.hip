@@ -563,7 +563,10 @@ static bool quad_eligible(const Params& p) {
   const char* e = getenv("LBFT_NO_QUAD");
   // (its LDS queue columns are 32 lanes apart at compile time, LBFT_QUAD_STRIDE32: 64 networks per wavefront -- batches beyond 131 072
   // networks, or a forced lanes_per_wavefront -- run the generic class-0 kernel)
-  return LBFT_C0_QUAD && sim_quad(p) && !(LBFT_QUAD_STRIDE32 && p.lpw > 32) && !(e && atoi(e));
+  // (... except the smallest batches: with one network per wavefront and fewer than 1 024 of them lbft_k_run0u wins -- 256 x 4: 4.77 ms against 7.24 here and
+  // 5.92 on lbft_k_run0s; at 1 024 the two tie (4.89 / 4.91), at 2 048 this kernel leads again: profiles/r05/lds_resident_instance_ab.txt)
+  const bool tiny = p.lpw == 1 && p.m < 1024 && !getenv("LBFT_NO_UNI");
+  return LBFT_C0_QUAD && sim_quad(p) && !tiny && !(LBFT_QUAD_STRIDE32 && p.lpw > 32) && !(e && atoi(e));
 }
 // (round 5: since round 4's work on lbft_k_run0q the lane-private kernel beats the wavefront-wide pop at EVERY batch size of the headline network --
 // 2 048 / 4 096 / 8 192 / 16 384 x 4: 4.78 / 6.48 / 8.23 / 10.36 ms against 4.90 / 7.41 / 9.42 / 12.19 -- so lbft_k_run0s / lbft_k_run0u now serve the

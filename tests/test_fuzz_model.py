@@ -151,7 +151,8 @@ def test_random_configurations_on_the_device_match_the_oracle(oracle, chunk):
 # The headline network's own kernel (lbft_k_run0q: 4 nodes, unit voting rights, log-normal delays, <= 64 snapshot slots, fixed at
 # compile time; pairs of lanes scanning a queue): everything else about the configuration drawn at random -- pacemaker parameters,
 # epoch lengths, delay mean / variance, equivocators, loss, partitions, Q2 -- with 1 .. 64 networks per wavefront and launches
-# cut into pieces.  At least half of the draws must have run on that kernel (the rest: the general small-network kernel).
+# cut into pieces.  At least half of the draws must have run on that kernel -- or, one network per wavefront (batches this small then run lbft_k_run0u), on the
+# scalar-unit kernel -- (the rest: the general small-network kernels).
 @pytest.mark.gpu
 @pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_QUAD_CHUNKS", "5"))))
 def test_random_headline_network_configurations_on_the_device_match_the_oracle(oracle, chunk):
@@ -176,7 +177,7 @@ def test_random_headline_network_configurations_on_the_device_match_the_oracle(o
         kw.setdefault("mean", float(rng.choice([3.0, 10.0, 25.0])))
         kw.setdefault("variance", float(rng.choice([0.0, 4.0, 100.0])))
         max_clock = int(rng.choice([300, 600, 1000, 2500]))
-        m = int(rng.choice([129, 300, 700]))
+        m = int(rng.choice([129, 300, 700, 1100]))  # (1 100 with one lane per wavefront: lbft_k_run0q; smaller batches there: lbft_k_run0u)
         seeds = rng.integers(1, 2 ** 62, m, dtype=np.uint64)
         ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds, max_clock, threads=8, history_cap=96)
         nc = amd.NodeConfig(kw.get("target_commit_interval", 100000), kw.get("delta", 20), kw.get("gamma", 2.0), kw.get("lambda_", 0.5))
@@ -186,7 +187,7 @@ def test_random_headline_network_configurations_on_the_device_match_the_oracle(o
                                      quirks=kw.get("quirks", 0), calendar_queue=bool(rng.random() < 0.3), max_steps_per_launch=int(rng.choice([0, 0, 173])),
                                      lanes_per_wavefront=int(rng.choice([1, 2, 4, 8, 16, 32, 64])), block_capacity=max_clock + 64)  # (1..32: lbft_k_run0q since round 5)
         res = sim.loop_until(max_clock, allow_faults=True)
-        on_quad += bool(sim.layout()["kernel_class"] & 16384)
+        on_quad += bool(sim.layout()["kernel_class"] & (16384 | 32768))  # lbft_k_run0q, or lbft_k_run0u where one network per wavefront of a batch this small runs there
         if res.faults.any() and not (res.faults & ~np.uint32(1)).any():
             # LBFT_FAULT_QUEUE_OVERFLOW only: the scanned queue of these kernels holds 256 events (a larger queue_capacity = the heap / calendar of
             # the general kernel, which the other device fuzz covers); slow pacemakers under long delays can exceed it
