@@ -51,6 +51,32 @@ def assert_equal_to_oracle(oracle, res, kw, seeds, max_clock, cap=256):
     return ref
 
 
+# Which class-0 run kernel serves which batch (round 5's measured crossover, lbft_hip.hip quad_eligible / small_batch_kernel / uni_kernel), named through
+# lbft_batch_layout's flag word -- bit 14 lbft_k_run0q, bit 13 lbft_k_run0s, bits 13 + 15 lbft_k_run0u -- and every such batch bit for bit against the oracle.
+@pytest.mark.parametrize("m,uniform,kernel,lanes", [
+    (512, False, "lbft_k_run0u", 1),     # below 1 024 networks: the scalar-unit kernel whatever the network (256 x 4: 4.77 ms against 7.24 on lbft_k_run0q)
+    (1024, False, "lbft_k_run0q", 1),    # BASELINE config 2's size with log-normal delays: the headline kernel, one network per wavefront
+    (1024, True, "lbft_k_run0u", 1),     # BASELINE config 2 (uniform delays): not the compile-time network -> the scalar-unit kernel (4.71 against 5.11 ms)
+    (8192, False, "lbft_k_run0q", 4),    # one GPU's share of config 3 on an 8-GPU node (8.2 against 9.4 ms)
+    (4096, True, "lbft_k_run0s", 2),     # uniform delays beyond one network per wavefront: the wavefront-wide pop (7.2 against 8.4 ms on lbft_k_run0)
+])
+def test_small_batches_run_on_the_measured_kernel_and_equal_the_oracle(amd, oracle, m, uniform, kernel, lanes):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    kw = dict(num_nodes=4, delay_model=1, uniform_lo=5, uniform_hi=15) if uniform else dict(num_nodes=4)
+    seeds = np.arange(1, m + 1, dtype=np.uint64) * 7919
+    sim, res = run_gpu(amd, kw, seeds, 1000)
+    lay = sim.layout()
+    assert bench.run_kernel_name(lay["kernel_class"]) == kernel and lay["lanes_per_wavefront"] == lanes, lay
+    idx = np.unique(np.linspace(0, m - 1, 768).astype(np.int64))
+    ref = oracle.run_batch(oracle.make_config(math_mode=1, **kw), seeds[idx], 1000, threads=HOST_THREADS, history_cap=64)
+    assert not res.faults.any()
+    assert (res.commit_counts[idx] == ref["commit_counts"]).all() and (res.active_rounds[idx] == ref["active_rounds"]).all()
+    assert (res.last_committed_states[idx] == ref["last_states"]).all() and (res.committed_histories(64)[idx] == ref["histories"]).all()
+
+
 def test_reference_golden_3_nodes(amd):
     # librabft-v2/tests/simulated_run.rs:45-66
     contexts = amd.Simulator.new(52, 3, amd.RandomDelay.new(10.0, 4.0)).loop_until(amd.GlobalTime(1000))
