@@ -523,7 +523,8 @@ def test_full_size_config4_16384x64_equivocators_properties(amd, oracle):
     m, n, max_clock = 16384, 64, 300
     kw = dict(num_nodes=n, mean=10.0, variance=400.0, equivocate_every=5)
     seeds = np.arange(1, m + 1, dtype=np.uint64)
-    _, res = run_gpu(amd, kw, seeds, max_clock)
+    sim, res = run_gpu(amd, kw, seeds, max_clock)
+    assert sim.layout()["kernel_class"] & 0x14ff == 0x0402, sim.layout()  # lbft_k_run2l (lbft_batch_layout: class 2 | two-wavefront kernel << 10 | record exchange << 12)
     assert not res.faults.any()
     cc = res.commit_counts
     hist = res.committed_histories(max(int(cc.max()), 1))
@@ -546,7 +547,8 @@ def test_full_size_config5_8192x100_weighted_epochs_properties(amd, oracle):
     rights = [1 + (i % 4) for i in range(n)]
     kw = dict(num_nodes=n, voting_rights=rights, commands_per_epoch=50)
     seeds = np.arange(1, m + 1, dtype=np.uint64)
-    _, res = run_gpu(amd, kw, seeds, max_clock)
+    sim, res = run_gpu(amd, kw, seeds, max_clock)
+    assert sim.layout()["kernel_class"] & 0x14ff == 0x0402, sim.layout()  # lbft_k_run2l (lbft_batch_layout: class 2 | two-wavefront kernel << 10 | record exchange << 12)
     assert not res.faults.any()
     cc = res.commit_counts
     hist = res.committed_histories(max(int(cc.max()), 1))
@@ -572,7 +574,8 @@ def test_full_size_config4_live_16384x64_equivocators_commit(amd, oracle):
     m, n, max_clock = 16384, 64, 1000
     kw = dict(num_nodes=n, mean=10.0, variance=400.0, equivocate_every=5, quirks=3)
     seeds = np.arange(1, m + 1, dtype=np.uint64)
-    _, res = run_gpu(amd, kw, seeds, max_clock)
+    sim, res = run_gpu(amd, kw, seeds, max_clock)
+    assert sim.layout()["kernel_class"] & 0x14ff == 0x1402, sim.layout()  # lbft_k_run2q (lbft_batch_layout: class 2 | two-wavefront kernel << 10 | record exchange << 12)
     assert not res.faults.any()
     cc = res.commit_counts
     assert (cc.min(axis=1) >= 5).mean() >= 0.9, np.bincount(cc.min(axis=1))   # liveness despite f_byz = 13 < 64 / 3
@@ -600,7 +603,8 @@ def test_full_size_config5_live_8192x100_rotating_rights_epochs(amd, oracle):
     rights = [1 + (i % 4) for i in range(n)]
     kw = dict(num_nodes=n, voting_rights=rights, commands_per_epoch=3, quirks=3, rights_rotation=1)
     seeds = np.arange(1, m + 1, dtype=np.uint64)
-    _, res = run_gpu(amd, kw, seeds, max_clock)
+    sim, res = run_gpu(amd, kw, seeds, max_clock)
+    assert sim.layout()["kernel_class"] & 0x14ff == 0x1402, sim.layout()  # lbft_k_run2q (lbft_batch_layout: class 2 | two-wavefront kernel << 10 | record exchange << 12)
     assert not res.faults.any()
     cc, ep = res.commit_counts, res.epochs
     assert (ep >= 2).all()                                   # >= 2 reconfigurations at every node of every instance
