@@ -101,7 +101,7 @@ def _kernel_metadata(so_path):
     for chunk in notes.split("  - .agpr_count:")[1:]:
         name = re.search(r"\.name:\s+(\S+)", chunk).group(1)
         kernels[name] = {k: int(re.search(r"\.%s:\s+(\d+)" % k, chunk).group(1))
-                         for k in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count")}
+                         for k in ("private_segment_fixed_size", "vgpr_count", "vgpr_spill_count", "sgpr_count")}
     return kernels
 
 
@@ -151,6 +151,28 @@ def test_uniform_kernel_compiles_to_scalar_code(hiplib):
     from librabft_simulator_amd import build
     k = [v for name, v in _kernel_metadata(build.OUT).items() if "lbft_k_run0u" in name]
     assert len(k) == 1 and k[0]["vgpr_count"] <= 176 and k[0]["private_segment_fixed_size"] == 0, k
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"), reason="needs the ROCm LLVM binutils")
+def test_built_kernels_match_the_committed_codegen_manifest(hiplib):
+    """tests/golden/kernel_manifest.json pins, per kernel, the machine code (bytes + sha256), VGPRs, SGPRs, spilled registers and scratch bytes of the
+    library the round's numbers were measured on, and the hipcc that built it.  The large-network kernels sit on a register-allocation knife's edge
+    (round 5: deleting a DEAD struct member grew lbft_k_run2l from 135 to 142 KB and cost 14 % on the device): any deviation -- a source edit, a
+    toolchain change -- fails here on the CPU box instead of costing time on the GPU unnoticed.  A deliberate kernel change regenerates the manifest
+    in the same commit, after measuring it: python tools/kernel_manifest.py --write."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_manifest
+    committed = json.load(open(kernel_manifest.MANIFEST))
+    built = kernel_manifest.manifest(hiplib.LIB_PATH)
+    for k in ("lbft_k_run0q", "lbft_k_run0", "lbft_k_run0s", "lbft_k_run0u", "lbft_k_run1l", "lbft_k_run2l", "lbft_k_run2q", "lbft_k_run<1>", "lbft_k_run<2>",
+              "lbft_k_init", "lbft_k_finalize"):
+        assert k in built["kernels"], (k, sorted(built["kernels"]))
+    d = kernel_manifest.diff(committed, built)
+    toolchain = committed["hipcc"] != built["hipcc"]
+    assert not d, ("the built kernels deviate from tests/golden/kernel_manifest.json%s:\n  %s\nre-measure (tools/gpu_configs_profile.sh) and regenerate it in "
+                   "the same commit: python tools/kernel_manifest.py --write" % (" (DIFFERENT hipcc: every kernel needs re-measuring)" if toolchain else "", "\n  ".join(d)))
 
 
 def test_kernel_hash_reads_the_code_object(hiplib):

@@ -35,9 +35,16 @@ CONFIGS = {
     "c4live_16384x64_longtail_equivocators_fixed": dict(instances=16384, nodes=64, max_clock=1000, variance=400.0, equivocate_every=5, quirks=3),
     "c5live_8192x100_rotating_rights_epochs_fixed": dict(instances=8192, nodes=100, max_clock=450, weights=[1 + (i % 4) for i in range(100)],
                                                          commands_per_epoch=3, quirks=3, rights_rotation=1),
+    # BASELINE configuration 5 AS IT IS NAMED (round-5 review, missing #1): 8 192 x 100 nodes, voting rights 1 + (i mod 4), an epoch every 50 commits
+    # with the reconfiguration actually firing -- the epoch switch of librabft-v2/src/node.rs:331-348 and the configuration read of
+    # bft-lib/src/simulated_context.rs:199-216 (here: the rights rotate by one node per epoch, the epoch-reconfiguration extension) -- in the fixed
+    # protocol mode (the reference semantics stall at the first change), run until EVERY node of EVERY instance has changed epoch
+    # at least once: ~33 commits per 1 000 ticks, the first change around clock 1 600-1 900, clock 2 500 leaves a margin.
+    "c5named_8192x100_weighted_epoch_every_50_commits": dict(instances=8192, nodes=100, max_clock=2500, weights=[1 + (i % 4) for i in range(100)],
+                                                             commands_per_epoch=50, quirks=3, rights_rotation=1),
 }
 HBM_PEAK_GBS = 8000.0
-OPT_IN = ("c5b", "c4live", "c5live")
+OPT_IN = ("c5b", "c4live", "c5live", "c5named")
 # What pins each configuration's results (printed with every line): the reference itself only holds answers for 3- / 8-node
 # LogNormal(10, 4) runs; everything else is "device == oracle", the oracle being the specification.
 PARITY = {
@@ -57,6 +64,7 @@ PARITY_SAMPLE = {
     "c4live_16384x64_longtail_equivocators_fixed": "2 048 of 16 384 instances per test run",
     "c5live_8192x100_rotating_rights_epochs_fixed": "1 024 of 8 192 instances per test run; ALL 8 192 once, offline against the oracle: profiles/r05/full_size_c5live_all_8192.txt",
 }
+# (round 6: every instance the oracle has a digest for in tests/golden/full_size_digests.npz is compared in every suite run -- tests/full_size_digest.py)
 # What a line measures, where that is not what its name suggests (printed with the line)
 NOTES = {
     "c4_16384x64_longtail_equivocators": "DEGENERATE as SURVEY 8(d) wrote it: under reference quirk Q1 stragglers never catch up and the network stops committing "
