@@ -184,7 +184,7 @@ struct Params {
   u32 qheap;           // event queue is a binary heap in the HBM rows (large networks) instead of the LDS-fronted array
   u32 qpack;           // event queue entries are single packed 64-bit words (kernel class 0; set by compute_layout)
   u32 qcal;            // event queue is a calendar (one FIFO per (time, kind) bucket) -- needs max_clock <= LBFT_CAL_MAX_CLOCK
-  u32 off_cal_head, off_cal_tail, off_cal_bm, cal_buckets;
+  u32 off_cal_head, cal_chunks /* (the slot that held off_cal_tail until round 6: heads and tails are interleaved now) */, off_cal_bm, cal_buckets;
   u32 total_votes, quorum;
   u32 equiv;         // extension: every node with index % equiv == 0 is an equivocating leader (0 = none; include/lbft.h)
   u32 quirks;                  // bit 1: EpochId::previous() = id - 1 (fixes reference quirk Q2, base_types.rs:31-37); bit 0 unsupported
@@ -269,6 +269,25 @@ extern unsigned long long lbft_host_stats[64];
 #ifndef LBFT_STEP_DONE
 #define LBFT_STEP_DONE() do { } while (0)
 #endif
+// (tests/tools/bucket_stats.cpp, round 6 "Stage A": every popped event and every scheduled one, for the histograms of events per calendar bucket,
+// distinct nodes per bucket and zero-delay hazards; nothing in device builds)
+#if defined(LBFT_HOST_BUCKETS) && !defined(__HIPCC__)
+void lbft_host_pop(int t, unsigned kind, unsigned node, unsigned sender);
+void lbft_host_push(long long t, unsigned kind, unsigned node);
+#define LBFT_HOOK_POP(t, k, n, s) lbft_host_pop(t, k, n, s)
+#define LBFT_HOOK_PUSH(t, k, n) lbft_host_push(t, k, n)
+#else
+#define LBFT_HOOK_POP(t, k, n, s) do { } while (0)
+#define LBFT_HOOK_PUSH(t, k, n) do { } while (0)
+#endif
+// (tests/tools/mem_lines.cpp, round 6: every access of the event loop to the instance's rows -- instance-relative byte offset, store or load -- for the
+// per-structure count of 128-byte lines an event touches; nothing in device builds)
+#if defined(LBFT_HOST_MEMHOOK) && !defined(__HIPCC__)
+void lbft_host_mem(unsigned byte_offset, int store);
+#define LBFT_HOOK_MEM(o, s) lbft_host_mem((unsigned)(o), s)
+#else
+#define LBFT_HOOK_MEM(o, s) do { } while (0)
+#endif
 
 // HBM layout: instances are grouped in tiles of `tw` (the instances one wavefront advances); a tile is contiguous and holds
 // its rows word-interleaved: word w of instance i lives at byte (i / tw) * total_words * 4 tw + w * 4 tw + (i % tw) * 4.
@@ -319,8 +338,13 @@ enum NodeField : u32 {
   // (voting constraints, tracker, ledger)
   NF_LVR, NF_LOCKED, NF_LQAT, NF_TR_EPOCH, NF_TR_HCR, NF_TR_LCT,
   NF_NEXT_CMD, NF_LAST_COMMITTED_BLK, NF_NCOMMITS,
-  NF_FIXED_WORDS  // followed by hcbr[2][n]: highest_certified_block_round per timeout author
+  NF_FIXED_WORDS  // followed by the set extension words (n > 32: words 1.. of the four author sets) and hcbr[2][n]: highest_certified_block_round per timeout author
 };
+// Node row = [fixed words][4 author sets x (mw - 1) extension words][hcbr[2][n]].  Round 6 moved the extension words in front of the hcbr buffers: the
+// event loop stages them with the fixed words (begin_node / ax_load), and behind 2n hcbr words they were 0.5-0.8 KB away -- 1.1-1.3 extra 128-byte lines per
+// event of a 64- / 100-node network (tests/tools/mem_lines.cpp); now the burst is ONE run of 41 + 4 (mw - 1) words, and the rows of a large network start
+// on line boundaries (compute_layout).  Networks of <= 32 nodes have no extension words: their layout is unchanged.
+LBFT_HD u32 node_hcbr_off(u32 mw) { return NF_FIXED_WORDS + 4u * (mw - 1u); }
 
 // Block rows.  The first BC_WORDS rows are the "hot record" that the event loop works on (held in a small
 // register-resident cache, see Sim::blk_get): the block's round and links, the rounds of its parent and
@@ -445,6 +469,7 @@ struct RngT {
   LBFT_HD u32 ring_off(u32 e) const { return rbase + ((e & rmask) << (rrsh + 1)); }  // two rows per entry
   LBFT_HD u64 ring_at(u32 e) const {
     u32 o = ring_off(e);
+    LBFT_HOOK_MEM(o, 0); LBFT_HOOK_MEM(o + (1u << rrsh), 0);
     return (u64)*reinterpret_cast<const u32*>(rtile + (size_t)o) | ((u64)*reinterpret_cast<const u32*>(rtile + (size_t)o + (1u << rrsh)) << 32);
   }
   // generator runs ahead: `g` more draws appended to the ring (the caller bounds g by the free room)
@@ -452,6 +477,7 @@ struct RngT {
     for (u32 q = 0; q < g; q++) {
       u64 v = step();
       u32 o = ring_off(rhead + rcnt);
+      LBFT_HOOK_MEM(o, 1); LBFT_HOOK_MEM(o + (1u << rrsh), 1);
       *reinterpret_cast<u32*>(rtile + (size_t)o) = (u32)v;
       *reinterpret_cast<u32*>(rtile + (size_t)o + (1u << rrsh)) = (u32)(v >> 32);
       rcnt++;
@@ -707,6 +733,8 @@ struct SimT {
   LBFT_HD u32 NN() const { return QUAD ? 4u : P.n; }
   LBFT_HD u32 MW() const { return QUAD ? 1u : P.mw; }
   LBFT_HD u32 NWORDS() const { return QUAD ? NF_FIXED_WORDS + 8u : P.node_words; }
+  // first hcbr word of a node row (behind the set extension words of a large network; a compile-time constant in the small-network classes)
+  LBFT_HD u32 HCO() const { return BIG ? NF_FIXED_WORDS + 4u * (MW() - 1u) : CLS == 3 ? NF_FIXED_WORDS + 4u * (P.mw - 1u) : (u32)NF_FIXED_WORDS; }
   LBFT_HD u32 SWORDS() const { return QUAD ? S_FIXED_WORDS + 8u : P.snap_words; }
   LBFT_HD u32 BWORDS() const { return QUAD ? (u32)B_WORDS : P.blk_words; }
   LBFT_HD u32 OFFNODE() const { return QUAD ? (u32)I_WORDS : P.off_node; }
@@ -745,7 +773,10 @@ struct SimT {
   u32 stamp, qlen, snap_free, nblocks, fault, maxq, maxsnap;
   u32 ev_stamp;   // creation stamp of the event being processed
   u32 cal_cursor, cal_free, cal_bump;  // calendar queue: first possibly non-empty bucket, height of the stack of freed slots, bump allocator
-  u32 sp_idx, sp_s1, sp_meta, sp_nx;   // calendar queue: the entry behind the last popped one, fetched ahead (sp_s1 = slot + 1, 0 = none); never stored
+  // calendar queue: the bucket being drained -- its index, its head word (chunk + 1) << 6 | position of the next entry (0 = no bucket open; written back
+  // when the bucket is left), the tail word as last seen -- and the next entry, fetched ahead (sp_s1 != 0: sp_meta is valid)
+  u32 sp_idx, sp_s1, sp_meta, sp_nx;
+  u32 cur_h;
   u32 last_node;  // node of the previous event (round-switch trace)
   // round-switch trace: folded duplicate timers of time vd_time still "pop" in the reference until stamp vd_stamp
   u32 vd_time, vd_stamp;
@@ -836,7 +867,7 @@ struct SimT {
       return (idx & 4u) ? v47 : v03;
     }
     if (hc_lds()) return wuni(hc[(node * 8u + buf * 4u + a) << hsh]);  // (`hc` is a generic pointer: a flat load counts as a source of divergence)
-    return nfm(node, NF_FIXED_WORDS + buf * NN() + a);
+    return nfm(node, HCO() + buf * NN() + a);
   }
   LBFT_HD void hc_set(u32 node, u32 buf, u32 a, u32 v) const {
     if (hc_reg()) {
@@ -847,7 +878,7 @@ struct SimT {
       return;
     }
     if (hc_lds()) hc[(node * 8u + buf * 4u + a) << hsh] = v;
-    else nfms(node, NF_FIXED_WORDS + buf * NN() + a, v);
+    else nfms(node, HCO() + buf * NN() + a, v);
   }
   LBFT_HD void hcbr_to_lds() const {
     if (!hc_lds()) return;
@@ -882,15 +913,17 @@ struct SimT {
   LBFT_HD static u32 mul24(u32 a, u32 b) { return a * b; }  // (__umul24 trips the same compiler bug)
   LBFT_HD u32 rowb() const { return TILE64 ? 256u : IMAJOR ? 4u : 4u * P.tw; }  // bytes of a row
   LBFT_HD u32 boff(u32 w) const { return TILE64 ? (w << 8) + lane4 : IMAJOR ? (w << 2) + lane4 : mul24(w, rowb()) + lane4; }  // tile-relative byte offset of row w (a tile is < 4 GiB)
-  LBFT_HD u32 ld(u32 w) const { return *reinterpret_cast<const u32*>(tile + (size_t)boff(w)); }
-  LBFT_HD void st(u32 w, u32 v) const { *reinterpret_cast<u32*>(tile + (size_t)boff(w)) = v; }
+  LBFT_HD u32 ld(u32 w) const { LBFT_HOOK_MEM(boff(w), 0); return *reinterpret_cast<const u32*>(tile + (size_t)boff(w)); }
+  LBFT_HD void st(u32 w, u32 v) const { LBFT_HOOK_MEM(boff(w), 1); *reinterpret_cast<u32*>(tile + (size_t)boff(w)) = v; }
   // row (w0 + f) given boff(w0): groups of 16 rows share one 32-bit base, the rest is the instruction's immediate
   LBFT_HD u32 ldf(u32 base, u32 f) const {
+    LBFT_HOOK_MEM(IMAJOR ? base + f * 4u : base, 0);
     if (TILE64) return *reinterpret_cast<const u32*>(tile + (size_t)(base + (f & ~15u) * LBFT_ROW_BYTES) + (f & 15u) * LBFT_ROW_BYTES);
     if (IMAJOR) return *reinterpret_cast<const u32*>(tile + (size_t)base + f * 4u);  // (consecutive fields: immediate offsets, wide loads)
     return *reinterpret_cast<const u32*>(tile + (size_t)(base + mul24(f, rowb())));
   }
   LBFT_HD void stf(u32 base, u32 f, u32 v) const {
+    LBFT_HOOK_MEM(IMAJOR ? base + f * 4u : base, 1);
     if (TILE64) *reinterpret_cast<u32*>(tile + (size_t)(base + (f & ~15u) * LBFT_ROW_BYTES) + (f & 15u) * LBFT_ROW_BYTES) = v;
     else if (IMAJOR) *reinterpret_cast<u32*>(tile + (size_t)base + f * 4u) = v;
     else *reinterpret_cast<u32*>(tile + (size_t)(base + mul24(f, rowb()))) = v;
@@ -1139,7 +1172,7 @@ struct SimT {
     cal_cursor = ldi(I_CAL_CURSOR); cal_free = ldi(I_CAL_FREE); cal_bump = ldi(I_CAL_BUMP);
     n_fold = ldi(I_NFOLD); n_upd = ldi(I_NUPD);
     cont = ldi(I_CONT);
-    sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0;
+    sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0; cur_h = 0;
     if (RING) { rng.rhead = ldi(I_RING_HEAD); rng.rcnt = ldi(I_RING_CNT); }
     blk_cache_reset();
   }
@@ -1155,6 +1188,7 @@ struct SimT {
       sti(I_SNAP_MASK_LO, (u32)snap_mask); sti(I_SNAP_MASK_HI, (u32)(snap_mask >> 32));
       sti(I_LAST_NODE, last_node); sti(I_VD_TIME, vd_time); sti(I_VD_STAMP, vd_stamp);
     }
+    if (cal() && cur_h) { st(calh(sp_idx), cur_h); cur_h = 0; sp_s1 = 0; }  // (the open bucket's head lives in a register while it drains)
     sti(I_CAL_CURSOR, cal_cursor); sti(I_CAL_FREE, cal_free); sti(I_CAL_BUMP, cal_bump);
     sti(I_NFOLD, n_fold); sti(I_NUPD, n_upd);
     if (q1()) sti(I_CONT, cont);
@@ -1262,6 +1296,19 @@ struct SimT {
       if (!qpacked()) st(P.off_qmeta + k, qm[qx(k)]);
     }
   }
+  // calendar queue rows: (head, tail) word pairs per bucket, chunk pool (rows off_qmeta), stack of freed chunks (rows off_qlo)
+#define LBFT_CAL_CH 32u  // words per chunk
+#define LBFT_CAL_CE 31u  // entries per chunk
+  LBFT_HD u32 calh(u32 idx) const { return P.off_cal_head + 2u * idx; }       // (chunk + 1) << 6 | position of the next entry to pop
+  LBFT_HD u32 calt(u32 idx) const { return P.off_cal_head + 2u * idx + 1u; }  // (chunk + 1) << 6 | position of the last entry written; 0 = empty bucket
+  LBFT_HD u32 chw(u32 c, u32 pos) const { return P.off_qmeta + c * LBFT_CAL_CH + pos; }
+  LBFT_HD u32 cal_alloc_chunk() {
+    u32 c;
+    if (cal_free) c = ld(P.off_qlo + --cal_free);
+    else c = cal_bump++;
+    if (LBFT_UNLIKELY(c >= P.cal_chunks)) { fault |= F_QUEUE_OVERFLOW; c = P.cal_chunks - 1u; }  // (in bounds; the instance's results are void from here on)
+    return c;
+  }
   // `reuse_stamp` != ~0u: the event takes that (already handed out, otherwise unused) creation stamp.
   LBFT_HD bool push_event(i64 time, u32 kind, u32 node, u32 sender, u32 slot, u32 reuse_stamp = ~0u) {
     u32 my_stamp = reuse_stamp;
@@ -1269,6 +1316,7 @@ struct SimT {
     if (LBFT_UNLIKELY(time > (i64)P.max_clock)) return false;
     if (LBFT_UNLIKELY(my_stamp >= (qpacked() ? (1u << LBFT_QP_STAMP_BITS) : (1u << 30)))) { fault |= F_STAMP_OVERFLOW; return false; }
     if (LBFT_UNLIKELY(qlen >= P.qcap)) { fault |= F_QUEUE_OVERFLOW; return false; }
+    LBFT_HOOK_PUSH(time, kind, node);
     u64 key = ((u64)(u32)time << 32) | ((3u - kind) << 30) | my_stamp;
     u32 meta = node | (sender << 8) | (slot << 16);
     if (qpacked())
@@ -1276,22 +1324,23 @@ struct SimT {
     if (cal()) {
       // Calendar queue: bucket = (time, kind) in pop order; creation stamps grow with every push, so appending
       // keeps each bucket sorted by stamp and the key never has to be stored or compared.  O(1), ~1 round trip.
+      // Round 6: a bucket is a chain of CHUNKS of 31 consecutive entries (one 128-byte line: word 0 = next chunk + 1, words 1..31 = event metas)
+      // instead of a linked list of single slots: an append is the tail word + one store into the tail chunk (the old form wrote the slot's meta,
+      // its link, its predecessor's link and read the free-slot stack: four more lines), a pop reads consecutive words of a line it already has.
       u32 idx = (u32)time * 4u + (3u - kind);
-      u32 tl = ld(P.off_cal_tail + idx);
-      // slot + 1: from the stack of freed slots (rows off_qlo, which the calendar does not need for keys; a stack rather than a
-      // linked free list so that a cooperative bulk send can take a whole group of slots with independent loads), else a fresh one
-      u32 s1;
-      if (cal_free) s1 = ld(P.off_qlo + --cal_free);
-      else s1 = ++cal_bump;                   // bounded by the qlen < qcap check above
-      st(P.off_qmeta + s1 - 1, meta);
-      st(P.off_qhi + s1 - 1, 0);              // next
-      if (tl) { st(P.off_qhi + tl - 1, s1); if (F_SPEC && tl == sp_s1) sp_nx = s1; }  // (the entry pop_event fetched ahead got a successor)
-      else {
-        st(P.off_cal_head + idx, s1);
+      u32 tl = ld(calt(idx));
+      u32 c, pos;
+      if (tl == 0) {  // empty bucket
+        c = cal_alloc_chunk(); pos = 1;
+        st(calh(idx), ((c + 1u) << 6) | 1u);
         u32 bw = P.off_cal_bm + (idx >> 5);
         st(bw, ld(bw) | (1u << (idx & 31u)));
-      }
-      st(P.off_cal_tail + idx, s1);
+      } else if ((tl & 63u) == LBFT_CAL_CE) {  // the tail chunk is full
+        c = cal_alloc_chunk(); pos = 1;
+        st(chw((tl >> 6) - 1u, 0), c + 1u);
+      } else { c = (tl >> 6) - 1u; pos = (tl & 63u) + 1u; }
+      st(chw(c, pos), meta);
+      st(calt(idx), ((c + 1u) << 6) | pos);
       if (idx < cal_cursor) cal_cursor = idx;
     } else if (heap()) {  // large networks: binary min-heap in the HBM rows, sift up
       u32 i = qlen;
@@ -1440,36 +1489,41 @@ LBFT_UNROLL
     if (qlen == 0) return false;
     LBFT_STAT(48 + (qlen > 56 ? 7 : qlen / 8));
     if (cal()) {  // first non-empty bucket at or after the cursor, head of its FIFO
-      // A bucket usually holds many events (all notifications of one time unit), so the previous pop already fetched the
-      // (meta, next) words of this bucket's next entry (sp_*): unless a push lowered the cursor since, that entry is the one
-      // to pop -- no bitmap word, no head row, no entry fetch: the three dependent round trips of a pop are gone.
-      u32 idx, s1, nx, w = 0, raw = 0;
-      bool have_raw = false;
-      if (F_SPEC && sp_s1 != 0 && cal_cursor == sp_idx) {
-        idx = sp_idx; s1 = sp_s1; meta = sp_meta; nx = sp_nx;
-      } else {
-        w = cal_cursor >> 5;
-        raw = ld(P.off_cal_bm + w);
+      // The bucket being drained stays "open" in registers (sp_idx, cur_h = its head word, sp_nx = its tail word as last seen): a pop is ONE load of the
+      // next entry -- whose address is known a step ahead, so it is fetched ahead (sp_meta) -- and no store at all; bitmap, head and tail words are only
+      // touched when a bucket is opened or drained, the chunk's link word once per 31 entries.
+      if (cur_h == 0 || cal_cursor != sp_idx) {
+        if (cur_h != 0) st(calh(sp_idx), cur_h);  // (a push lowered the cursor below the open bucket: park it)
+        u32 w = cal_cursor >> 5;
+        u32 raw = ld(P.off_cal_bm + w);
         u32 bits = raw & (~0u << (cal_cursor & 31u));
         while (!bits) { w++; raw = ld(P.off_cal_bm + w); bits = raw; }
-        have_raw = true;
-        idx = w * 32u + ctz32(bits);
-        cal_cursor = idx;
-        s1 = ld(P.off_cal_head + idx);
-        meta = ld(P.off_qmeta + s1 - 1);
-        nx = ld(P.off_qhi + s1 - 1);
-      }
-      st(P.off_cal_head + idx, nx);
-      if (!nx) {
-        if (!have_raw) { w = idx >> 5; raw = ld(P.off_cal_bm + w); }
-        st(P.off_cal_tail + idx, 0); st(P.off_cal_bm + w, raw & ~(1u << (idx & 31u)));
+        u32 idx = w * 32u + ctz32(bits);
+        cal_cursor = idx; sp_idx = idx;
+        cur_h = ld(calh(idx)); sp_nx = ld(calt(idx));
         sp_s1 = 0;
-      } else if (F_SPEC) {  // fetch the entry behind this one now; a later append to it is patched in by push_event / coop_bulk
-        sp_idx = idx; sp_s1 = nx;
-        sp_meta = ld(P.off_qmeta + nx - 1);
-        sp_nx = ld(P.off_qhi + nx - 1);
       }
-      st(P.off_qlo + cal_free++, s1);         // stack of freed slots
+      const u32 idx = sp_idx;
+      const u32 c = (cur_h >> 6) - 1u, pos = cur_h & 63u;
+      meta = (F_SPEC && sp_s1) ? sp_meta : ld(chw(c, pos));
+      bool last = cur_h == sp_nx;
+      if (last) {  // ... unless the bucket was appended to while it drained (a zero-delay send into the open bucket)
+        u32 t2 = ld(calt(idx));
+        if (t2 != sp_nx) { sp_nx = t2; last = false; }
+      }
+      if (last) {
+        st(calh(idx), 0); st(calt(idx), 0);
+        u32 bw = P.off_cal_bm + (idx >> 5);
+        st(bw, ld(bw) & ~(1u << (idx & 31u)));
+        st(P.off_qlo + cal_free++, c);  // stack of freed chunks
+        cur_h = 0;
+      } else if (pos == LBFT_CAL_CE) {
+        u32 nx = ld(chw(c, 0));
+        st(P.off_qlo + cal_free++, c);
+        cur_h = (nx << 6) | 1u;
+      } else cur_h++;
+      sp_s1 = 0;
+      if (F_SPEC && cur_h != 0) { sp_meta = ld(chw((cur_h >> 6) - 1u, cur_h & 63u)); sp_s1 = 1; }  // (not the last one: the next entry exists already)
       time = (i32)(idx >> 2);
       kind = 3u - (idx & 3u);
       ev_stamp = 0;                           // (only the round trace needs stamps; it runs on the heap queue)
@@ -1576,10 +1630,20 @@ LBFT_UNROLL
     if (live > maxsnap) maxsnap = live;
     return (i32)ld(OFFSFREE() + snap_free);
   }
-  LBFT_HD void snap_release(u32 slot) { snap_release(slot, ld(OFFSREF() + slot)); }
-  LBFT_HD void snap_release(u32 slot, u32 refs) {  // `refs` = the slot's reference count as loaded by the caller
+  // Reference count of a snapshot slot.  Small networks: a row of its own (OFFSREF).  Large networks (round 6): bits 16..31 of the slot's S_EPOCH word
+  // (epochs stay below 2^16: bounded by the block capacity) -- the count then rides in the line every reader of the slot fetches anyway, instead of costing
+  // a line of its own per notification / request / response (0.3-1.0 lines read and as many written per event: tests/tools/mem_lines.cpp).
+  LBFT_HD bool refpack() const { return wide(); }
+  LBFT_HD void snap_set_refs(u32 slot, u32 refs, u32 epoch) {  // `epoch`: what the slot's S_EPOCH word holds (the caller wrote it in this step)
+    if (refpack()) st(sfw(slot, S_EPOCH), epoch | (refs << 16)); else st(OFFSREF() + slot, refs);
+  }
+  LBFT_HD void snap_release(u32 slot) {
+    if (refpack()) { u32 w = ld(sfw(slot, S_EPOCH)); snap_release(slot, w >> 16, w & 0xffffu); }
+    else snap_release(slot, ld(OFFSREF() + slot), 0);
+  }
+  LBFT_HD void snap_release(u32 slot, u32 refs, u32 epoch) {  // `refs` (and the slot's epoch) as loaded by the caller
     u32 r = refs - 1;
-    st(OFFSREF() + slot, r);
+    snap_set_refs(slot, r, epoch);
     if (r == 0) snap_free_slot(slot);
   }
 
@@ -1654,7 +1718,7 @@ LBFT_UNROLL
   // ---- author sets of a node (NF_TC_MASK, NF_TO_MASK, NF_BAL0_AUTHORS, NF_BAL1_AUTHORS): authors 0..31 in
   // the cached fixed rows, authors >= 32 (n > 32 only) in extension rows behind the hcbr buffers ----
   LBFT_HD u32 am_idx(u32 f) const { return f == NF_TC_MASK ? 0u : f == NF_TO_MASK ? 1u : f == NF_BAL0_AUTHORS ? 2u : 3u; }
-  LBFT_HD u32 amxw(u32 node, u32 f, u32 k) const { return nfw(node, NF_FIXED_WORDS + 2 * NN() + am_idx(f) * (MW() - 1) + k - 1); }
+  LBFT_HD u32 amxw(u32 node, u32 f, u32 k) const { return nfw(node, NF_FIXED_WORDS + am_idx(f) * (MW() - 1) + k - 1); }
   // Words 1..3 of the four sets are staged in registers with the fixed rows (begin_node / end_node): a read-modify-write of
   // an extension row would otherwise be one dependent memory round trip per author >= 32 in every vote / timeout insertion
   // (64-node networks: half of all authors).  Indices are kept compile-time after unrolling (value selects, not dynamically
@@ -1664,7 +1728,7 @@ LBFT_UNROLL
   LBFT_HD void ax_load(u32 node) const {
     axdirty = 0;
     if (!F_AX || !wide()) return;
-    u32 base = nfw(node, NF_FIXED_WORDS + 2 * NN());
+    u32 base = nfw(node, NF_FIXED_WORDS);
     LBFT_UNROLL
     for (u32 i = 0; i < 4; i++) {
       LBFT_UNROLL
@@ -1681,7 +1745,7 @@ LBFT_UNROLL
     for (u32 i = 0; i < 4; i++) {
       LBFT_UNROLL
       for (u32 k = 0; k < 3; k++)
-        if ((axdirty >> (i * 3 + k)) & 1u) st(nfw(node, NF_FIXED_WORDS + 2 * NN() + i * (MW() - 1) + k), ax[i][k]);
+        if ((axdirty >> (i * 3 + k)) & 1u) st(nfw(node, NF_FIXED_WORDS + i * (MW() - 1) + k), ax[i][k]);
     }
   }
   LBFT_HD u32 ax_get(u32 i, u32 k) const {  // k = 1..3
@@ -2385,6 +2449,7 @@ LBFT_UNROLL
     Resp rp;
     u32 sb = boff(OFFSNAP() + slot * SWORDS());
     rp.epoch = ldf(sb, S_EPOCH); rp.certs = ldf(sb, S_CERTS); rp.prop = ldf(sb, S_PROP_VOTE);
+    if (refpack()) rp.epoch &= 0xffffu;
     rp.tc_round = rp.to_round = rp.tc_mask0 = rp.to_mask0 = 0;
     if (LBFT_RESP_FAST) { rp.tc_round = ldf(sb, S_TC_ROUND); rp.to_round = ldf(sb, S_TO_ROUND); rp.tc_mask0 = ldf(sb, S_TC_MASK); rp.to_mask0 = ldf(sb, S_TO_MASK); }
     u32 qb = sqw(sfw(slot, 0), 0);
@@ -2465,7 +2530,7 @@ LBFT_UNROLL
     u32 tcw[4], tow[4];
     LBFT_UNROLL
     for (u32 q = 0; q < 4; q++) { tcw[q] = LBFT_UNI(tw_[q], k); tow[q] = LBFT_UNI(ow_[q], k); }
-    const u32 src_tc = nfw(node, NF_FIXED_WORDS + tc_sel * NN()), src_to = nfw(node, NF_FIXED_WORDS + (1u - tc_sel) * NN());
+    const u32 src_tc = nfw(node, HCO() + tc_sel * NN()), src_to = nfw(node, HCO() + (1u - tc_sel) * NN());
     const u32 dst_tc = base + S_FIXED_WORDS, dst_to = base + S_FIXED_WORDS + NN();
     // (at most two passes of 64 authors: unrolled, so that the set words are picked with compile-time indices -- indexed by the loop
     // variable the two four-word arrays went through scratch memory, a store + a dependent load per pass in every lane of the wavefront)
@@ -2499,7 +2564,8 @@ LBFT_UNROLL
     u32 sb = boff(OFFSNAP() + slot * SWORDS());
     LBFT_UNROLL
     for (u32 f = 0; f < S_FIXED_WORDS; f++) sn.w[f] = ldf(sb, f);
-    sn.refs = ld(OFFSREF() + slot);
+    if (refpack()) { sn.refs = sn.w[S_EPOCH] >> 16; sn.w[S_EPOCH] &= 0xffffu; }
+    else sn.refs = ld(OFFSREF() + slot);
     LBFT_UNROLL
     for (u32 a = 0; a < 4; a++) sn.to_hcbr[a] = 0;
     if (small_sets()) {
@@ -2782,13 +2848,14 @@ LBFT_UNROLL
       else if (which == 3) refs_twin += pushed ? 1u : 0u;
       else if (which == 4) rrefs += pushed ? 1u : 0u;
       else if (q1() && (i32)pslot >= 0) {  // response / sync request under quirks bit 0: the slot travels with the event
-        if (pushed) st(OFFSREF() + pslot, 1); else snap_free_slot(pslot);
+        if (pushed) snap_set_refs(pslot, 1, which == 0 ? nf(node, NF_EPOCH) /* the peer's store: it is the node in the cache of this step */ : sp.sync_epoch);
+        else snap_free_slot(pslot);
       }
       LBFT_MARK(19);
     }
-    if (slot >= 0) { if (refs) st(OFFSREF() + (u32)slot, refs); else snap_free_slot((u32)slot); }
-    if (slot_twin >= 0) { if (refs_twin) st(OFFSREF() + (u32)slot_twin, refs_twin); else snap_free_slot((u32)slot_twin); }
-    if (q1() && n_b && rs >= 0 && !(bulk & 2u)) { if (rrefs) st(OFFSREF() + (u32)rs, rrefs); else snap_free_slot((u32)rs); }
+    if (slot >= 0) { if (refs) snap_set_refs((u32)slot, refs, nf(node, NF_EPOCH)); else snap_free_slot((u32)slot); }
+    if (slot_twin >= 0) { if (refs_twin) snap_set_refs((u32)slot_twin, refs_twin, nf(node, NF_EPOCH)); else snap_free_slot((u32)slot_twin); }
+    if (q1() && n_b && rs >= 0 && !(bulk & 2u)) { if (rrefs) snap_set_refs((u32)rs, rrefs, nf(node, NF_EPOCH)); else snap_free_slot((u32)rs); }
     LBFT_MARK(13);
   }
 
@@ -2808,8 +2875,8 @@ LBFT_UNROLL
   u32 bulk;       // leader lane: bit 0 = a broadcast is pending, bit 1 = a query-all is pending (set by send_loop)
   u32 bulk_copy;  // leader lane: bit 0 = the hcbr words of a response snapshot are to be copied (a request under quirks bit 0), slot << 8
   u32 bulk_node;  // leader lane: the node whose actions are being processed
-  LBFT_HD u32 ldc(u32 l4, u32 w) const { return *reinterpret_cast<const u32*>(tile + (size_t)((IMAJOR ? (w << 2) : mul24(w, rowb())) + l4)); }
-  LBFT_HD void stc(u32 l4, u32 w, u32 v) const { *reinterpret_cast<u32*>(tile + (size_t)((IMAJOR ? (w << 2) : mul24(w, rowb())) + l4)) = v; }
+  LBFT_HD u32 ldc(u32 l4, u32 w) const { LBFT_HOOK_MEM((IMAJOR ? (w << 2) : mul24(w, rowb())) + l4, 0); return *reinterpret_cast<const u32*>(tile + (size_t)((IMAJOR ? (w << 2) : mul24(w, rowb())) + l4)); }
+  LBFT_HD void stc(u32 l4, u32 w, u32 v) const { LBFT_HOOK_MEM((IMAJOR ? (w << 2) : mul24(w, rowb())) + l4, 1); *reinterpret_cast<u32*>(tile + (size_t)((IMAJOR ? (w << 2) : mul24(w, rowb())) + l4)) = v; }
   // the first try of sample_delay() on the draw `bits`: true = accepted (then d is the delay sample_delay() returns)
   LBFT_HD bool fast_delay(u64 bits, i64& d) const {
     if (DMODEL() == 1) {
@@ -2975,18 +3042,6 @@ LBFT_UNROLL
       if (nl) {
         const u32 fc = LBFT_UNI(cal_free, k), bump = LBFT_UNI(cal_bump, k);
         const u32 slot_word = which == 0 ? 0u : (u32)rs;
-        PL<u32> s1;  // queue slot + 1 of the lane's message
-        LBFT_FOR_LANES(l) {
-          s1[l] = 0;
-          if (live[l]) {
-            u32 rank = popc64(L & ((1ULL << l) - 1ULL));
-            s1[l] = rank < fc ? ldc(l4, P.off_qlo + fc - 1u - rank) : bump + (rank - fc) + 1u;
-            u32 snap = which == 0 ? (u32)(twin[l] ? st_ : sr) : slot_word;
-            u32 meta = which == 0 ? (r[l] | (node << 8) | (snap << 16)) : (node | (r[l] << 8) | (snap << 16));
-            stc(l4, P.off_qmeta + s1[l] - 1u, meta);
-          }
-        }
-        LBFT_CMARK(8);  // slots + meta
         // lanes whose messages share a bucket (same time; the kind is common): M; sharing a bitmap word (same time >> 3): M3
         PL<u64> M, M3;
         LBFT_FOR_LANES(l) { M[l] = live[l] ? L : 0; M3[l] = M[l]; }
@@ -2997,36 +3052,68 @@ LBFT_UNROLL
           if (B == 0 || B == L) continue;
           LBFT_FOR_LANES(l) { u64 m = bit[l] ? B : ~B; M[l] &= m; if (b >= 3u) M3[l] &= m; }
         }
-        PL<u32> succ_lane, has_succ, has_pred, succ_slot;
-        LBFT_FOR_LANES(l) {
-          u64 lower = M[l] & ((1ULL << l) - 1ULL);
-          u64 upper = l == 63u ? 0ULL : (M[l] >> (l + 1u)) << (l + 1u);
-          has_pred[l] = lower != 0; has_succ[l] = upper != 0;
-          succ_lane[l] = upper ? ctz64(upper) : l;
-        }
-        pl_shfl(succ_slot, s1, succ_lane);
         LBFT_CMARK(9);  // grouping
-        PL<u32> tl;
+        // A group = the messages of one bucket, in lane (= stamp) order.  Its first lane (the leader) reads the bucket's tail word; member number rk
+        // takes entry base + rk behind the tail chunk's last one, spilling into up to three new chunks, which the leaders take from the stack of freed
+        // chunks / the bump allocator by rank (a two-bit-plane ballot prefix over the leaders' needs): one dependent load per distinct bucket.
+        PL<u32> lead, rk, gs, tl;
         LBFT_FOR_LANES(l) {
-          tl[l] = 0;
-          if (live[l]) {
-            stc(l4, P.off_qhi + s1[l] - 1u, has_succ[l] ? succ_slot[l] : 0u);  // next
-            if (!has_pred[l]) tl[l] = ldc(l4, P.off_cal_tail + t[l] * 4u + kc);
-          }
+          lead[l] = live[l] ? ctz64(M[l]) : l;
+          rk[l] = popc64(M[l] & ((1ULL << l) - 1ULL));
+          gs[l] = popc64(M[l]);
+          tl[l] = (live[l] && rk[l] == 0) ? ldc(l4, calt(t[l] * 4u + kc)) : 0u;
         }
+        PL<u32> tg;  // the group's tail word, in every member
+        pl_shfl(tg, tl, lead);
+        PL<u32> qn, q0, q1b;  // new chunks a leader needs (0..3)
+        LBFT_FOR_LANES(l) {
+          qn[l] = 0;
+          if (live[l] && rk[l] == 0) { u32 base = tg[l] ? (tg[l] & 63u) : 0u; qn[l] = (base + gs[l] + LBFT_CAL_CE - 1u) / LBFT_CAL_CE - (tg[l] ? 1u : 0u); }
+          q0[l] = qn[l] & 1u; q1b[l] = (qn[l] >> 1) & 1u;
+        }
+        const u64 Q0 = pl_ballot(q0), Q1 = pl_ballot(q1b);
+        const u32 total_new = popc64(Q0) + 2u * popc64(Q1);
+        const u32 pool = P.cal_chunks;
+        PL<u32> id0, id1, id2;
+        LBFT_FOR_LANES(l) {
+          const u64 lower = (1ULL << l) - 1ULL;
+          const u32 a0 = popc64(Q0 & lower) + 2u * popc64(Q1 & lower);
+          u32 ids[3] = {0, 0, 0};
+          LBFT_UNROLL
+          for (u32 j = 0; j < 3; j++)
+            if (j < qn[l]) {
+              u32 ar = a0 + j;  // allocation rank of this chunk
+              u32 c = ar < fc ? ldc(l4, P.off_qlo + fc - 1u - ar) : bump + (ar - fc);
+              ids[j] = c < pool ? c : pool - 1u;  // (pool exhausted: the leader lane raises the fault below; stay in bounds)
+            }
+          id0[l] = ids[0]; id1[l] = ids[1]; id2[l] = ids[2];
+        }
+        PL<u32> g0, g1, g2;
+        pl_shfl(g0, id0, lead); pl_shfl(g1, id1, lead); pl_shfl(g2, id2, lead);
+        LBFT_CMARK(8);  // chunks
         PL<u32> needbit;
         LBFT_FOR_LANES(l) {
           needbit[l] = 0;
           if (live[l]) {
-            u32 idx = t[l] * 4u + kc;
-            if (!has_pred[l]) {
-              if (tl[l]) stc(l4, P.off_qhi + tl[l] - 1u, s1[l]);
-              else { stc(l4, P.off_cal_head + idx, s1[l]); needbit[l] = 1; }
+            const u32 have = tg[l] ? 1u : 0u, base = tg[l] ? (tg[l] & 63u) : 0u;
+            const u32 e = base + rk[l], q = e / LBFT_CAL_CE, pos = e % LBFT_CAL_CE + 1u;
+            const u32 c = q < have ? (tg[l] >> 6) - 1u : (q - have == 0 ? g0[l] : q - have == 1 ? g1[l] : g2[l]);
+            u32 snap = which == 0 ? (u32)(twin[l] ? st_ : sr) : slot_word;
+            u32 meta = which == 0 ? (r[l] | (node << 8) | (snap << 16)) : (node | (r[l] << 8) | (snap << 16));
+            stc(l4, chw(c, pos), meta);
+            if (rk[l] == 0) {  // the leader: links between the chunks, the bucket's tail (and head) word
+              const u32 idx = t[l] * 4u + kc, n_new = qn[l];
+              if (have && n_new) stc(l4, chw((tg[l] >> 6) - 1u, 0), g0[l] + 1u);
+              if (n_new > 1u) stc(l4, chw(g0[l], 0), g1[l] + 1u);
+              if (n_new > 2u) stc(l4, chw(g1[l], 0), g2[l] + 1u);
+              const u32 lastc = n_new == 0 ? (tg[l] >> 6) - 1u : n_new == 1 ? g0[l] : n_new == 2 ? g1[l] : g2[l];
+              const u32 last_e = base + gs[l] - 1u;
+              stc(l4, calt(idx), ((lastc + 1u) << 6) | (last_e % LBFT_CAL_CE + 1u));
+              if (!have) { stc(l4, calh(idx), ((g0[l] + 1u) << 6) | 1u); needbit[l] = 1; }
             }
-            if (!has_succ[l]) stc(l4, P.off_cal_tail + idx, s1[l]);
           }
         }
-        LBFT_CMARK(10);  // links, heads, tails
+        LBFT_CMARK(10);  // entries, links, heads, tails
         const u64 NB = pl_ballot(needbit);
         if (NB) {  // occupancy bits of buckets that were empty: one read-modify-write per bitmap word
           PL<u32> bits;
@@ -3049,22 +3136,22 @@ LBFT_UNROLL
         if (is_k) {
           qlen += nl;
           if (qlen > maxq) maxq = qlen;
-          cal_free = fc - (nl < fc ? nl : fc);
-          cal_bump = bump + (nl > fc ? nl - fc : 0u);
+          cal_free = fc - (total_new < fc ? total_new : fc);
+          cal_bump = bump + (total_new > fc ? total_new - fc : 0u);
+          if (cal_bump > pool) { fault |= F_QUEUE_OVERFLOW; cal_bump = pool; }
           u32 lo = (u32)clk * 4u + kc;  // every message lies at or after the current time: a lower bound for the cursor
           if (lo < cal_cursor) cal_cursor = lo;
         }
       }
     }
     if (is_k) {
-      if (F_SPEC && sp_s1) sp_nx = ld(P.off_qhi + sp_s1 - 1);  // the entry pop_event fetched ahead may have got a successor from another lane
       stamp += cnt;
       if (stamp >= (1u << 30)) fault |= F_STAMP_OVERFLOW;
       if (which == 0) {
-        if (sr >= 0) { if (refs) st(OFFSREF() + (u32)sr, refs); else snap_free_slot((u32)sr); }
-        if (st_ >= 0) { if (refs_twin) st(OFFSREF() + (u32)st_, refs_twin); else snap_free_slot((u32)st_); }
+        if (sr >= 0) { if (refs) snap_set_refs((u32)sr, refs, nf(node, NF_EPOCH)); else snap_free_slot((u32)sr); }
+        if (st_ >= 0) { if (refs_twin) snap_set_refs((u32)st_, refs_twin, nf(node, NF_EPOCH)); else snap_free_slot((u32)st_); }
       } else if (q1() && rs >= 0) {
-        if (rrefs) st(OFFSREF() + (u32)rs, rrefs); else snap_free_slot((u32)rs);
+        if (rrefs) snap_set_refs((u32)rs, rrefs, nf(node, NF_EPOCH)); else snap_free_slot((u32)rs);
       }
     }
     LBFT_MARK(19);
@@ -3127,7 +3214,7 @@ LBFT_UNROLL
     for (u32 w = 0; w < I_WORDS; w++) st(w, 0);
     clock = 0; stamp = 0; qlen = 0; nblocks = 0; fault = 0; maxq = 0; maxsnap = 0;
     ev0 = ev1 = ev2 = ev3 = 0; n_fold = 0; n_upd = 0; cont = 0;
-    sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0;
+    sp_idx = 0; sp_s1 = 0; sp_meta = 0; sp_nx = 0; cur_h = 0;
     blk_cache_reset();
     snap_free = P.scap;
     snap_mask = P.scap >= 64 ? ~0ULL : ((1ULL << P.scap) - 1);
@@ -3137,7 +3224,7 @@ LBFT_UNROLL
       for (u32 k = 0; k < NN() * P.rcap; k++) st(P.off_trace + k, 0xffffffffu);
       for (u32 k = 0; k < NN(); k++) st(P.off_trace + NN() * P.rcap + k, 0);
     }
-    for (u32 s = 0; s < P.scap; s++) { st(OFFSFREE() + s, P.scap - 1 - s); st(OFFSREF() + s, 0); }
+    for (u32 s = 0; s < P.scap; s++) { st(OFFSFREE() + s, P.scap - 1 - s); st(OFFSREF() + s, 0); }  // (large networks: the count lives in the slot, written when it is taken)
     for (u32 k = 0; k < NN() * P.ecap * P.rarch_words; k++) st(P.off_rarch + k, 0);  // (an unused archive entry reads as "no store": current_round 0)
     rng.seed(seed);
     for (u32 node = 0; node < NN(); node++) {
@@ -3198,6 +3285,7 @@ LBFT_UNROLL
       i32 t_event = t;
       if (t > clock) clock = t;
       u32 node = meta & 0xffu, sender = (meta >> 8) & 0xffu, slot = meta >> 16;
+      if (!resumed) LBFT_HOOK_POP(t_event, kind, node, sender);
       if (!LEAN && !(C0 && LBFT_C0_NO_TRACE_STATE)) last_node = node;
       // One shared site for the node-row burst (and, for a notification, its snapshot words in the same
       // burst), one for update_node + process_node_actions: lanes of a wavefront that handle different
@@ -3205,7 +3293,9 @@ LBFT_UNROLL
       bool do_update = true, sync = false, more = false;
       SendPlan sp;
       sp.response = 0; sp.resp_slot = 0; sp.sync = 0; sp.sync_stamp = 0; sp.sync_epoch = 0; sp.sync_certs = 0; sp.have_actions = 0;
-      begin_node((q1() && kind == 1) ? sender : node);  // Q1 fixed: a request is processed on the peer it was sent to
+      // (reference semantics, quirk Q1: a request is answered by the requester itself with a payload-free response -- nothing of the node is read or
+      // written, so its rows are not fetched: a third of a large network's events, three lines each; class 0 keeps the burst, its lanes run in lockstep)
+      if (C0 || kind != 1 || q1()) begin_node((q1() && kind == 1) ? sender : node);  // Q1 fixed: a request is processed on the peer it was sent to
       Snap sn;
       LBFT_UNROLL
       for (u32 f = 0; f < S_FIXED_WORDS; f++) sn.w[f] = 0;
@@ -3235,7 +3325,7 @@ LBFT_UNROLL
       } else if (kind == 0) {  // DataSyncNotifyEvent (simulator.rs:416-440)
         ev0++; LBFT_STAT(2);
         sync = handle_notification(node, sender, slot, sn);
-        snap_release(slot, sn.refs);
+        snap_release(slot, sn.refs, sn.w[S_EPOCH]);
         if (q1()) { sp.sync_epoch = nf(node, NF_EPOCH); sp.sync_certs = nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16); }  // the request is created now (data_sync.rs:170-176)
         LBFT_MARK(3);
       } else if (kind == 1) {  // DataSyncRequestEvent (simulator.rs:441-453)
@@ -3244,7 +3334,8 @@ LBFT_UNROLL
           // handle_request on the peer `sender` (data_sync.rs:183-207): its store now, plus what the request said
           u32 qb = sfw(slot, 0);
           u32 req_epoch = ld(qb + S_EPOCH), req_certs = ld(qb + S_CERTS);
-          snap_release(slot);
+          if (refpack()) { snap_release(slot, req_epoch >> 16, req_epoch & 0xffffu); req_epoch &= 0xffffu; }
+          else snap_release(slot);
           i32 rs = snap_alloc();
           if (rs >= 0) {
             u32 rb = sfw((u32)rs, 0);
@@ -3425,13 +3516,19 @@ inline bool sim_lean1(const Params& p) { return sim_class(p) == 1 && sim_lean_fe
 // Row layout for a batch; fills the offset fields of `p` and returns words per instance.  Accumulated in 64 bits: a tile is
 // addressed with 32-bit byte offsets (boff(): row << rsh, at most 8), so a layout is only usable while it stays below 2^24 rows; the
 // caller rejects larger ones (layout_fits) instead of letting row offsets wrap.
+#define LBFT_CAL_CE_LAYOUT 31u  // (= LBFT_CAL_CE inside SimT)
 inline u32 node_words_used(const Params& p) { return NF_FIXED_WORDS + 2 * p.n + 4 * ((p.n + 31) / 32 - 1); }
 inline u32 snap_words_used(const Params& p) { return S_FIXED_WORDS + 2 * p.n + 2 * ((p.n + 31) / 32 - 1) + ((p.quirks & 1u) ? 2 : 0); }
 inline u32 layout_tile_width(const Params& p) { return sim_class(p) == 0 ? (LBFT_C0_IMAJOR ? 1u : 64u) : sim_class(p) == 1 ? 64u : 1u; }
 inline u64 compute_layout(Params& p) {
   u64 w = I_WORDS;
   p.mw = (p.n + 31) / 32;
+  // large networks (instance-major rows): every node row starts on a 128-byte line, so that the 41 + 4 (mw - 1) words an event stages are two lines,
+  // not two or three (round 6; the instance's first word is line-aligned as well: total_words below)
+  const bool align_rows = p.mw > 1;
+  if (align_rows) w = (w + 31) & ~(u64)31;
   p.off_node = (u32)w; p.node_words = NF_FIXED_WORDS + 2 * p.n + 4 * (p.mw - 1);
+  if (align_rows) p.node_words = (p.node_words + 31u) & ~31u;
   w += (u64)p.n * p.node_words;
   p.snap_words = S_FIXED_WORDS + 2 * p.n + 2 * (p.mw - 1) + ((p.quirks & 1u) ? 2 : 0);  // + the request's (epoch, certificates)
   p.blk_words = B_WORDS + 4 * (p.mw - 1);  // + extension words (nodes / authors >= 32) of KNOWN, QC, PEND and VOTERS
@@ -3446,12 +3543,22 @@ inline u64 compute_layout(Params& p) {
     p.off_blk = (u32)w; w += (u64)p.bcap * p.blk_words;
   };
   if (hot_first) snaps_blocks();
-  p.off_qhi = (u32)w; w += p.qcap;
-  p.off_qlo = (u32)w; w += p.qcap;  // (the calendar stores no keys: these rows hold its stack of freed slots)
-  p.off_qmeta = (u32)w; w += p.qcap;
+  // Calendar queue (round 6): a pool of 32-word chunks (31 event metas + a link word each) in the rows off_qmeta, the stack of freed chunks in the rows
+  // off_qlo, no key / link rows.  An entry costs 4.13 bytes; the pool holds qcap entries plus one partly filled tail chunk per bucket that can be
+  // non-empty at a time (events only ever sit in the ~delay-spread many time slots ahead of the clock; a margin of qcap / 32 chunks, at least 256) -- running out raises
+  // F_QUEUE_OVERFLOW like a full queue.
+  p.cal_chunks = 0;
+  if (p.qcal) {
+    u32 spare = p.qcap / 32u;
+    p.cal_chunks = (p.qcap + LBFT_CAL_CE_LAYOUT - 1u) / LBFT_CAL_CE_LAYOUT + (spare < 256u ? 256u : spare);
+    if (align_rows) w = (w + 31) & ~(u64)31;  // chunks are lines
+  }
+  p.off_qhi = (u32)w; w += p.qcal ? 0 : p.qcap;
+  p.off_qlo = (u32)w; w += p.qcal ? p.cal_chunks : p.qcap;
+  if (p.qcal && align_rows) w = (w + 31) & ~(u64)31;
+  p.off_qmeta = (u32)w; w += p.qcal ? (u64)p.cal_chunks * 32u : p.qcap;
   p.cal_buckets = p.qcal ? ((u32)p.max_clock + 1u) * 4u : 0;
-  p.off_cal_head = (u32)w; w += p.cal_buckets;
-  p.off_cal_tail = (u32)w; w += p.cal_buckets;
+  p.off_cal_head = (u32)w; w += 2ULL * p.cal_buckets;  // (head, tail) word pairs: a bucket that becomes non-empty writes both -- one line
   p.off_cal_bm = (u32)w; w += (p.cal_buckets + 31) / 32 + (p.qcal ? 1 : 0);
   if (!hot_first) snaps_blocks();  // (zero_calendar relies on head / tail / bitmap being the rows right before the snapshots here)
   p.off_log = (u32)w; w += (u64)p.n * p.lcap;
@@ -3462,6 +3569,7 @@ inline u64 compute_layout(Params& p) {
   p.off_rarch = (u32)w; w += (u64)p.n * p.ecap * p.rarch_words;
   p.off_sync = (u32)w; w += (p.quirks & 1u) ? p.bcap : 0;
   p.off_ring = (u32)w; w += 2ULL * p.ring;
+  if (align_rows) w = (w + 31) & ~(u64)31;
   p.total_words = w > 0xffffffffULL ? 0xffffffffu : (u32)w;
   p.qpack = sim_class(p) == 0 ? 1u : 0u;
   return w;

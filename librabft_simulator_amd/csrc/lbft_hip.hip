@@ -463,7 +463,7 @@ __device__ __forceinline__ void node_op_body(const Params& p, u32* __restrict__ 
   } else if (op == OP_CREATE_NOTIFICATION) {
     s.begin_node(node);
     i32 slot = s.snap_alloc();
-    if (slot >= 0) { s.write_snapshot(node, (u32)slot); s.st(p.off_snap_ref + (u32)slot, 1); }
+    if (slot >= 0) { s.write_snapshot(node, (u32)slot); s.snap_set_refs((u32)slot, 1, s.nf(node, NF_EPOCH)); }
     out[0] = (unsigned long long)(long long)slot;
   } else if (op == OP_HANDLE_NOTIFICATION) {
     s.begin_node(node);
@@ -476,18 +476,19 @@ __device__ __forceinline__ void node_op_body(const Params& p, u32* __restrict__ 
   } else if (op == OP_CREATE_REQUEST) {  // DataSyncNode::create_request (data_sync.rs:66-71,179-181): epoch + the chains' heads
     s.begin_node(node);
     i32 slot = s.make_request_slot(s.nf(node, NF_EPOCH), s.nf(node, NF_HCC_BLK) | (s.nf(node, NF_HQC_BLK) << 16));
-    if (slot >= 0) s.st(p.off_snap_ref + (u32)slot, 1);
+    if (slot >= 0) s.snap_set_refs((u32)slot, 1, s.nf(node, NF_EPOCH));
     out[0] = (unsigned long long)(long long)slot;
   } else if (op == OP_HANDLE_REQUEST) {  // DataSyncNode::handle_request on `node` (data_sync.rs:183-207): its store now + the request
     s.begin_node(node);
     u32 qb = s.sfw(arg1, 0);
     u32 req_epoch = s.ld(qb + S_EPOCH), req_certs = s.ld(qb + S_CERTS);
+    if (s.refpack()) req_epoch &= 0xffffu;  // (large networks: the slot's reference count rides in the upper half of this word)
     i32 slot = s.snap_alloc();
     if (slot >= 0) {
       u32 rb = s.sfw((u32)slot, 0);
       s.write_store_snapshot(node, rb);
       s.st(s.sqw(rb, 0), req_epoch); s.st(s.sqw(rb, 1), req_certs);
-      s.st(p.off_snap_ref + (u32)slot, 1);
+      s.snap_set_refs((u32)slot, 1, s.nf(node, NF_EPOCH));
     }
     out[0] = (unsigned long long)(long long)slot;
   } else if (op == OP_HANDLE_RESPONSE) {  // DataSyncNode::handle_response(response from peer arg0, clock) (data_sync.rs:209-240)
@@ -559,13 +560,16 @@ static thread_local std::string g_err;
 // 451 ms; with the staging 476-511 ms; the full-register kernel with twice the lanes 503 ms; 8 192 x 100 nodes: 2.49 / 2.75-2.85 / 2.85 s).
 // Tuning knobs: LBFT_NO_LEAN=1 = always the full-register kernels; LBFT_LEAN2=0 = the full-register kernel for large networks.
 // class-0 batches with few networks per wavefront run lbft_k_run0s (wavefront-wide pop); LBFT_NO_POPC=1: lbft_k_run0 for every batch size
+// (one reading of LBFT_NO_UNI for both kernel choices it touches -- round-5 advisor: "LBFT_NO_UNI=0" used to count as set in one of them)
+static bool uni_allowed() { const char* e = getenv("LBFT_NO_UNI"); return !(e && atoi(e)); }
 static bool quad_eligible(const Params& p) {
   const char* e = getenv("LBFT_NO_QUAD");
   // (its LDS queue columns are 32 lanes apart at compile time, LBFT_QUAD_STRIDE32: 64 networks per wavefront -- batches beyond 131 072
   // networks, or a forced lanes_per_wavefront -- run the generic class-0 kernel)
   // (... except the smallest batches: with one network per wavefront and fewer than 1 024 of them lbft_k_run0u wins -- 256 x 4: 4.77 ms against 7.24 here and
   // 5.92 on lbft_k_run0s; at 1 024 the two tie (4.89 / 4.91), at 2 048 this kernel leads again: profiles/r05/lds_resident_instance_ab.txt)
-  const bool tiny = p.lpw == 1 && p.m < 1024 && !getenv("LBFT_NO_UNI");
+  // (LBFT_NO_UNI=1 sends those tiny batches to lbft_k_run0s -- the kernel lbft_k_run0u replaced there --, not back here)
+  const bool tiny = p.lpw == 1 && p.m < 1024;
   return LBFT_C0_QUAD && sim_quad(p) && !tiny && !(LBFT_QUAD_STRIDE32 && p.lpw > 32) && !(e && atoi(e));
 }
 // (round 5: since round 4's work on lbft_k_run0q the lane-private kernel beats the wavefront-wide pop at EVERY batch size of the headline network --
@@ -587,10 +591,7 @@ static u32 blk_window_max() {
 static bool blk_window_allowed() { return blk_window_max() != 0; }
 static bool quad_kernel(const Params& p) { return quad_eligible(p); }
 // ... and among them the batches with ONE network per wavefront lbft_k_run0u (wavefront-uniform code on the scalar unit); LBFT_NO_UNI=1: lbft_k_run0s
-static bool uni_kernel(const Params& p) {
-  const char* e = getenv("LBFT_NO_UNI");
-  return small_batch_kernel(p) && p.lpw == 1 && !(e && atoi(e));
-}
+static bool uni_kernel(const Params& p) { return small_batch_kernel(p) && p.lpw == 1 && uni_allowed(); }
 static bool lean_allowed() { const char* e = getenv("LBFT_NO_LEAN"); return !(e && atoi(e)); }
 static bool lean2_allowed() { const char* e = getenv("LBFT_LEAN2"); return lean_allowed() && !(e && !atoi(e)); }
 

@@ -108,7 +108,7 @@ inline int build_node_image(const Params& dp, u32* hw, u32 node, const u32* weig
   // copy of its rows taken at that epoch change, SimT::retire_store) ----
   auto put_store = [&](u32 e, u32 row0) {  // row0: first word of the rows describing the store
     auto F = [&](u32 f) { return s.ld(row0 + f); };
-    auto set_word_of = [&](u32 f, u32 k) { return k == 0 ? F(f) : s.ld(row0 + NF_FIXED_WORDS + 2 * n + s.am_idx(f) * (mw - 1) + k - 1); };
+    auto set_word_of = [&](u32 f, u32 k) { return k == 0 ? F(f) : s.ld(row0 + NF_FIXED_WORDS + s.am_idx(f) * (mw - 1) + k - 1); };
     auto node_set = [&](u32 f) { std::vector<u32> v; for (u32 k = 0; k < mw; k++) for (u32 m = set_word_of(f, k); m; m &= m - 1) v.push_back(32 * k + ctz32(m)); return v; };
     auto put_timeout = [&](u32 round, u32 hcbr, u32 a) {  // Timeout = SignedValue<Timeout_>
       w.u64v(e); w.u64v(round); w.u64v(hcbr); w.u64v(a); w.u64v(a); w.u64v(record_hash_timeout(e, round, hcbr, a));
@@ -158,12 +158,12 @@ inline int build_node_image(const Params& dp, u32* hw, u32 node, const u32* weig
     if (htc) {  // highest_timeout_certificate: Option<Vec<Timeout>>
       auto tc = node_set(NF_TC_MASK);
       w.b.push_back(1); w.u64v(tc.size());
-      for (u32 a : tc) put_timeout(htc, F(NF_FIXED_WORDS + tc_sel * n + a), a);
+      for (u32 a : tc) put_timeout(htc, F(node_hcbr_off(mw) + tc_sel * n + a), a);
     } else w.b.push_back(0);
     {
       auto to = node_set(NF_TO_MASK);
       w.u64v(to.size());
-      for (u32 a : to) { w.u64v(a); put_timeout(cur, F(NF_FIXED_WORDS + (1u - tc_sel) * n + a), a); }
+      for (u32 a : to) { w.u64v(a); put_timeout(cur, F(node_hcbr_off(mw) + (1u - tc_sel) * n + a), a); }
     }
     {  // current_votes: HashMap<Author, Vote>, ascending author; the two ballot entries hold the voters by block
       auto v0 = node_set(NF_BAL0_AUTHORS), v1 = node_set(NF_BAL1_AUTHORS);
@@ -382,7 +382,7 @@ inline int load_node_image(const Params& dp, u32* hw, u32 node, const u32* weigh
   auto put_store = [&](const StoreImg& st, u32 row0, bool bits) {
     const u64 e = st.epoch;
     auto W = [&](u32 f, u32 v) { s.st(row0 + f, v); };
-    auto set_word_at = [&](u32 f, u32 k) { return k == 0 ? row0 + f : row0 + NF_FIXED_WORDS + 2 * n + s.am_idx(f) * (mw - 1) + k - 1; };
+    auto set_word_at = [&](u32 f, u32 k) { return k == 0 ? row0 + f : row0 + NF_FIXED_WORDS + s.am_idx(f) * (mw - 1) + k - 1; };
     auto clear_set = [&](u32 f) { for (u32 k = 0; k < mw; k++) s.st(set_word_at(f, k), 0); };
     auto add_to_set = [&](u32 f, u32 a) { u32 w = set_word_at(f, a >> 5); s.st(w, s.ld(w) | (1u << (a & 31u))); };
     W(NF_EPOCH, (u32)e);
@@ -403,9 +403,9 @@ inline int load_node_image(const Params& dp, u32* hw, u32 node, const u32* weigh
     // timeouts: the certificate in buffer 0, the current round's in buffer 1
     W(NF_TC_SEL, 0);
     clear_set(NF_TC_MASK); clear_set(NF_TO_MASK);
-    for (u32 k = 0; k < 2 * n; k++) W(NF_FIXED_WORDS + k, 0);
-    if (st.has_tc) for (auto& t : st.tc) { add_to_set(NF_TC_MASK, (u32)t.author); W(NF_FIXED_WORDS + (u32)t.author, (u32)t.hcbr); }
-    for (auto& t : st.to) { add_to_set(NF_TO_MASK, (u32)t.author); W(NF_FIXED_WORDS + n + (u32)t.author, (u32)t.hcbr); }
+    for (u32 k = 0; k < 2 * n; k++) W(node_hcbr_off(mw) + k, 0);
+    if (st.has_tc) for (auto& t : st.tc) { add_to_set(NF_TC_MASK, (u32)t.author); W(node_hcbr_off(mw) + (u32)t.author, (u32)t.hcbr); }
+    for (auto& t : st.to) { add_to_set(NF_TO_MASK, (u32)t.author); W(node_hcbr_off(mw) + n + (u32)t.author, (u32)t.hcbr); }
     W(NF_TO_WEIGHT, (u32)st.to_weight);
     // votes: at most two distinct blocks (two ballot entries)
     clear_set(NF_BAL0_AUTHORS); clear_set(NF_BAL1_AUTHORS);

@@ -47,14 +47,15 @@ def gather_rows(row, group=None, device=None):
     return out.reshape(world, -1).cpu()
 
 
-def aggregate_counters(counters, group=None, device=None, extra_max=()):
+def aggregate_counters(counters, group=None, device=None, extra_max=(), extra_sum=()):
     """Aggregate the counters of every rank (sum; high-water marks with max) with ONE collective.  Works with any
     initialised torch.distributed backend; returns a dict with the same keys as lbft_counters.  `extra_max`: further
     values reduced with max in the same collective (bench.py: the timed region of the slowest rank), returned as
-    out["extra_max"]."""
+    out["extra_max"]; `extra_sum`: further values summed in the same collective (bench.py: the rounds / commits / events of the
+    strong-scaling leg), returned as out["extra_sum"]."""
     sums, maxs = counters_to_vector(counters)
-    rows = gather_rows(list(sums) + list(maxs) + list(extra_max), group=group, device=device)
-    ns, nm = len(sums), len(maxs)
+    rows = gather_rows(list(sums) + list(maxs) + list(extra_max) + list(extra_sum), group=group, device=device)
+    ns, nm, nx = len(sums), len(maxs), len(extra_max)
     s = rows[:, :ns].sum(dim=0).tolist()
     m = rows[:, ns:ns + nm].max(dim=0).values.tolist()
     out = {"events": [int(v) for v in s[:4]]}
@@ -62,5 +63,6 @@ def aggregate_counters(counters, group=None, device=None, extra_max=()):
         out[k] = int(v)
     for k, v in zip(MAX_KEYS, m):
         out[k] = int(v)
-    out["extra_max"] = rows[:, ns + nm:].max(dim=0).values.tolist() if len(extra_max) else []
+    out["extra_max"] = rows[:, ns + nm:ns + nm + nx].max(dim=0).values.tolist() if nx else []
+    out["extra_sum"] = rows[:, ns + nm + nx:].sum(dim=0).tolist() if len(extra_sum) else []
     return out

@@ -318,6 +318,7 @@ class BatchSimulator:
             round_trace = min(int(max_clock) // 5 + 64, worst)
         if round_trace:
             check(_lib.lib().lbft_batch_enable_round_trace(self._h, int(round_trace)))
+        self._mutated()
         rc = check(_lib.lib().lbft_batch_run_until(self._h, int(max_clock)), allow_fault=allow_faults or auto)
         if auto and rc == _lib.LBFT_ERR_FAULT:
             if round_trace < worst and (BatchResult(self).faults & _lib.LBFT_FAULT_TRACE_OVERFLOW).any():
@@ -343,6 +344,7 @@ class BatchSimulator:
         """At most ``steps`` events per instance (first call = Simulator::new).  Returns (unfinished instances, BatchResult
         or None); the result is available once nothing is left to process."""
         left = C.c_uint64()
+        self._mutated()
         check(_lib.lib().lbft_batch_run_steps(self._h, int(max_clock), int(steps), C.byref(left)), allow_fault=allow_faults)
         return int(left.value), (BatchResult(self) if left.value == 0 else None)
 
@@ -357,11 +359,13 @@ class BatchSimulator:
     def load_checkpoint(self, path):
         """load_node (node.rs:211-231) at batch granularity: into a batch created with the same configuration."""
         buf = np.fromfile(path, dtype=np.uint8)
+        self._mutated()
         check(_lib.lib().lbft_batch_checkpoint_load(self._h, buf.ctypes.data, buf.size))
 
     def manual(self, max_clock=1000):
         """Node-level mode: initial node states only (NodeState::make_initial_state), no event loop.  Returns
         ``nodes[instance][author]`` -> NodeHandle."""
+        self._mutated()
         check(_lib.lib().lbft_batch_manual_begin(self._h, int(max_clock)))
         return [[NodeHandle(self, i, n) for n in range(self.num_nodes)] for i in range(self.num_instances)]
 
@@ -373,6 +377,7 @@ class BatchSimulator:
         for k, (op, inst, node, peer, handle, t) in enumerate(calls):
             arr[k] = _lib.LbftNodeCall(int(op), int(inst), int(node), int(peer), int(handle), 0, int(t))
         res = (_lib.LbftNodeResult * len(calls))()
+        self._mutated()
         check(_lib.lib().lbft_node_calls(self._h, arr, len(calls), res))
         return [{"actions": r.actions.as_dict(), "handle": int(r.handle), "should_sync": bool(r.should_sync), "status": int(r.status)} for r in res]
 
@@ -381,6 +386,7 @@ class BatchSimulator:
 
     def manual_finalize(self):
         """Makes commit counts / histories / States of a node-level session readable (BatchResult)."""
+        self._mutated()
         check(_lib.lib().lbft_batch_manual_finalize(self._h), allow_fault=True)
         return BatchResult(self)
 
@@ -397,9 +403,15 @@ class BatchSimulator:
         for an image naming records this instance's block pool does not hold.  The node is untouched when it raises."""
         buf = np.frombuffer(bytes(image), dtype=np.uint8)
         check(_lib.lib().lbft_batch_load_node(self._h, int(instance), int(node), buf.ctypes.data, len(buf), int(node_time)))
-        self._state_generation = getattr(self, "_state_generation", 0) + 1  # (BatchResult objects drop what they read back before)
+        self._mutated()
+
+    def _mutated(self):
+        """Every call that changes device state -- a run, a reset, a checkpoint / node load, a node-level call -- invalidates what BatchResult
+        objects of this simulator read back before (they re-read on their next access; round-5 advisor: only load_node used to do this)."""
+        self._state_generation = getattr(self, "_state_generation", 0) + 1
 
     def reset(self):
+        self._mutated()
         check(_lib.lib().lbft_batch_reset(self._h))
 
     def stream_handle(self):
@@ -451,6 +463,7 @@ class NodeHandle:
     def update_node(self, clock):
         """ConsensusNode::update_node(clock: NodeTime) -> NodeUpdateActions (librabft-v2/src/node.rs:240-304)."""
         a = LbftActions()
+        self._sim._mutated()
         check(_lib.lib().lbft_node_update(self._sim._h, self.instance, self.author, int(clock), C.byref(a)))
         return a.as_dict()
 
@@ -464,6 +477,7 @@ class NodeHandle:
         """DataSyncNode::handle_notification (data_sync.rs:113-177); True when the reference returns Some(request)."""
         sender, handle = notification
         sync = C.c_uint32()
+        self._sim._mutated()
         check(_lib.lib().lbft_node_handle_notification(self._sim._h, self.instance, self.author, sender, handle, C.byref(sync)))
         return bool(sync.value)
 
@@ -477,12 +491,14 @@ class NodeHandle:
         """DataSyncNode::handle_request (data_sync.rs:183-207): the records the requester lacks -> opaque response handle."""
         _, handle = request
         h = C.c_uint32()
+        self._sim._mutated()
         check(_lib.lib().lbft_node_handle_request(self._sim._h, self.instance, self.author, handle, C.byref(h)))
         return (self.author, int(h.value))
 
     def handle_response(self, response, clock):
         """DataSyncNode::handle_response(response, clock) (data_sync.rs:209-240)."""
         peer, handle = response
+        self._sim._mutated()
         check(_lib.lib().lbft_node_handle_response(self._sim._h, self.instance, self.author, peer, handle, int(clock)))
 
     def release(self, message):

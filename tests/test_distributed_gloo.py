@@ -24,7 +24,8 @@ def _worker(rank, world, port, n_instances, base_seed, ret):
     local = {"events": c["events"], "rng_draws": c["rng_draws"], "rounds": c["rounds"], "commits": c["commits"],
              "events_scheduled": c["events_scheduled"], "faulted_instances": 0, "max_queue": c["max_queue"],
              "max_snapshots": 0, "max_blocks": 0}
-    total = aggregate_counters(local)
+    # bench.py's second leg rides in the SAME collective: the timed regions (max over ranks) and the strong-scaling leg's sums
+    total = aggregate_counters(local, extra_max=[1.5 + rank, 10.0 - rank], extra_sum=[c["rounds"], len(seeds)])
     ret[rank] = (len(seeds), int(seeds[0]), int(seeds[-1]), total)
     dist.barrier()
     dist.destroy_process_group()
@@ -46,6 +47,7 @@ def test_two_rank_sharding_and_counter_allreduce(oracle):
     agg = ret[0][3]
     for k in ("events", "rng_draws", "rounds", "commits", "events_scheduled", "max_queue"):
         assert agg[k] == whole[k], k
+    assert agg["extra_max"] == [2.5, 10.0] and agg["extra_sum"] == [float(whole["rounds"]), float(n)]
 
 
 def test_shard_range_covers_everything():
