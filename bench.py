@@ -45,9 +45,11 @@ def parse():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses HIP device 0")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work for the oracle sample")
-    ap.add_argument("--measure-traffic", action="store_true",
-                    help="(N = 1, rocprofv3 on the box) re-collect FETCH_SIZE / WRITE_SIZE of the run kernel in two child runs of this command and report "
-                         "them as roofline.traffic_measured_here beside the value replayed from the committed profile")
+    ap.add_argument("--measure-traffic", action="store_true", default=None,
+                    help="(N = 1, rocprofv3 on the box) collect FETCH_SIZE / WRITE_SIZE of the run kernel in two child runs of this command: roofline.traffic is "
+                         "then MEASURED IN THIS RUN (roofline.traffic_measured_here) instead of replayed from the committed profile.  Default since round 6 for "
+                         "the headline workload on one GPU; --no-measure-traffic skips it")
+    ap.add_argument("--no-measure-traffic", dest="measure_traffic", action="store_false")
     ap.add_argument("--native-collective", action="store_true",
                     help="also aggregate the counters through the C ABI's own collective (lbft_batch_counters_allgather_reduce: ncclAllGather on a "
                          "communicator built with ncclCommInitRank, one device per rank) and check it against the torch.distributed aggregate")
@@ -82,13 +84,13 @@ def traffic_measured_here(argv):
         return {"error": "rocprofv3 not found"}
     if os.environ.get("LBFT_BENCH_CHILD"):  # (a child of this very function never profiles again, whatever its command line says)
         return {"error": "nested --measure-traffic refused"}
-    child = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--measure-traffic"] + ["--no-cpu-baseline", "--parity-instances", "0"]
+    child = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a != "--measure-traffic"] + ["--no-cpu-baseline", "--parity-instances", "0", "--no-measure-traffic"]
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="lbft_pmc_", dir="/tmp")
         try:
             r = subprocess.run([prof, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--output-format", "csv", "--"] + child,
-                               env=dict(os.environ, TMPDIR="/tmp", LBFT_BENCH_CHILD="1"), cwd="/tmp", capture_output=True, text=True, timeout=600)
+                               env=dict(os.environ, TMPDIR="/tmp", LBFT_BENCH_CHILD="1"), cwd="/tmp", capture_output=True, text=True, timeout=240)
             per = collections.defaultdict(float)
             for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 with open(path) as f:
@@ -390,6 +392,11 @@ def main():
         headline = (m, args.nodes, args.max_clock) == (65536, 4, 1000)
         traffic = measured_traffic_gb() if headline else None
         issue = measured_issue() if headline else None
+        # PMC counters cannot be read from inside this process: the headline line on one GPU collects them in two rocprofv3 child runs of the same
+        # command (bounded: 240 s each; a box without rocprofv3, or a failing pass, leaves the replayed value and says so)
+        want_here = args.measure_traffic if args.measure_traffic is not None else (headline and world == 1 and not os.environ.get("LBFT_BENCH_CHILD"))
+        here = traffic_measured_here(sys.argv[1:]) if (want_here and world == 1) else None
+        here_ok = bool(here) and "gb_corrected" in here
         local_events = sum(c["events"])
         achieved = local_events * bpe / (k_ms * 1e-3) / 1e9
         ex_bytes, pops = executed_bytes(layout, c)
@@ -417,17 +424,18 @@ def main():
             # cancelled timers and requests do not write node rows back) over the kernel's duration -- the honest fraction.  The
             # SURVEY 8(d) figure charged to every reference-equivalent event stands beside it as `frac_reference_equivalent`.
             "roofline": {"bound": "hbm", "achieved": achieved_ex, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_ex / HBM_PEAK_GBS,
-                         "traffic": traffic["gb_corrected"] if traffic else None, "traffic_unit": "GB per launch",
+                         "traffic": here["gb_corrected"] if here_ok else traffic["gb_corrected"] if traffic else None, "traffic_unit": "GB per launch",
                          # where `traffic` comes from: PMC counters cannot be read from inside this process, so the line REPLAYS the committed
                          # profile of the same kernels (stamped with the hash of their machine code; null when the stamp is stale)
-                         "traffic_source": ("committed profile %s (kernel hash %s): replayed, not measured in this run" % (traffic.get("profile"), traffic.get("source_hash")))
+                         "traffic_source": here["source"] if here_ok else
+                                           ("committed profile %s (kernel hash %s): replayed, not measured in this run" % (traffic.get("profile"), traffic.get("source_hash")))
                                            if traffic else "none: no committed profile matches the built kernels",
-                         "traffic_measured_here": traffic_measured_here(sys.argv[1:]) if (args.measure_traffic and world == 1) else None,
+                         "traffic_measured_here": here, "traffic_replayed_from_committed_profile": traffic["gb_corrected"] if traffic else None,
                          "traffic_detail": traffic, "kernel": run_kernel_name(layout.get("kernel_class", 0)), "kernel_ms": k_ms,
                          "algorithmic_gb_per_launch": ex_bytes / 1e9,
                          "queue_pops_per_launch": pops, "node_updates_per_launch": c.get("node_updates"),
                          "timers_folded_per_launch": c.get("timers_folded"), "queue_pops_per_s": pops / (k_ms * 1e-3),
-                         "executed_le_traffic": (ex_bytes / 1e9 <= traffic["gb_corrected"]) if traffic else None,
+                         "executed_le_traffic": (ex_bytes / 1e9 <= (here["gb_corrected"] if here_ok else traffic["gb_corrected"])) if (here_ok or traffic) else None,
                          "frac_reference_equivalent": achieved / HBM_PEAK_GBS,
                          "reference_equivalent": {"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "bytes_per_event": bpe,
                                                   "gb_per_launch": local_events * bpe / 1e9, "events_per_launch": local_events},
@@ -461,7 +469,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, args.nodes, args.max_clock)
         print(json.dumps(out))
         if out["roofline"]["executed_le_traffic"] is False:  # the "algorithmic" bytes must be a lower bound of what crosses the L2 boundary
-            sys.stderr.write("bench.py: executed algorithmic bytes %.2f GB exceed the measured traffic %.2f GB\n" % (ex_bytes / 1e9, traffic["gb_corrected"]))
+            sys.stderr.write("bench.py: executed algorithmic bytes %.2f GB exceed the measured traffic %.2f GB\n" % (ex_bytes / 1e9, out["roofline"]["traffic"]))
             if dist is not None:
                 dist.destroy_process_group()
             sys.exit(4)

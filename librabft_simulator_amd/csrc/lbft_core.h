@@ -754,6 +754,10 @@ struct SimT {
   static constexpr bool F_BX = LEAN2 ? (LBFT_LEAN_BX != 0) : (LBFT_BX != 0);
   static constexpr bool F_SPEC = LEAN2 ? (LBFT_LEAN_SPEC != 0) : (LBFT_SPEC != 0);
   static constexpr bool COOP = BIG;
+#ifndef LBFT_REQRUN
+#define LBFT_REQRUN 1  // (round 6) lbft_k_run2l: runs of Q1 requests are taken by the whole wavefront (coop_requests)
+#endif
+  static constexpr bool REQRUN = CLS == 5 && LBFT_REQRUN != 0;
   static constexpr bool RING = BIG || CLS == 3;
   bool coop_on;  // set by run_coop: the event loop is being run by a whole wavefront
   static constexpr u32 PB = CLS == 9 ? LBFT_POP_BATCH_QUAD : LBFT_POP_BATCH;  // slots per batch of the packed queue's scan
@@ -1309,6 +1313,41 @@ struct SimT {
     if (LBFT_UNLIKELY(c >= P.cal_chunks)) { fault |= F_QUEUE_OVERFLOW; c = P.cal_chunks - 1u; }  // (in bounds; the instance's results are void from here on)
     return c;
   }
+  // opens the first non-empty bucket at or after the cursor, unless that is the one already open (the queue is not empty)
+  LBFT_HD void cal_open() {
+    if (cur_h != 0 && cal_cursor == sp_idx) return;
+    if (cur_h != 0) st(calh(sp_idx), cur_h);  // (a push lowered the cursor below the open bucket: park it)
+    u32 w = cal_cursor >> 5;
+    u32 raw = ld(P.off_cal_bm + w);
+    u32 bits = raw & (~0u << (cal_cursor & 31u));
+    while (!bits) { w++; raw = ld(P.off_cal_bm + w); bits = raw; }
+    u32 idx = w * 32u + ctz32(bits);
+    cal_cursor = idx; sp_idx = idx;
+    cur_h = ld(calh(idx)); sp_nx = ld(calt(idx));
+    sp_s1 = 0;
+  }
+  // `cnt` entries of the open bucket, from its head on and all in the head's chunk, have been consumed
+  LBFT_HD void cal_advance(u32 cnt) {
+    const u32 idx = sp_idx, c = (cur_h >> 6) - 1u, lastpos = (cur_h & 63u) + cnt - 1u;
+    bool last = (((c + 1u) << 6) | lastpos) == sp_nx;
+    if (last) {  // ... unless the bucket was appended to while it drained (a zero-delay send into the open bucket)
+      u32 t2 = ld(calt(idx));
+      if (t2 != sp_nx) { sp_nx = t2; last = false; }
+    }
+    if (last) {
+      st(calh(idx), 0); st(calt(idx), 0);
+      u32 bw = P.off_cal_bm + (idx >> 5);
+      st(bw, ld(bw) & ~(1u << (idx & 31u)));
+      st(P.off_qlo + cal_free++, c);  // stack of freed chunks
+      cur_h = 0;
+    } else if (lastpos == LBFT_CAL_CE) {
+      u32 nx = ld(chw(c, 0));
+      st(P.off_qlo + cal_free++, c);
+      cur_h = (nx << 6) | 1u;
+    } else cur_h = ((c + 1u) << 6) | (lastpos + 1u);
+    sp_s1 = 0;
+    if (F_SPEC && cur_h != 0) { sp_meta = ld(chw((cur_h >> 6) - 1u, cur_h & 63u)); sp_s1 = 1; }  // (not the last one: the next entry exists already)
+  }
   // `reuse_stamp` != ~0u: the event takes that (already handed out, otherwise unused) creation stamp.
   LBFT_HD bool push_event(i64 time, u32 kind, u32 node, u32 sender, u32 slot, u32 reuse_stamp = ~0u) {
     u32 my_stamp = reuse_stamp;
@@ -1492,38 +1531,10 @@ LBFT_UNROLL
       // The bucket being drained stays "open" in registers (sp_idx, cur_h = its head word, sp_nx = its tail word as last seen): a pop is ONE load of the
       // next entry -- whose address is known a step ahead, so it is fetched ahead (sp_meta) -- and no store at all; bitmap, head and tail words are only
       // touched when a bucket is opened or drained, the chunk's link word once per 31 entries.
-      if (cur_h == 0 || cal_cursor != sp_idx) {
-        if (cur_h != 0) st(calh(sp_idx), cur_h);  // (a push lowered the cursor below the open bucket: park it)
-        u32 w = cal_cursor >> 5;
-        u32 raw = ld(P.off_cal_bm + w);
-        u32 bits = raw & (~0u << (cal_cursor & 31u));
-        while (!bits) { w++; raw = ld(P.off_cal_bm + w); bits = raw; }
-        u32 idx = w * 32u + ctz32(bits);
-        cal_cursor = idx; sp_idx = idx;
-        cur_h = ld(calh(idx)); sp_nx = ld(calt(idx));
-        sp_s1 = 0;
-      }
+      cal_open();
       const u32 idx = sp_idx;
-      const u32 c = (cur_h >> 6) - 1u, pos = cur_h & 63u;
-      meta = (F_SPEC && sp_s1) ? sp_meta : ld(chw(c, pos));
-      bool last = cur_h == sp_nx;
-      if (last) {  // ... unless the bucket was appended to while it drained (a zero-delay send into the open bucket)
-        u32 t2 = ld(calt(idx));
-        if (t2 != sp_nx) { sp_nx = t2; last = false; }
-      }
-      if (last) {
-        st(calh(idx), 0); st(calt(idx), 0);
-        u32 bw = P.off_cal_bm + (idx >> 5);
-        st(bw, ld(bw) & ~(1u << (idx & 31u)));
-        st(P.off_qlo + cal_free++, c);  // stack of freed chunks
-        cur_h = 0;
-      } else if (pos == LBFT_CAL_CE) {
-        u32 nx = ld(chw(c, 0));
-        st(P.off_qlo + cal_free++, c);
-        cur_h = (nx << 6) | 1u;
-      } else cur_h++;
-      sp_s1 = 0;
-      if (F_SPEC && cur_h != 0) { sp_meta = ld(chw((cur_h >> 6) - 1u, cur_h & 63u)); sp_s1 = 1; }  // (not the last one: the next entry exists already)
+      meta = (F_SPEC && sp_s1) ? sp_meta : ld(chw((cur_h >> 6) - 1u, cur_h & 63u));
+      cal_advance(1);
       time = (i32)(idx >> 2);
       kind = 3u - (idx & 3u);
       ev_stamp = 0;                           // (only the round trace needs stamps; it runs on the heap queue)
@@ -2872,6 +2883,221 @@ LBFT_UNROLL
   //     messages fall into the same bucket find each other with bit-sliced ballots over the time, link themselves in lane
   //     (= stamp) order, and one lane per bucket appends the chain to the bucket's tail -- one dependent load per distinct
   //     bucket instead of one memory round trip per message.
+  // ---- lanes = scheduled times: ONE delay sample per message of a list of `cnt` (<= 128), in list order, off the ring of pre-generated draws of the
+  // network in lane k.  Every lane evaluates one ring draw as if a sample started there; a ballot of "first try accepted" tells how many consecutive
+  // samples settle at once, a draw that needs the rejection path (~1.2 %) is sampled serially by the leader.  tm0 / tm1: lane j (j - 64) = scheduled
+  // time of message j, 0xffffffff = past the horizon.  `stop_zero`: stop behind the first message whose delay is zero (the caller must not run ahead of
+  // an event scheduled AT the current time: coop_requests); returns the number of samples taken.
+  LBFT_HD u32 coop_sample(u32 k, u32 l4, i32 clk, u32 cnt, PL<u32>& tm0, PL<u32>& tm1, bool stop_zero) {
+    const bool is_k = LBFT_IS_LANE(k);
+    const u32 ring_row = P.off_ring, ring_mask = P.ring - 1u;
+    LBFT_FOR_LANES(l) { tm0[l] = 0xffffffffu; tm1[l] = 0xffffffffu; }
+    u32 j = 0;
+    while (j < cnt) {
+      u32 avail = LBFT_UNI(rng.rcnt, k);
+      if (avail == 0) {
+        if (is_k) rng.ring_fill(rng.ring_room() < 64u ? rng.ring_room() : 64u);
+        avail = LBFT_UNI(rng.rcnt, k);
+      }
+      const u32 take = avail < 64u ? avail : 64u;
+      const u32 head = LBFT_UNI(rng.rhead, k);
+      PL<u32> fast, tv, zero;
+      LBFT_FOR_LANES(l) {
+        fast[l] = 0; tv[l] = 0xffffffffu; zero[l] = 0;
+        if (l < take) {
+          u32 e = ring_row + 2u * ((head + l) & ring_mask);
+          u64 bits = (u64)ldc(l4, e) | ((u64)ldc(l4, e + 1u) << 32);
+          i64 d;
+          fast[l] = fast_delay(bits, d) ? 1u : 0u;
+          tv[l] = horizon_time(clk, d);
+          zero[l] = d == 0 ? 1u : 0u;
+        }
+      }
+      const u64 F = pl_ballot(fast);
+      u32 run = ~F ? ctz64(~F) : 64u;  // consecutive first-try samples from the head of the ring
+      if (run > take) run = take;
+      if (run > cnt - j) run = cnt - j;
+      bool stop = false;
+      if (stop_zero && run) {
+        const u64 Z = pl_ballot(zero) & (run >= 64u ? ~0ULL : ((1ULL << run) - 1ULL));
+        if (Z) { run = ctz64(Z) + 1u; stop = true; }
+      }
+      {  // message j + q takes lane q's value (q < run)
+        PL<u32> src, got;
+        LBFT_FOR_LANES(l) src[l] = (l - j) & 63u;
+        pl_shfl(got, tv, src);
+        LBFT_FOR_LANES(l) if (l >= j && l < j + run) tm0[l] = got[l];
+        if (cnt > 64u) {
+          LBFT_FOR_LANES(l) src[l] = (64u + l - j) & 63u;
+          pl_shfl(got, tv, src);
+          LBFT_FOR_LANES(l) if (64u + l >= j && 64u + l < j + run) tm1[l] = got[l];
+        }
+      }
+      if (is_k) { rng.rhead += run; rng.rcnt -= run; rng.draws += run; }
+      j += run;
+      if (stop) break;
+      if (j < cnt && run < take) {  // the draw at the head needs the rejection path: the leader samples it serially
+        u32 tvk = 0, zk = 0;
+        if (is_k) { i64 d = sample_delay(); tvk = horizon_time(clk, d); zk = d == 0 ? 1u : 0u; }
+        u32 tvu = LBFT_UNI(tvk, k);
+        if (j < 64u) pl_write(tm0, j, tvu); else pl_write(tm1, j - 64u, tvu);
+        j++;
+        if (stop_zero && LBFT_UNI(zk, k)) break;
+      }
+    }
+    return j;
+  }
+  // ---- lanes = messages of ONE kind for the network in lane k, in lane (= creation stamp) order: `live` lanes are appended to the calendar buckets
+  // (t[l], kc) with the event word meta[l].  Returns the ballot of the lanes that were scheduled (a full queue drops the surplus and raises the fault).
+  LBFT_HD u64 bulk_append(u32 k, u32 l4, i32 clk, u32 kc, PL<u32>& live, const PL<u32>& t, const PL<u32>& meta) {
+    const bool is_k = LBFT_IS_LANE(k);
+      u64 L = pl_ballot(live);
+      u32 nl = popc64(L);
+      const u32 qlen_u = LBFT_UNI(qlen, k);
+      const u32 room = P.qcap > qlen_u ? P.qcap - qlen_u : 0u;
+      if (nl > room) {  // queue overflow: the surplus is not scheduled
+        LBFT_FOR_LANES(l) if (live[l] && popc64(L & ((1ULL << l) - 1ULL)) >= room) live[l] = 0;
+        if (is_k) fault |= F_QUEUE_OVERFLOW;
+        L = pl_ballot(live);
+        nl = popc64(L);
+      }
+      if (nl) {
+        const u32 fc = LBFT_UNI(cal_free, k), bump = LBFT_UNI(cal_bump, k);
+        // lanes whose messages share a bucket (same time; the kind is common): M; sharing a bitmap word (same time >> 3): M3
+        PL<u64> M, M3;
+        LBFT_FOR_LANES(l) { M[l] = live[l] ? L : 0; M3[l] = M[l]; }
+        for (u32 b = 0; (1u << b) <= (u32)P.max_clock; b++) {
+          PL<u32> bit;
+          LBFT_FOR_LANES(l) bit[l] = (live[l] && ((t[l] >> b) & 1u)) ? 1u : 0u;
+          const u64 B = pl_ballot(bit);
+          if (B == 0 || B == L) continue;
+          LBFT_FOR_LANES(l) { u64 m = bit[l] ? B : ~B; M[l] &= m; if (b >= 3u) M3[l] &= m; }
+        }
+        LBFT_CMARK(9);  // grouping
+        // A group = the messages of one bucket, in lane (= stamp) order.  Its first lane (the leader) reads the bucket's tail word; member number rk
+        // takes entry base + rk behind the tail chunk's last one, spilling into up to three new chunks, which the leaders take from the stack of freed
+        // chunks / the bump allocator by rank (a two-bit-plane ballot prefix over the leaders' needs): one dependent load per distinct bucket.
+        PL<u32> lead, rk, gs, tl;
+        LBFT_FOR_LANES(l) {
+          lead[l] = live[l] ? ctz64(M[l]) : l;
+          rk[l] = popc64(M[l] & ((1ULL << l) - 1ULL));
+          gs[l] = popc64(M[l]);
+          tl[l] = (live[l] && rk[l] == 0) ? ldc(l4, calt(t[l] * 4u + kc)) : 0u;
+        }
+        PL<u32> tg;  // the group's tail word, in every member
+        pl_shfl(tg, tl, lead);
+        PL<u32> qn, q0, q1b;  // new chunks a leader needs (0..3)
+        LBFT_FOR_LANES(l) {
+          qn[l] = 0;
+          if (live[l] && rk[l] == 0) { u32 base = tg[l] ? (tg[l] & 63u) : 0u; qn[l] = (base + gs[l] + LBFT_CAL_CE - 1u) / LBFT_CAL_CE - (tg[l] ? 1u : 0u); }
+          q0[l] = qn[l] & 1u; q1b[l] = (qn[l] >> 1) & 1u;
+        }
+        const u64 Q0 = pl_ballot(q0), Q1 = pl_ballot(q1b);
+        const u32 total_new = popc64(Q0) + 2u * popc64(Q1);
+        const u32 pool = P.cal_chunks;
+        PL<u32> id0, id1, id2;
+        LBFT_FOR_LANES(l) {
+          const u64 lower = (1ULL << l) - 1ULL;
+          const u32 a0 = popc64(Q0 & lower) + 2u * popc64(Q1 & lower);
+          u32 ids[3] = {0, 0, 0};
+          LBFT_UNROLL
+          for (u32 j = 0; j < 3; j++)
+            if (j < qn[l]) {
+              u32 ar = a0 + j;  // allocation rank of this chunk
+              u32 c = ar < fc ? ldc(l4, P.off_qlo + fc - 1u - ar) : bump + (ar - fc);
+              ids[j] = c < pool ? c : pool - 1u;  // (pool exhausted: the leader lane raises the fault below; stay in bounds)
+            }
+          id0[l] = ids[0]; id1[l] = ids[1]; id2[l] = ids[2];
+        }
+        PL<u32> g0, g1, g2;
+        pl_shfl(g0, id0, lead); pl_shfl(g1, id1, lead); pl_shfl(g2, id2, lead);
+        LBFT_CMARK(8);  // chunks
+        PL<u32> needbit;
+        LBFT_FOR_LANES(l) {
+          needbit[l] = 0;
+          if (live[l]) {
+            const u32 have = tg[l] ? 1u : 0u, base = tg[l] ? (tg[l] & 63u) : 0u;
+            const u32 e = base + rk[l], q = e / LBFT_CAL_CE, pos = e % LBFT_CAL_CE + 1u;
+            const u32 c = q < have ? (tg[l] >> 6) - 1u : (q - have == 0 ? g0[l] : q - have == 1 ? g1[l] : g2[l]);
+            stc(l4, chw(c, pos), meta[l]);
+            if (rk[l] == 0) {  // the leader: links between the chunks, the bucket's tail (and head) word
+              const u32 idx = t[l] * 4u + kc, n_new = qn[l];
+              if (have && n_new) stc(l4, chw((tg[l] >> 6) - 1u, 0), g0[l] + 1u);
+              if (n_new > 1u) stc(l4, chw(g0[l], 0), g1[l] + 1u);
+              if (n_new > 2u) stc(l4, chw(g1[l], 0), g2[l] + 1u);
+              const u32 lastc = n_new == 0 ? (tg[l] >> 6) - 1u : n_new == 1 ? g0[l] : n_new == 2 ? g1[l] : g2[l];
+              const u32 last_e = base + gs[l] - 1u;
+              stc(l4, calt(idx), ((lastc + 1u) << 6) | (last_e % LBFT_CAL_CE + 1u));
+              if (!have) { stc(l4, calh(idx), ((g0[l] + 1u) << 6) | 1u); needbit[l] = 1; }
+            }
+          }
+        }
+        LBFT_CMARK(10);  // entries, links, heads, tails
+        const u64 NB = pl_ballot(needbit);
+        if (NB) {  // occupancy bits of buckets that were empty: one read-modify-write per bitmap word
+          PL<u32> bits;
+          LBFT_FOR_LANES(l) bits[l] = 0;
+          for (u32 v = 0; v < 8u; v++) {
+            PL<u32> is_v;
+            LBFT_FOR_LANES(l) is_v[l] = (needbit[l] && (t[l] & 7u) == v) ? 1u : 0u;
+            const u64 Bv = pl_ballot(is_v);
+            if (!Bv) continue;
+            LBFT_FOR_LANES(l) if (needbit[l] && (M3[l] & Bv)) bits[l] |= 1u << (v * 4u + kc);
+          }
+          LBFT_FOR_LANES(l) {
+            if (needbit[l] && (M3[l] & NB & ((1ULL << l) - 1ULL)) == 0) {
+              u32 w = P.off_cal_bm + (t[l] >> 3);
+              stc(l4, w, ldc(l4, w) | bits[l]);
+            }
+          }
+        }
+        if (is_k) {
+          qlen += nl;
+          if (qlen > maxq) maxq = qlen;
+          cal_free = fc - (total_new < fc ? total_new : fc);
+          cal_bump = bump + (total_new > fc ? total_new - fc : 0u);
+          if (cal_bump > pool) { fault |= F_QUEUE_OVERFLOW; cal_bump = pool; }
+          u32 lo = (u32)clk * 4u + kc;  // every message lies at or after the current time: a lower bound for the cursor
+          if (lo < cal_cursor) cal_cursor = lo;
+        }
+      }
+    return L;
+  }
+  // ---- cooperative request run (round 6; the bucket-parallel step where it is exact): under the reference's quirk Q1 a DataSyncRequest is answered by the
+  // requester itself with a payload-free response (simulator.rs:441-453) -- the event reads and writes no node, it draws ONE delay and schedules the
+  // response.  The requests of one (time, kind) bucket are therefore independent of one another; only their draws and creation stamps are ordered.  The
+  // chunked calendar hands a wavefront up to 31 consecutive requests of the network in lane k in one line: lanes = requests -- one load each for the
+  // entries, the delay samples off the draw ring by ballot (coop_sample), ONE grouped append of the responses (bulk_append) -- instead of one event-loop
+  // step per request (a third of all events of a 64- / 100-node network).  A response scheduled AT the current time pops before the bucket's remaining
+  // requests (ScheduledEvent::cmp: responses sort before requests): the run stops behind it (coop_sample(.., stop_zero)).
+  u32 req_done;  // leader lane: requests the last coop_requests consumed
+  LBFT_HD void coop_requests(u32 k, u32 budget) {
+    const bool is_k = LBFT_IS_LANE(k);
+    const u32 l4 = LBFT_UNI(lane4, k);
+    const u32 h = LBFT_UNI(cur_h, k), tailw = LBFT_UNI(sp_nx, k), idx = LBFT_UNI(sp_idx, k);
+    const u32 c = (h >> 6) - 1u, pos = h & 63u;
+    u32 avail = ((tailw >> 6) == (h >> 6) ? (tailw & 63u) : LBFT_CAL_CE) - pos + 1u;
+    if (avail > budget) avail = budget;
+    if (is_k && (i32)(idx >> 2) > clock) clock = (i32)(idx >> 2);
+    const i32 clk = (i32)LBFT_UNI((u32)clock, k);
+    PL<u32> meta;
+    LBFT_FOR_LANES(l) meta[l] = l < avail ? ldc(l4, chw(c, pos + l)) : 0u;
+    PL<u32> tm0, tm1;
+    const u32 cnt = coop_sample(k, l4, clk, avail, tm0, tm1, true);
+    PL<u32> live, zero;
+    LBFT_FOR_LANES(l) { live[l] = (l < cnt && tm0[l] != 0xffffffffu) ? 1u : 0u; zero[l] = (live[l] && tm0[l] == (u32)clk) ? 1u : 0u; }
+    const u64 Z = pl_ballot(zero);
+    if (is_k) qlen -= cnt;  // (the pops first: the queue's high-water mark is what the event-by-event order reaches)
+    bulk_append(k, l4, clk, 1u /* 3 - DataSyncResponse */, live, tm0, meta);  // the response carries the request's (node, sender): same event word
+    if (is_k) {
+      ev1 += cnt;
+      stamp += cnt;
+      if (stamp >= (1u << 30)) fault |= F_STAMP_OVERFLOW;
+      if (!Z) cal_cursor = idx;  // (bulk_append lowered the cursor to the responses' kind at this time: nothing was scheduled there)
+      cal_advance(cnt);
+      req_done = cnt;
+    }
+  }
   u32 bulk;       // leader lane: bit 0 = a broadcast is pending, bit 1 = a query-all is pending (set by send_loop)
   u32 bulk_copy;  // leader lane: bit 0 = the hcbr words of a response snapshot are to be copied (a request under quirks bit 0), slot << 8
   u32 bulk_node;  // leader lane: the node whose actions are being processed
@@ -2951,51 +3177,7 @@ LBFT_UNROLL
     LBFT_MARK(16);
     // ---- one delay sample per receiver, in list order ----
     PL<u32> tm0, tm1;  // scheduled time of message j (lane j of tm0 / lane j - 64 of tm1); 0xffffffff = past the horizon
-    LBFT_FOR_LANES(l) { tm0[l] = 0xffffffffu; tm1[l] = 0xffffffffu; }
-    for (u32 j = 0; j < cnt;) {
-      u32 avail = LBFT_UNI(rng.rcnt, k);
-      if (avail == 0) {
-        if (is_k) rng.ring_fill(rng.ring_room() < 64u ? rng.ring_room() : 64u);
-        avail = LBFT_UNI(rng.rcnt, k);
-      }
-      const u32 take = avail < 64u ? avail : 64u;
-      const u32 head = LBFT_UNI(rng.rhead, k);
-      PL<u32> fast, tv;
-      LBFT_FOR_LANES(l) {
-        fast[l] = 0; tv[l] = 0xffffffffu;
-        if (l < take) {
-          u32 e = ring_row + 2u * ((head + l) & ring_mask);
-          u64 bits = (u64)ldc(l4, e) | ((u64)ldc(l4, e + 1u) << 32);
-          i64 d;
-          fast[l] = fast_delay(bits, d) ? 1u : 0u;
-          tv[l] = horizon_time(clk, d);
-        }
-      }
-      const u64 F = pl_ballot(fast);
-      u32 run = ~F ? ctz64(~F) : 64u;  // consecutive first-try samples from the head of the ring
-      if (run > take) run = take;
-      if (run > cnt - j) run = cnt - j;
-      {  // message j + q takes lane q's value (q < run)
-        PL<u32> src, got;
-        LBFT_FOR_LANES(l) src[l] = (l - j) & 63u;
-        pl_shfl(got, tv, src);
-        LBFT_FOR_LANES(l) if (l >= j && l < j + run) tm0[l] = got[l];
-        if (cnt > 64u) {
-          LBFT_FOR_LANES(l) src[l] = (64u + l - j) & 63u;
-          pl_shfl(got, tv, src);
-          LBFT_FOR_LANES(l) if (64u + l >= j && 64u + l < j + run) tm1[l] = got[l];
-        }
-      }
-      if (is_k) { rng.rhead += run; rng.rcnt -= run; rng.draws += run; }
-      j += run;
-      if (j < cnt && run < take) {  // the draw at the head needs the rejection path: the leader samples it serially
-        u32 tvk = 0;
-        if (is_k) tvk = horizon_time(clk, sample_delay());
-        u32 tvu = LBFT_UNI(tvk, k);
-        if (j < 64u) pl_write(tm0, j, tvu); else pl_write(tm1, j - 64u, tvu);
-        j++;
-      }
-    }
+    coop_sample(k, l4, clk, cnt, tm0, tm1, false);
     LBFT_MARK(18);
     // ---- schedule: lanes = messages, 64 at a time ----
     i32 sr = -1, st_ = -1;  // snapshot slot of the notification / of its twin (-1 not needed yet, -2 none available)
@@ -3029,119 +3211,15 @@ LBFT_UNROLL
       } else if (rs < 0) {
         LBFT_FOR_LANES(l) live[l] = 0;
       }
-      u64 L = pl_ballot(live);
-      u32 nl = popc64(L);
-      const u32 qlen_u = LBFT_UNI(qlen, k);
-      const u32 room = P.qcap > qlen_u ? P.qcap - qlen_u : 0u;
-      if (nl > room) {  // queue overflow: the surplus is not scheduled
-        LBFT_FOR_LANES(l) if (live[l] && popc64(L & ((1ULL << l) - 1ULL)) >= room) live[l] = 0;
-        if (is_k) fault |= F_QUEUE_OVERFLOW;
-        L = pl_ballot(live);
-        nl = popc64(L);
+      PL<u32> meta;
+      LBFT_FOR_LANES(l) {
+        u32 snap = which == 0 ? (u32)(twin[l] ? st_ : sr) : (u32)rs;
+        meta[l] = which == 0 ? (r[l] | (node << 8) | (snap << 16)) : (node | (r[l] << 8) | (snap << 16));
       }
+      const u64 L = bulk_append(k, l4, clk, kc, live, t, meta);
+      const u32 nl = popc64(L);
       if (nl) {
-        const u32 fc = LBFT_UNI(cal_free, k), bump = LBFT_UNI(cal_bump, k);
-        const u32 slot_word = which == 0 ? 0u : (u32)rs;
-        // lanes whose messages share a bucket (same time; the kind is common): M; sharing a bitmap word (same time >> 3): M3
-        PL<u64> M, M3;
-        LBFT_FOR_LANES(l) { M[l] = live[l] ? L : 0; M3[l] = M[l]; }
-        for (u32 b = 0; (1u << b) <= (u32)P.max_clock; b++) {
-          PL<u32> bit;
-          LBFT_FOR_LANES(l) bit[l] = (live[l] && ((t[l] >> b) & 1u)) ? 1u : 0u;
-          const u64 B = pl_ballot(bit);
-          if (B == 0 || B == L) continue;
-          LBFT_FOR_LANES(l) { u64 m = bit[l] ? B : ~B; M[l] &= m; if (b >= 3u) M3[l] &= m; }
-        }
-        LBFT_CMARK(9);  // grouping
-        // A group = the messages of one bucket, in lane (= stamp) order.  Its first lane (the leader) reads the bucket's tail word; member number rk
-        // takes entry base + rk behind the tail chunk's last one, spilling into up to three new chunks, which the leaders take from the stack of freed
-        // chunks / the bump allocator by rank (a two-bit-plane ballot prefix over the leaders' needs): one dependent load per distinct bucket.
-        PL<u32> lead, rk, gs, tl;
-        LBFT_FOR_LANES(l) {
-          lead[l] = live[l] ? ctz64(M[l]) : l;
-          rk[l] = popc64(M[l] & ((1ULL << l) - 1ULL));
-          gs[l] = popc64(M[l]);
-          tl[l] = (live[l] && rk[l] == 0) ? ldc(l4, calt(t[l] * 4u + kc)) : 0u;
-        }
-        PL<u32> tg;  // the group's tail word, in every member
-        pl_shfl(tg, tl, lead);
-        PL<u32> qn, q0, q1b;  // new chunks a leader needs (0..3)
-        LBFT_FOR_LANES(l) {
-          qn[l] = 0;
-          if (live[l] && rk[l] == 0) { u32 base = tg[l] ? (tg[l] & 63u) : 0u; qn[l] = (base + gs[l] + LBFT_CAL_CE - 1u) / LBFT_CAL_CE - (tg[l] ? 1u : 0u); }
-          q0[l] = qn[l] & 1u; q1b[l] = (qn[l] >> 1) & 1u;
-        }
-        const u64 Q0 = pl_ballot(q0), Q1 = pl_ballot(q1b);
-        const u32 total_new = popc64(Q0) + 2u * popc64(Q1);
-        const u32 pool = P.cal_chunks;
-        PL<u32> id0, id1, id2;
-        LBFT_FOR_LANES(l) {
-          const u64 lower = (1ULL << l) - 1ULL;
-          const u32 a0 = popc64(Q0 & lower) + 2u * popc64(Q1 & lower);
-          u32 ids[3] = {0, 0, 0};
-          LBFT_UNROLL
-          for (u32 j = 0; j < 3; j++)
-            if (j < qn[l]) {
-              u32 ar = a0 + j;  // allocation rank of this chunk
-              u32 c = ar < fc ? ldc(l4, P.off_qlo + fc - 1u - ar) : bump + (ar - fc);
-              ids[j] = c < pool ? c : pool - 1u;  // (pool exhausted: the leader lane raises the fault below; stay in bounds)
-            }
-          id0[l] = ids[0]; id1[l] = ids[1]; id2[l] = ids[2];
-        }
-        PL<u32> g0, g1, g2;
-        pl_shfl(g0, id0, lead); pl_shfl(g1, id1, lead); pl_shfl(g2, id2, lead);
-        LBFT_CMARK(8);  // chunks
-        PL<u32> needbit;
-        LBFT_FOR_LANES(l) {
-          needbit[l] = 0;
-          if (live[l]) {
-            const u32 have = tg[l] ? 1u : 0u, base = tg[l] ? (tg[l] & 63u) : 0u;
-            const u32 e = base + rk[l], q = e / LBFT_CAL_CE, pos = e % LBFT_CAL_CE + 1u;
-            const u32 c = q < have ? (tg[l] >> 6) - 1u : (q - have == 0 ? g0[l] : q - have == 1 ? g1[l] : g2[l]);
-            u32 snap = which == 0 ? (u32)(twin[l] ? st_ : sr) : slot_word;
-            u32 meta = which == 0 ? (r[l] | (node << 8) | (snap << 16)) : (node | (r[l] << 8) | (snap << 16));
-            stc(l4, chw(c, pos), meta);
-            if (rk[l] == 0) {  // the leader: links between the chunks, the bucket's tail (and head) word
-              const u32 idx = t[l] * 4u + kc, n_new = qn[l];
-              if (have && n_new) stc(l4, chw((tg[l] >> 6) - 1u, 0), g0[l] + 1u);
-              if (n_new > 1u) stc(l4, chw(g0[l], 0), g1[l] + 1u);
-              if (n_new > 2u) stc(l4, chw(g1[l], 0), g2[l] + 1u);
-              const u32 lastc = n_new == 0 ? (tg[l] >> 6) - 1u : n_new == 1 ? g0[l] : n_new == 2 ? g1[l] : g2[l];
-              const u32 last_e = base + gs[l] - 1u;
-              stc(l4, calt(idx), ((lastc + 1u) << 6) | (last_e % LBFT_CAL_CE + 1u));
-              if (!have) { stc(l4, calh(idx), ((g0[l] + 1u) << 6) | 1u); needbit[l] = 1; }
-            }
-          }
-        }
-        LBFT_CMARK(10);  // entries, links, heads, tails
-        const u64 NB = pl_ballot(needbit);
-        if (NB) {  // occupancy bits of buckets that were empty: one read-modify-write per bitmap word
-          PL<u32> bits;
-          LBFT_FOR_LANES(l) bits[l] = 0;
-          for (u32 v = 0; v < 8u; v++) {
-            PL<u32> is_v;
-            LBFT_FOR_LANES(l) is_v[l] = (needbit[l] && (t[l] & 7u) == v) ? 1u : 0u;
-            const u64 Bv = pl_ballot(is_v);
-            if (!Bv) continue;
-            LBFT_FOR_LANES(l) if (needbit[l] && (M3[l] & Bv)) bits[l] |= 1u << (v * 4u + kc);
-          }
-          LBFT_FOR_LANES(l) {
-            if (needbit[l] && (M3[l] & NB & ((1ULL << l) - 1ULL)) == 0) {
-              u32 w = P.off_cal_bm + (t[l] >> 3);
-              stc(l4, w, ldc(l4, w) | bits[l]);
-            }
-          }
-        }
         if (which == 0) { refs += popc64(L & ~T); refs_twin += popc64(L & T); } else rrefs += nl;
-        if (is_k) {
-          qlen += nl;
-          if (qlen > maxq) maxq = qlen;
-          cal_free = fc - (total_new < fc ? total_new : fc);
-          cal_bump = bump + (total_new > fc ? total_new - fc : 0u);
-          if (cal_bump > pool) { fault |= F_QUEUE_OVERFLOW; cal_bump = pool; }
-          u32 lo = (u32)clk * 4u + kc;  // every message lies at or after the current time: a lower bound for the cursor
-          if (lo < cal_cursor) cal_cursor = lo;
-        }
       }
     }
     if (is_k) {
@@ -3465,9 +3543,30 @@ LBFT_UNROLL
       c.node = 0; c.sender = 0; c.kind = 0; c.t_event = 0; c.do_update = false;
       bulk = 0; bulk_copy = 0;
       bool act = go;
+      if (act && P.ring_topup) {  // the generator runs ahead of the consumers in every network of the wavefront at once (see RngT)
+        u32 room = rng.ring_room();
+        rng.ring_fill(room < P.ring_topup ? room : P.ring_topup);
+      }
+      if (REQRUN && !q1() && coop()) {  // a run of >= 2 requests at the head of a network's open bucket: the whole wavefront takes it (coop_requests)
+        bool is_req = false;
+        if (act && qlen != 0) {
+          cal_open();
+          const u32 in_chunk = ((sp_nx >> 6) == (cur_h >> 6) ? (sp_nx & 63u) : LBFT_CAL_CE) - (cur_h & 63u) + 1u;
+          is_req = (sp_idx & 3u) == 2u && in_chunk >= 2u && max_steps - steps >= 2u;
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        unsigned long long rq = __ballot(is_req);
+#else
+        unsigned long long rq = is_req ? 1ULL : 0ULL;
+#endif
+        while (rq) {
+          u32 k = ctz64(rq);
+          rq &= rq - 1;
+          coop_requests(k, LBFT_UNI(max_steps - steps, k));
+        }
+        if (is_req) { steps += req_done; act = false; }
+      }
       if (act) {
-        // the generator runs ahead of the consumers in every network of the wavefront at once (see RngT)
-        if (P.ring_topup) { u32 room = rng.ring_room(); rng.ring_fill(room < P.ring_topup ? room : P.ring_topup); }
         if (!step_begin(c)) { go = false; act = false; } else steps++;
       }
 #if defined(__HIP_DEVICE_COMPILE__)

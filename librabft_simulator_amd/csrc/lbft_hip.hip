@@ -655,6 +655,7 @@ struct lbft_batch {
   u32 rcap = 0; // round-switch trace capacity (rounds per node); 0 = off
   bool keep_stores = false;  // lbft_batch_keep_retired_stores: the record store a node retires at an epoch change is archived in full
   unsigned long long* d_prof = nullptr;
+  unsigned long long* h_counters = nullptr;  // pinned: the counter read-back of a run is one asynchronous copy behind the finalize kernel (round 6)
   size_t lds_bytes = 0;
   u32 run_waves = LBFT_RUN_WAVES;  // wavefronts per workgroup of the run kernel this batch uses (prepare_run)
   float init_ms = 0, run_ms = 0;
@@ -726,6 +727,7 @@ static void free_batch(lbft_batch* b) {
   (void)hipSetDevice(b->device);
   hipFree(b->d_seeds); hipFree(b->d_state); hipFree(b->d_zx); hipFree(b->d_zf); hipFree(b->d_et); hipFree(b->d_dur);
   hipFree(b->d_leaders); hipFree(b->d_weights); hipFree(b->d_prof); hipFree(b->d_unfinished); hipFree(b->d_states_out); hipFree(b->d_counters); hipFree(b->d_scratch); hipFree(b->d_calls); hipFree(b->d_call_out);
+  if (b->h_counters) hipHostFree(b->h_counters);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   if (b->ev2) hipEventDestroy(b->ev2);
@@ -801,6 +803,7 @@ int lbft_batch_create(const lbft_config* cfg, const uint64_t* seeds, size_t n_in
   CREATE_TRY(hipMemcpy(b->d_seeds, seeds, n_instances * sizeof(u64), hipMemcpyHostToDevice));
   CREATE_TRY(hipMalloc(&b->d_unfinished, sizeof(u32)));
   CREATE_TRY(hipMalloc(&b->d_prof, LBFT_NPHASES * sizeof(unsigned long long)));
+  CREATE_TRY(hipMemset(b->d_prof, 0, LBFT_NPHASES * sizeof(unsigned long long)));  // (zeroed per run only in phase-timer builds)
   CREATE_TRY(hipMalloc(&b->d_states_out, n_instances * cfg->num_nodes * sizeof(u64)));
   CREATE_TRY(hipMalloc(&b->d_counters, C_WORDS * sizeof(unsigned long long)));
   CREATE_TRY(hipMalloc(&b->d_scratch, n_instances * cfg->num_nodes * sizeof(u64) + 256));  // + the node-level calls' result words
@@ -1111,7 +1114,7 @@ int lbft_batch_layout(const lbft_batch* b, uint32_t* out) {
   // larger networks the hcbr words an event happens to carry are NOT counted (the figure is a lower bound there).
   // (lbft_k_run0q, LBFT_C0_HCREG: the node's 2n hcbr words ride in its burst -- hc_load / hc_store -- and are counted)
   out[0] = (NF_FIXED_WORDS + 4 * (p.mw - 1) + ((quad_kernel(p) && LBFT_C0_HCREG) ? 2 * p.n : 0)) * 4;
-  out[1] = (p.qpack ? 8 : 12);
+  out[1] = (p.qpack ? 8 : p.qcal ? 4 : 12);  // (the calendar keeps no key: an entry is the 4-byte meta word, plus 1/31 of a chunk's link word)
   out[2] = (S_FIXED_WORDS + 2 * (p.mw - 1) + (p.n <= 4 ? 2 * p.n : 0)) * 4;
   out[3] = (B_WORDS + 4 * (p.mw - 1)) * 4;   // bytes of one block record
   out[4] = p.total_words * 4; // HBM bytes per instance
@@ -1301,7 +1304,9 @@ int lbft_batch_run_until(lbft_batch* b, int64_t max_clock) {
   if (prc != LBFT_OK) return prc;
   Params& p = b->p;
   u32 lpw = p.lpw;
-  HIP_TRY(hipMemsetAsync(b->d_prof, 0, LBFT_NPHASES * sizeof(unsigned long long), b->stream));
+#if defined(LBFT_PHASE_TIMERS)
+  HIP_TRY(hipMemsetAsync(b->d_prof, 0, LBFT_NPHASES * sizeof(unsigned long long), b->stream));  // (product builds never write the phase accumulators)
+#endif
   u32 grid_full = (u32)((b->m + LBFT_BLOCK - 1) / LBFT_BLOCK);
   u32 grid_init = (u32)((b->m + lpw - 1) / lpw);
   HIP_TRY(hipEventRecord(b->ev0, b->stream));
@@ -1393,7 +1398,7 @@ int lbft_batch_run_steps(lbft_batch* b, int64_t max_clock, uint32_t steps, uint6
 }
 
 struct CheckpointHeader {
-  char magic[8];  // "LBFTCKP4"
+  char magic[8];  // "LBFTCKP5"
   u32 n, qcap, scap, bcap, lcap, rcap, total_words, equiv;
   // everything that changes the meaning of the state words without changing their number: the protocol mode, the fault model,
   // the kernel class and the queue discipline / key encoding it implies, the archive capacity of retired record stores
@@ -1411,7 +1416,7 @@ static u32 weights_hash(const std::vector<u32>& w) {
 }
 static void fill_header(const lbft_batch* b, CheckpointHeader& h) {
   memset(&h, 0, sizeof(h));
-  memcpy(h.magic, "LBFTCKP4", 8);
+  memcpy(h.magic, "LBFTCKP5", 8);
   const Params& p = b->p; const lbft_config& c = b->cfg;
   h.n = p.n; h.qcap = p.qcap; h.scap = p.scap; h.bcap = p.bcap; h.lcap = p.lcap; h.rcap = p.rcap; h.total_words = p.total_words;
   h.equiv = p.equiv; h.m = b->m; h.cpe = c.commands_per_epoch; h.max_clock = b->started_max_clock; h.tci = c.target_commit_interval;
@@ -1440,7 +1445,7 @@ int lbft_batch_checkpoint_load(lbft_batch* b, const void* buf, size_t len) {
   if (b->ran || b->manual || b->started) { g_err = "load a checkpoint into a fresh (or reset) batch"; return LBFT_ERR_STATE; }
   CheckpointHeader h;
   memcpy(&h, buf, sizeof(h));
-  if (memcmp(h.magic, "LBFTCKP4", 8) != 0) { g_err = "not a checkpoint (or one of an older format)"; return LBFT_ERR_INVALID; }
+  if (memcmp(h.magic, "LBFTCKP5", 8) != 0) { g_err = "not a checkpoint (or one of an older format)"; return LBFT_ERR_INVALID; }
   // the batch must have been created with the same configuration; capacities come from the checkpoint.  A failed load leaves
   // the batch's own capacities as they were.
   const lbft_config saved_cfg = b->cfg;
@@ -1471,8 +1476,11 @@ static int finalize_run(lbft_batch* b, u32 grid_full, u64 launches) {
   HIP_TRY(hipMemsetAsync(b->d_counters, 0, C_WORDS * sizeof(unsigned long long), b->stream));
   lbft_k_finalize<<<dim3(grid_full, (p.n + LBFT_FINAL_WAVES - 1) / LBFT_FINAL_WAVES), LBFT_BLOCK * LBFT_FINAL_WAVES, 0, b->stream>>>(p, b->d_state, b->d_states_out, b->d_counters);
   HIP_TRY(hipGetLastError());
-  unsigned long long hc[C_WORDS];
-  HIP_TRY(hipMemcpyAsync(hc, b->d_counters, sizeof(hc), hipMemcpyDeviceToHost, b->stream));
+  // reset + init + run + finalize + this copy are ONE stream sequence with a single synchronisation at its end (no host round trip in between); the
+  // destination is pinned, so the copy is a DMA behind the finalize kernel instead of a staged copy with a synchronisation of its own
+  if (!b->h_counters) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&b->h_counters), C_WORDS * sizeof(unsigned long long), hipHostMallocDefault));
+  unsigned long long* hc = b->h_counters;
+  HIP_TRY(hipMemcpyAsync(hc, b->d_counters, C_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
   HIP_TRY(hipEventElapsedTime(&b->init_ms, b->ev0, b->ev1));
   HIP_TRY(hipEventElapsedTime(&b->run_ms, b->ev1, b->ev2));

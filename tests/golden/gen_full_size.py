@@ -4,7 +4,8 @@ run over every instance of the full-size configurations of tools/configs.py, one
 hashes) of all its nodes.  Hours of CPU time on 8 cores, minutes on the GPU box's 256 host threads -- which is where round 6 ran it
 (`gpurun -- python tests/golden/gen_full_size.py --out gpurun_out/full_size_digests.npz --device`), never inside the test suite.
 
-    python tests/golden/gen_full_size.py [names ...] [--count c5named...=1024] [--merge tests/golden/full_size_digests.npz] [--out PATH] [--device]
+    python tests/golden/gen_full_size.py [names ...] [--count c5named...=1024] [--merge A.npz --merge B.npz] [--out PATH] [--device]
+    python tests/golden/gen_full_size.py --none --merge A.npz --merge B.npz --out tests/golden/full_size_digests.npz     # only merge
 
 --count NAME=K   only the first K instances of configuration NAME (prefix match) get a digest; the rest stay "not covered" (c5named: 49 core-seconds per
                  instance on the oracle)
@@ -46,9 +47,10 @@ def main():
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
     ap.add_argument("--chunk", type=int, default=0, help="instances per oracle call (0 = 4 x threads)")
     ap.add_argument("--count", action="append", default=[], help="NAME=K: only the first K instances of NAME")
-    ap.add_argument("--merge", default=None)
+    ap.add_argument("--merge", action="append", default=[], help="existing fixture file(s) to start from (repeatable: the union of what they cover)")
     ap.add_argument("--out", default=fsd.FIXTURE)
     ap.add_argument("--device", action="store_true")
+    ap.add_argument("--none", action="store_true", help="run nothing: merge the given fixtures and write the result")
     ap.add_argument("--log", default=None)
     a = ap.parse_args()
     limits = {}
@@ -63,18 +65,37 @@ def main():
 
     table, meta = {}, {"configs": {}, "digest": "blake2b-64(u32le commit_counts || u32le active_rounds || u64le last_states) per instance",
                        "oracle": "oracle/lbft_oracle.cpp, math_mode 1, seeds = instance index + 1"}
-    if a.merge and os.path.exists(a.merge):
-        with np.load(a.merge, allow_pickle=False) as z:
-            meta = json.loads(str(z["meta"]))
+    for path in a.merge:
+        if not os.path.exists(path):
+            continue
+        with np.load(path, allow_pickle=False) as z:
+            m2 = json.loads(str(z["meta"]))
+            for k, v in m2.get("configs", {}).items():
+                if v.get("covered", 0) >= meta.get("configs", {}).get(k, {}).get("covered", 0):
+                    meta.setdefault("configs", {})[k] = v
             for name in fsd.FULL_SIZE:
                 if name in z.files:
-                    table[name] = (z[name].copy(), z[name + "__covered"].astype(bool))
+                    dg2, cov2 = z[name].copy(), z[name + "__covered"].astype(bool)
+                    if name in table:
+                        dg1, cov1 = table[name]
+                        both = cov1 & cov2
+                        assert (dg1[both] == dg2[both]).all(), "the merged fixtures disagree on %s" % name
+                        dg1[cov2] = dg2[cov2]
+                        table[name] = (dg1, cov1 | cov2)
+                    else:
+                        table[name] = (dg2, cov2)
     try:
         meta["oracle_source_sha1"] = subprocess.check_output(["sha1sum", os.path.join(ROOT, "oracle", "lbft_oracle.cpp")]).decode().split()[0]
     except Exception:
         pass
     chunk = a.chunk or 4 * a.threads
     os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+    if a.none:
+        a.names = []
+        for name, (dg, cov) in table.items():
+            meta.setdefault("configs", {}).setdefault(name, {})["covered"] = int(cov.sum())
+        save(a.out, table, meta)
+        say("merged: " + ", ".join("%s %d" % (k, int(v[1].sum())) for k, v in table.items()))
     for name in a.names:
         c = CONFIGS[name]
         m = c["instances"]

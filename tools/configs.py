@@ -108,14 +108,19 @@ def roofline(layout, k, kernel_ms, name=None):
     r = k["events"][0] / max(ev, 1)
     bpe = 2 * s_node + s_evt * (1 + p) + s_notif * 2 * r
     pops = ev - k.get("timers_folded", 0)
-    ex = pops * s_node + k.get("node_updates", pops) * s_node + 2 * pops * s_evt + 2 * k["events"][0] * s_notif
+    # (round 6) outside kernel class 0, a request under the reference's quirk Q1 -- answered by the requester itself with a payload-free response -- no longer
+    # fetches the node's rows: those pops move an event entry and nothing else
+    cls = layout["kernel_class"] & 255
+    q1 = bool(CONFIGS.get(name, {}).get("quirks", 0) & 1) if name else bool(layout["kernel_class"] & 4096)
+    node_reads = pops - (k["events"][1] if (cls != 0 and not q1) else 0)
+    ex = node_reads * s_node + k.get("node_updates", pops) * s_node + 2 * pops * s_evt + 2 * k["events"][0] * s_notif
     sec = kernel_ms * 1e-3
     t = measured_traffic(name) if name else None
     # `frac` = the algorithmic bytes of what the device EXECUTES over the kernel time (as bench.py since round 4); the SURVEY 8(d) figure
     # charged to every reference-equivalent event stands beside it
     out = {"bound": "hbm", "kernel": kernel_name(layout), "kernel_ms": kernel_ms, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "algorithmic_gb_per_launch": ex / 1e9, "achieved": ex / sec / 1e9, "frac": ex / sec / 1e9 / HBM_PEAK_GBS,
-           "queue_pops": pops, "node_updates": k.get("node_updates"), "pops_per_s_per_cu": pops / sec / 256.0,
+           "queue_pops": pops, "node_row_reads": node_reads, "node_updates": k.get("node_updates"), "pops_per_s_per_cu": pops / sec / 256.0,
            "frac_reference_equivalent": ev * bpe / sec / 1e9 / HBM_PEAK_GBS,
            "reference_equivalent": {"bytes_per_event": bpe, "gb_per_launch": ev * bpe / 1e9, "achieved": ev * bpe / sec / 1e9,
                                     "frac": ev * bpe / sec / 1e9 / HBM_PEAK_GBS},
