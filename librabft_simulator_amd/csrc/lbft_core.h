@@ -755,9 +755,9 @@ struct SimT {
   static constexpr bool F_SPEC = LEAN2 ? (LBFT_LEAN_SPEC != 0) : (LBFT_SPEC != 0);
   static constexpr bool COOP = BIG;
 #ifndef LBFT_REQRUN
-#define LBFT_REQRUN 1  // (round 6) lbft_k_run2l: runs of Q1 requests are taken by the whole wavefront (coop_requests)
+#define LBFT_REQRUN 1  // (round 6) lbft_k_run2l / lbft_k_run2q: the requests at the head of a bucket are taken by the whole wavefront, a chunk at a time (coop_requests)
 #endif
-  static constexpr bool REQRUN = CLS == 5 && LBFT_REQRUN != 0;
+  static constexpr bool REQRUN = (CLS == 5 || CLS == 7) && LBFT_REQRUN != 0;
   static constexpr bool RING = BIG || CLS == 3;
   bool coop_on;  // set by run_coop: the event loop is being run by a whole wavefront
   static constexpr u32 PB = CLS == 9 ? LBFT_POP_BATCH_QUAD : LBFT_POP_BATCH;  // slots per batch of the packed queue's scan
@@ -3071,6 +3071,78 @@ LBFT_UNROLL
   // step per request (a third of all events of a 64- / 100-node network).  A response scheduled AT the current time pops before the bucket's remaining
   // requests (ScheduledEvent::cmp: responses sort before requests): the run stops behind it (coop_sample(.., stop_zero)).
   u32 req_done;  // leader lane: requests the last coop_requests consumed
+  // quirks bit 0 (requests answered by the PEER, handle_request data_sync.rs:183-207): handling a request reads the peer's store and writes nothing of any
+  // node, so the requests of a run stay independent -- lanes = requests, each lane stages the peer of ITS request (the node cache of a lane is dead between
+  // two events, and for the length of this call every lane addresses the column of the network in lane k) and writes the response snapshot of its own.
+  // What is shared is resolved by ballots: the request slots (the n - 1 requests of a query-all share one: the first lane of each group of equal slots takes
+  // the group's references off at once), the stack of free slots (released slots are pushed, response slots popped, by rank).  Lanes whose response
+  // falls behind the horizon take no slot (event by event the slot would be taken and handed back: nothing of it remains); `live` loses the lanes that
+  // find the stack empty, meta[l] gets the response's slot.
+  LBFT_HD void coop_answer_requests(u32 k, u32 l4, u32 cnt, PL<u32>& live, PL<u32>& meta) {
+    const bool is_k = LBFT_IS_LANE(k);
+    const u32 own_l4 = lane4;
+    lane4 = l4;
+    // the requests' slots: epoch | references << 16, certificates
+    PL<u32> rslot, ew, rcerts, inrun;
+    LBFT_FOR_LANES(l) {
+      inrun[l] = l < cnt ? 1u : 0u;
+      rslot[l] = meta[l] >> 16; ew[l] = 0; rcerts[l] = 0;
+      if (inrun[l]) { u32 qb = sfw(rslot[l], 0); ew[l] = ld(qb + S_EPOCH); rcerts[l] = ld(qb + S_CERTS); }
+    }
+    const u64 RUN = pl_ballot(inrun);
+    PL<u64> MS;  // lanes of the run whose requests share this lane's slot
+    LBFT_FOR_LANES(l) MS[l] = inrun[l] ? RUN : 0;
+    for (u32 b = 0; (1u << b) < P.scap; b++) {
+      PL<u32> bit;
+      LBFT_FOR_LANES(l) bit[l] = (inrun[l] && ((rslot[l] >> b) & 1u)) ? 1u : 0u;
+      const u64 B = pl_ballot(bit);
+      if (B == 0 || B == RUN) continue;
+      LBFT_FOR_LANES(l) MS[l] &= bit[l] ? B : ~B;
+    }
+    PL<u32> freed;
+    LBFT_FOR_LANES(l) {
+      freed[l] = 0;
+      if (inrun[l] && (MS[l] & ((1ULL << l) - 1ULL)) == 0) {  // first lane of its group
+        u32 left = (ew[l] >> 16) - popc64(MS[l]);
+        st(sfw(rslot[l], S_EPOCH), (ew[l] & 0xffffu) | (left << 16));
+        freed[l] = left == 0 ? 1u : 0u;
+      }
+    }
+    const u64 FR = pl_ballot(freed);
+    const u32 sf0 = LBFT_UNI(snap_free, k);
+    LBFT_FOR_LANES(l) if (freed[l]) st(OFFSFREE() + sf0 + popc64(FR & ((1ULL << l) - 1ULL)), rslot[l]);
+    const u32 sf1 = sf0 + popc64(FR);
+    // response slots for the lanes whose response will be scheduled
+    const u64 A = pl_ballot(live);
+    PL<u32> rs;
+    LBFT_FOR_LANES(l) {
+      rs[l] = 0;
+      if (live[l]) {
+        u32 rank = popc64(A & ((1ULL << l) - 1ULL));
+        if (rank < sf1) rs[l] = ld(OFFSFREE() + sf1 - 1u - rank); else live[l] = 0;  // (no slot left: not scheduled, the stamp is consumed)
+      }
+    }
+    const u32 want = popc64(A), got = want < sf1 ? want : sf1;
+    if (is_k) {
+      if (got < want) fault |= F_SNAP_OVERFLOW;
+      snap_free = sf1 - got;
+      u32 in_use = P.scap - snap_free;
+      if (in_use > maxsnap) maxsnap = in_use;
+    }
+    // the peer's store at request time + the request it answers (handle_request); one reference: the response event
+    LBFT_FOR_LANES(l) {
+      if (live[l]) {
+        const u32 peer = (meta[l] >> 8) & 0xffu;
+        begin_node(peer);
+        const u32 rb = sfw(rs[l], 0);
+        write_store_snapshot(peer, rb, false);
+        st(sqw(rb, 0), ew[l] & 0xffffu); st(sqw(rb, 1), rcerts[l]);
+        st(rb + S_EPOCH, nf(peer, NF_EPOCH) | (1u << 16));
+        meta[l] = (meta[l] & 0xffffu) | (rs[l] << 16);
+      }
+    }
+    lane4 = own_l4;
+  }
   LBFT_HD void coop_requests(u32 k, u32 budget) {
     const bool is_k = LBFT_IS_LANE(k);
     const u32 l4 = LBFT_UNI(lane4, k);
@@ -3087,6 +3159,7 @@ LBFT_UNROLL
     PL<u32> live, zero;
     LBFT_FOR_LANES(l) { live[l] = (l < cnt && tm0[l] != 0xffffffffu) ? 1u : 0u; zero[l] = (live[l] && tm0[l] == (u32)clk) ? 1u : 0u; }
     const u64 Z = pl_ballot(zero);
+    if (q1()) coop_answer_requests(k, l4, cnt, live, meta);  // quirks bit 0: the peers' stores travel with the responses
     if (is_k) qlen -= cnt;  // (the pops first: the queue's high-water mark is what the event-by-event order reaches)
     bulk_append(k, l4, clk, 1u /* 3 - DataSyncResponse */, live, tm0, meta);  // the response carries the request's (node, sender): same event word
     if (is_k) {
@@ -3547,9 +3620,9 @@ LBFT_UNROLL
         u32 room = rng.ring_room();
         rng.ring_fill(room < P.ring_topup ? room : P.ring_topup);
       }
-      if (REQRUN && !q1() && coop()) {  // a run of >= 2 requests at the head of a network's open bucket: the whole wavefront takes it (coop_requests)
+      if (REQRUN && coop()) {  // a run of >= 2 requests at the head of a network's open bucket: the whole wavefront takes it (coop_requests)
         bool is_req = false;
-        if (act && qlen != 0) {
+        if (act && qlen != 0 && !(q1() && cont != 0)) {  // (a response still going through its epochs comes first: step_begin resumes it)
           cal_open();
           const u32 in_chunk = ((sp_nx >> 6) == (cur_h >> 6) ? (sp_nx & 63u) : LBFT_CAL_CE) - (cur_h & 63u) + 1u;
           is_req = (sp_idx & 3u) == 2u && in_chunk >= 2u && max_steps - steps >= 2u;
