@@ -18,7 +18,7 @@ LIVE = {"c3_65536x4": 256, "c4_16384x64_longtail_equivocators": 8, "c4live_16384
         "c5live_8192x100_rotating_rights_epochs_fixed": 4, "c5named_8192x100_weighted_epoch_every_50_commits": 0}
 # ... and what the device tests assert about the coverage
 MIN_COVERED = {"c3_65536x4": 65536, "c4_16384x64_longtail_equivocators": 16384, "c4live_16384x64_longtail_equivocators_fixed": 16384,
-               "c5_8192x100_weighted_epochs": 8192, "c5live_8192x100_rotating_rights_epochs_fixed": 8192, "c5named_8192x100_weighted_epoch_every_50_commits": 256}
+               "c5_8192x100_weighted_epochs": 8192, "c5live_8192x100_rotating_rights_epochs_fixed": 8192, "c5named_8192x100_weighted_epoch_every_50_commits": 1024}
 
 
 def test_fixture_covers_every_full_size_configuration():
@@ -30,7 +30,9 @@ def test_fixture_covers_every_full_size_configuration():
         dg, cov = table[name]
         assert len(dg) == len(cov) == CONFIGS[name]["instances"]
         assert int(cov.sum()) >= MIN_COVERED[name], (name, int(cov.sum()))
-        assert len(np.unique(dg[cov])) == int(cov.sum())    # distinct seeds -> distinct runs: a constant or zero-filled column would be a broken fixture
+        # distinct seeds -> (nearly always) distinct runs: a constant or zero-filled column would be a broken fixture.  Not `==`: short integer-time
+        # histories do coincide (c5live instances 1546 / 3311: 7 commits at every node with the same proposers and times; the stalled c4 networks)
+        assert len(np.unique(dg[cov])) >= 0.95 * int(cov.sum()), (name, len(np.unique(dg[cov])))
         assert name in meta["configs"]
 
 
