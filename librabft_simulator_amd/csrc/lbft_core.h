@@ -758,6 +758,10 @@ struct SimT {
 #define LBFT_REQRUN 1  // (round 6) lbft_k_run2l / lbft_k_run2q: the requests at the head of a bucket are taken by the whole wavefront, a chunk at a time (coop_requests)
 #endif
   static constexpr bool REQRUN = (CLS == 5 || CLS == 7) && LBFT_REQRUN != 0;
+#ifndef LBFT_RSPRUN
+#define LBFT_RSPRUN 1  // (round 6) lbft_k_run2l: runs of responses whose update_node is a no-op are taken by the whole wavefront too (coop_responses)
+#endif
+  static constexpr bool RSPRUN = REQRUN && CLS == 5 && LBFT_RSPRUN != 0;
   static constexpr bool RING = BIG || CLS == 3;
   bool coop_on;  // set by run_coop: the event loop is being run by a whole wavefront
   static constexpr u32 PB = CLS == 9 ? LBFT_POP_BATCH_QUAD : LBFT_POP_BATCH;  // slots per batch of the packed queue's scan
@@ -2283,6 +2287,38 @@ LBFT_UNROLL
     return act;
   }
 
+  // ---- (round 6) would update_node(node, lclock) change anything?  Evaluated on the node's staged fixed words alone (no block record): true = PROVABLY
+  // nothing -- the pacemaker's epoch and round stand (pacemaker.rs:160-178), there is nothing to propose (:180-187), neither the timeout deadline nor the
+  // query-all deadline has passed (:188-205), no vote is due (the proposed block's round IS the current round, record_store.rs proposed_block, and it is not
+  // above latest_voted_round: node.rs:259-262 fails whatever the locked round says), no election was won (record_store.rs:702-738), nothing is left to commit
+  // (node.rs:313-350: highest_committed_round is the tracker's), and the tracker neither moves nor asks for a query-all (node.rs:364-396).  `next` = the
+  // next_scheduled_update the call returns then.  false = anything else: the caller takes the ordinary path (conservative wherever a block record would
+  // have to be read to decide).  The response runs (coop_responses) rest on it: an event whose update is a no-op touches the node's timer words only.
+  LBFT_HD bool update_is_noop(u32 node, i64 lclock, i64& next) const {
+    const i64 lqat = (i64)(i32)nf(node, NF_LQAT);
+    const u32 hqc = nf(node, NF_HQC_ROUND), htc = nf(node, NF_HTC_ROUND);
+    const u32 ar = (hqc > htc ? hqc : htc) + 1;
+    const u32 epoch = nf(node, NF_EPOCH);
+    bool ok = epoch == nf(node, NF_PM_EPOCH) && ar == nf(node, NF_PM_ROUND);
+    const u32 pb = proposed_block(node);
+    ok = ok && !(nf(node, NF_PM_LEADER) == node && pb == 0);
+    const i64 start = (i64)(i32)nf(node, NF_PM_START);
+    const i64 dur = (i64)(nf(node, NF_PM_DUR_LO) | ((u64)nf(node, NF_PM_DUR_HI) << 32));
+    const bool has_timeout = (ar == nf(node, NF_CUR_ROUND)) && am_test(node, NF_TO_MASK, node);
+    i64 nx;
+    if (!has_timeout) nx = (i64)((u64)start + (u64)dur);
+    else nx = (i64)((u64)lqat + (u64)f64_to_i64_sat(P.lambda * (double)dur));
+    ok = ok && lclock < nx;
+    ok = ok && !(pb != 0 && nf(node, NF_CUR_ROUND) > nf(node, NF_LVR));
+    ok = ok && (nf(node, NF_ELECTION) & 0xffu) != 1u;
+    ok = ok && epoch <= nf(node, NF_TR_EPOCH) && nf(node, NF_HC_ROUND) <= nf(node, NF_TR_HCR);
+    const i64 lct = (i64)(i32)nf(node, NF_TR_LCT);
+    const i64 dl = (i64)((u64)(lct > lqat ? lct : lqat) + (u64)P.tci);
+    ok = ok && lclock < dl;
+    next = dl < nx ? dl : nx;
+    return ok;
+  }
+
   // ---- DataSyncNode::create_notification (data_sync.rs:82-111) into snapshot slot ----
   // hcbr words of the authors in `mask` (author = author0 + bit): node buffer -> snapshot, four loads in flight at a
   // time (a load-store-load-store chain would be one memory round trip per author)
@@ -2421,15 +2457,28 @@ LBFT_UNROLL
     // authors the node already holds are not fetched, the others several per round trip.
     const bool pre = LBFT_RESP_FAST && have;  // (the response's own store: these words came with its first burst)
     u32 tc_round = pre ? rp.tc_round : ld(base + S_TC_ROUND), to_round = pre ? rp.to_round : ld(base + S_TO_ROUND);
-    for (u32 k = 0; k < MW(); k++) {
-      if (tc_round != nf(node, NF_CUR_ROUND)) break;
-      u32 tk = (pre && k == 0) ? rp.tc_mask0 : ld(k == 0 ? base + S_TC_MASK : base + S_FIXED_WORDS + 2 * NN() + (k - 1));
-      insert_timeouts_at(node, base + S_FIXED_WORDS, tk, tc_round, 32 * k);
+    // (the words of a set are fetched together, before the insertions -- see handle_notification)
+    if (tc_round == nf(node, NF_CUR_ROUND)) {
+      const u32 xb = base + S_FIXED_WORDS + 2 * NN();
+      u32 x0 = pre ? rp.tc_mask0 : ld(base + S_TC_MASK), x1 = 0, x2 = 0, x3 = 0;
+      if (1 < MW()) x1 = ld(xb);
+      if (2 < MW()) x2 = ld(xb + 1u);
+      if (3 < MW()) x3 = ld(xb + 2u);
+      for (u32 k = 0; k < MW(); k++) {
+        if (tc_round != nf(node, NF_CUR_ROUND)) break;
+        insert_timeouts_at(node, base + S_FIXED_WORDS, k == 0 ? x0 : k == 1 ? x1 : k == 2 ? x2 : x3, tc_round, 32 * k);
+      }
     }
-    for (u32 k = 0; k < MW(); k++) {
-      if (to_round != nf(node, NF_CUR_ROUND)) break;
-      u32 ok = (pre && k == 0) ? rp.to_mask0 : ld(k == 0 ? base + S_TO_MASK : base + S_FIXED_WORDS + 2 * NN() + (MW() - 1) + (k - 1));
-      insert_timeouts_at(node, base + S_FIXED_WORDS + NN(), ok, to_round, 32 * k);
+    if (to_round == nf(node, NF_CUR_ROUND)) {
+      const u32 xb = base + S_FIXED_WORDS + 2 * NN() + (MW() - 1);
+      u32 x0 = pre ? rp.to_mask0 : ld(base + S_TO_MASK), x1 = 0, x2 = 0, x3 = 0;
+      if (1 < MW()) x1 = ld(xb);
+      if (2 < MW()) x2 = ld(xb + 1u);
+      if (3 < MW()) x3 = ld(xb + 2u);
+      for (u32 k = 0; k < MW(); k++) {
+        if (to_round != nf(node, NF_CUR_ROUND)) break;
+        insert_timeouts_at(node, base + S_FIXED_WORDS + NN(), k == 0 ? x0 : k == 1 ? x1 : k == 2 ? x2 : x3, to_round, 32 * k);
+      }
     }
     // the proposed block, unless the burst above found it known to the node already (a bit that is only ever set)
     if (pb && !((pbk >> (node & 31u)) & 1u)) insert_block(node, pb);
@@ -2627,13 +2676,19 @@ LBFT_UNROLL
       // (record_store.rs:390-415), and the current round only moves forward while a set is inserted: a set whose
       // round differs from the current round on entry is skipped as a whole -- which is the common case, because
       // every notification keeps carrying the sender's last timeout certificate (data_sync.rs:93-96).
+      // (large networks: the extension words of a set -- authors >= 32 -- are fetched together, before the insertions whose stores the compiler
+      // cannot move a load across: one round trip per set instead of one per word; the slot's words do not change while it is referenced)
       if (tc_round == nf(node, NF_CUR_ROUND)) {
         LBFT_STAT(35);
+        u32 x1 = 0, x2 = 0, x3 = 0;
+        if (wide()) { if (1 < MW()) x1 = ld(sxw(slot, 0, 1)); if (2 < MW()) x2 = ld(sxw(slot, 0, 2)); if (3 < MW()) x3 = ld(sxw(slot, 0, 3)); }
         insert_timeouts(node, slot, S_FIXED_WORDS, sn.w[S_TC_MASK], tc_round);
-        for (u32 k = 1; wide() && k < MW(); k++) insert_timeouts(node, slot, S_FIXED_WORDS, ld(sxw(slot, 0, k)), tc_round, 32 * k);
+        for (u32 k = 1; wide() && k < MW(); k++) insert_timeouts(node, slot, S_FIXED_WORDS, k == 1 ? x1 : k == 2 ? x2 : x3, tc_round, 32 * k);
       }
       if (to_round == nf(node, NF_CUR_ROUND)) {
         if (sn.w[S_TO_MASK]) LBFT_STAT(36);
+        u32 x1 = 0, x2 = 0, x3 = 0;
+        if (wide()) { if (1 < MW()) x1 = ld(sxw(slot, 1, 1)); if (2 < MW()) x2 = ld(sxw(slot, 1, 2)); if (3 < MW()) x3 = ld(sxw(slot, 1, 3)); }
         if (small_sets()) {  // hcbr words already fetched with the notification
           for (u32 m = sn.w[S_TO_MASK] & 15u; m; m &= m - 1) {  // (one inlined copy of insert_timeout, not one per author)
             u32 a = ctz32(m);
@@ -2642,7 +2697,7 @@ LBFT_UNROLL
           }
         } else
         insert_timeouts(node, slot, S_FIXED_WORDS + NN(), sn.w[S_TO_MASK], to_round);
-        for (u32 k = 1; wide() && k < MW(); k++) insert_timeouts(node, slot, S_FIXED_WORDS + NN(), ld(sxw(slot, 1, k)), to_round, 32 * k);
+        for (u32 k = 1; wide() && k < MW(); k++) insert_timeouts(node, slot, S_FIXED_WORDS + NN(), k == 1 ? x1 : k == 2 ? x2 : x3, to_round, 32 * k);
       }
       LBFT_MARK(23);
       if (vote) { LBFT_STAT(37); insert_vote(node, sender, vote, blk_get(vote)); }
@@ -3170,6 +3225,105 @@ LBFT_UNROLL
       cal_advance(cnt);
       req_done = cnt;
     }
+    LBFT_STAT(30); LBFT_STATN(31, cnt);
+    LBFT_FOR_LANES(l) if (l < cnt) LBFT_HOOK_POP(clk, 1u, meta[l] & 0xffu, (meta[l] >> 8) & 0xffu);  // (host analysis tools: the run's events are pops too)
+    LBFT_MARK(4);  // (diagnostic builds: a request run is charged to the requests' phase)
+  }
+  // ---- cooperative response run (round 6), reference semantics (quirk Q1): a DataSyncResponse carries nothing insertable (simulator.rs:454-466 on a response the
+  // requester built from its own store), so the event is update_node + the timer of process_node_actions, and on a settled node -- every other event left it
+  // right behind an update_node -- that update changes nothing (update_is_noop).  The responses at the head of the open bucket are taken by the whole
+  // wavefront, lanes = events: each lane stages the node of ITS event (for the length of this call every lane addresses the column of the network in lane k;
+  // a lane's node cache is dead between two events), evaluates the predicate and the timer it schedules; the run ends in front of the first event whose
+  // update would do anything -- that one takes the ordinary step.  Events of the run for the SAME node are a group: event by event the first schedules (or
+  // folds) the timer, every later one folds into it (same node state, same time: process_node_actions' duplicate-timer rule); the group's first lane writes
+  // the node's four timer words once.  Creation stamps by lane, timers appended in lane order (bulk_append), counters by ballot.
+  u32 rsp_done;  // leader lane: responses the last coop_responses consumed (0: the head event is not a no-op)
+  LBFT_HD void coop_responses(u32 k, u32 budget) {
+    const bool is_k = LBFT_IS_LANE(k);
+    const u32 l4 = LBFT_UNI(lane4, k);
+    const u32 h = LBFT_UNI(cur_h, k), tailw = LBFT_UNI(sp_nx, k), idx = LBFT_UNI(sp_idx, k);
+    const u32 c = (h >> 6) - 1u, pos = h & 63u;
+    u32 avail = ((tailw >> 6) == (h >> 6) ? (tailw & 63u) : LBFT_CAL_CE) - pos + 1u;
+    if (avail > budget) avail = budget;
+    if (is_k && (i32)(idx >> 2) > clock) clock = (i32)(idx >> 2);
+    const i32 clk = (i32)LBFT_UNI((u32)clock, k);
+    const u32 stamp0 = LBFT_UNI(stamp, k);
+    const u32 own_l4 = lane4;
+    lane4 = l4;
+    PL<u32> in, node, ok, tnew, ign, ltt, dups;
+    LBFT_FOR_LANES(l) {
+      in[l] = l < avail ? 1u : 0u;
+      node[l] = 0; ok[l] = 0; tnew[l] = 0xffffffffu; ign[l] = 0; ltt[l] = 0; dups[l] = 0;
+      if (in[l]) {
+        const u32 nd = ld(chw(c, pos + l)) & 0xffu;
+        node[l] = nd;
+        begin_node(nd);
+        const i64 startup = (i64)(i32)nf(nd, NF_STARTUP);
+        i64 next;
+        ok[l] = update_is_noop(nd, (i64)clk - startup, next) ? 1u : 0u;
+        i64 t_new = (i64)((u64)next + (u64)startup);  // process_node_actions (simulator.rs:296-325)
+        if (t_new < (i64)clk + 1) t_new = (i64)clk + 1;
+        i64 ig = t_new - 1;
+        if (ig > (i64)P.max_clock) ig = P.max_clock;
+        ign[l] = (u32)(i32)ig;
+        tnew[l] = t_new <= (i64)P.max_clock ? (u32)t_new : 0xffffffffu;
+        ltt[l] = nf(nd, NF_LAST_TIMER_T); dups[l] = nf(nd, NF_TIMER_DUPS);
+      }
+    }
+    PL<u32> bad;
+    LBFT_FOR_LANES(l) bad[l] = (in[l] && !ok[l]) ? 1u : 0u;
+    const u64 BAD = pl_ballot(bad);
+    const u32 cnt = BAD ? ctz64(BAD) : avail;
+    LBFT_STAT(13); LBFT_STATN(14, cnt); if (BAD) LBFT_STAT(15); if (!cnt) LBFT_STAT(29);
+    if (cnt) {
+      const u64 RUN = (1ULL << cnt) - 1ULL;  // (cnt <= 31)
+      PL<u64> MS;  // lanes of the run whose events are for this lane's node
+      LBFT_FOR_LANES(l) MS[l] = l < cnt ? RUN : 0;
+      for (u32 b = 0; (1u << b) < NN(); b++) {
+        PL<u32> bit;
+        LBFT_FOR_LANES(l) bit[l] = (l < cnt && ((node[l] >> b) & 1u)) ? 1u : 0u;
+        const u64 B = pl_ballot(bit);
+        if (B == 0 || B == RUN) continue;
+        LBFT_FOR_LANES(l) MS[l] &= bit[l] ? B : ~B;
+      }
+      PL<u32> live, fold, tmeta;
+      LBFT_FOR_LANES(l) {
+        live[l] = 0; fold[l] = 0; tmeta[l] = node[l];  // a timer's event word: its node (no sender, no slot)
+        if (l < cnt) {
+          const bool first = (MS[l] & ((1ULL << l) - 1ULL)) == 0;
+          const bool sched = tnew[l] != 0xffffffffu;               // (past the horizon: neither queued nor folded, the stamp is consumed)
+          const bool first_folds = sched && tnew[l] == ltt[l];     // the node's pending timer has this very time
+          live[l] = (first && sched && !first_folds) ? 1u : 0u;
+          fold[l] = (sched && (!first || first_folds)) ? 1u : 0u;
+          if (first) {
+            const u32 g = popc64(MS[l]), last_l = 63u - (u32)clz64(MS[l]);
+            const u32 folds = sched ? (first_folds ? g : g - 1u) : 0u;
+            st(nfw(node[l], NF_IGNORE_UNTIL), ign[l]);
+            if (sched && !first_folds) st(nfw(node[l], NF_LAST_TIMER_T), tnew[l]);
+            if (folds) { st(nfw(node[l], NF_TIMER_DUPS), dups[l] + folds); st(nfw(node[l], NF_DUP_STAMP), stamp0 + last_l); }
+          }
+        }
+      }
+      const u64 F = pl_ballot(fold);
+      if (is_k) qlen -= cnt;  // (the pops first: the queue's high-water mark is what the event-by-event order reaches)
+      bulk_append(k, l4, clk, 0u /* 3 - UpdateTimer */, live, tnew, tmeta);
+      lane4 = own_l4;
+      if (is_k) {
+        ev2 += cnt;
+#if !defined(LBFT_NO_EXEC_COUNTERS)
+        n_upd += cnt;
+        n_fold += popc64(F);
+#endif
+        stamp += cnt;
+        if (stamp >= (1u << 30)) fault |= F_STAMP_OVERFLOW;
+        cal_cursor = idx;  // (bulk_append lowered the cursor to the timers' kind at this time; every timer lies at a later time)
+        cal_advance(cnt);
+      }
+    }
+    lane4 = own_l4;
+    if (is_k) rsp_done = cnt;
+    LBFT_FOR_LANES(l) if (l < cnt) LBFT_HOOK_POP(clk, 2u, node[l], 0u);  // (host analysis tools: the run's events are pops too)
+    LBFT_MARK(5);  // (diagnostic builds: a response run is charged to the responses' phase)
   }
   u32 bulk;       // leader lane: bit 0 = a broadcast is pending, bit 1 = a query-all is pending (set by send_loop)
   u32 bulk_copy;  // leader lane: bit 0 = the hcbr words of a response snapshot are to be copied (a request under quirks bit 0), slot << 8
@@ -3621,11 +3775,12 @@ LBFT_UNROLL
         rng.ring_fill(room < P.ring_topup ? room : P.ring_topup);
       }
       if (REQRUN && coop()) {  // a run of >= 2 requests at the head of a network's open bucket: the whole wavefront takes it (coop_requests)
-        bool is_req = false;
+        bool is_req = false, is_rsp = false;
         if (act && qlen != 0 && !(q1() && cont != 0)) {  // (a response still going through its epochs comes first: step_begin resumes it)
           cal_open();
           const u32 in_chunk = ((sp_nx >> 6) == (cur_h >> 6) ? (sp_nx & 63u) : LBFT_CAL_CE) - (cur_h & 63u) + 1u;
           is_req = (sp_idx & 3u) == 2u && in_chunk >= 2u && max_steps - steps >= 2u;
+          is_rsp = RSPRUN && !q1() && (sp_idx & 3u) == 1u && in_chunk >= 2u && max_steps - steps >= 2u;
         }
 #if defined(__HIP_DEVICE_COMPILE__)
         unsigned long long rq = __ballot(is_req);
@@ -3638,6 +3793,19 @@ LBFT_UNROLL
           coop_requests(k, LBFT_UNI(max_steps - steps, k));
         }
         if (is_req) { steps += req_done; act = false; }
+        if (RSPRUN && !q1()) {  // ... and a run of responses whose update_node is a no-op (coop_responses)
+#if defined(__HIP_DEVICE_COMPILE__)
+          unsigned long long rs = __ballot(is_rsp);
+#else
+          unsigned long long rs = is_rsp ? 1ULL : 0ULL;
+#endif
+          while (rs) {
+            u32 k = ctz64(rs);
+            rs &= rs - 1;
+            coop_responses(k, LBFT_UNI(max_steps - steps, k));
+          }
+          if (is_rsp && rsp_done) { steps += rsp_done; act = false; }  // (0: the head event's update does something -- the ordinary step takes it)
+        }
       }
       if (act) {
         if (!step_begin(c)) { go = false; act = false; } else steps++;
