@@ -368,6 +368,10 @@ enum BlockField : u32 {
 
 // Snapshot (notification, data_sync.rs:16-39) rows; followed by tc_hcbr[n], to_hcbr[n].
 enum SnapField : u32 { S_EPOCH = 0, S_CERTS /* hcc | hqc << 16 */, S_PROP_VOTE /* proposed | vote << 16 */, S_TC_ROUND, S_TO_ROUND, S_TC_MASK, S_TO_MASK, S_FIXED_WORDS };
+// Large networks (round 6): bit 31 of S_TC_ROUND / S_TO_ROUND = "an extension word of this set (authors >= 32) is non-zero".  The receiver of a notification /
+// response whose set is of its current round fetched those words in a round trip of their own -- nearly always to find them empty (a healthy network has no
+// timeouts in flight); the writer has them in registers.  Rounds stay far below 2^31.
+#define LBFT_S_XFLAG 0x80000000u
 
 #define LBFT_CAL_MAX_CLOCK 16383  // calendar queue: (max_clock + 1) * 4 buckets per instance (two rows + one bitmap bit each: 0.5 MiB
                                   // per instance at the cap; the host side falls back to the heap when the batch would not fit the HBM)
@@ -2349,8 +2353,10 @@ LBFT_UNROLL
     st(base + S_CERTS, nf(node, NF_HCC_BLK) | (nf(node, NF_HQC_BLK) << 16));
     st(base + S_PROP_VOTE, nf(node, NF_PROPOSED_BLK));  // current_proposed_block, whoever proposed it
     u32 htc = nf(node, NF_HTC_ROUND);
-    st(base + S_TC_ROUND, htc);
-    st(base + S_TO_ROUND, nf(node, NF_CUR_ROUND));
+    u32 xt = 0, xo = 0;
+    for (u32 k = 1; wide() && k < MW(); k++) { xt |= htc ? am_word(node, NF_TC_MASK, k) : 0u; xo |= am_word(node, NF_TO_MASK, k); }
+    st(base + S_TC_ROUND, htc | (xt ? LBFT_S_XFLAG : 0u));
+    st(base + S_TO_ROUND, nf(node, NF_CUR_ROUND) | (xo ? LBFT_S_XFLAG : 0u));
     u32 tc_sel = nf(node, NF_TC_SEL);
     for (u32 k = 0; k < MW(); k++) {
       u32 tk = htc ? am_word(node, NF_TC_MASK, k) : 0, ok = am_word(node, NF_TO_MASK, k);
@@ -2456,15 +2462,17 @@ LBFT_UNROLL
     // moves forward while a set is inserted (see handle_notification): a set of another round is skipped as a whole, the
     // authors the node already holds are not fetched, the others several per round trip.
     const bool pre = LBFT_RESP_FAST && have;  // (the response's own store: these words came with its first burst)
-    u32 tc_round = pre ? rp.tc_round : ld(base + S_TC_ROUND), to_round = pre ? rp.to_round : ld(base + S_TO_ROUND);
+    const u32 tc_raw = pre ? rp.tc_round : ld(base + S_TC_ROUND), to_raw = pre ? rp.to_round : ld(base + S_TO_ROUND);
+    const u32 tc_round = wide() ? tc_raw & ~LBFT_S_XFLAG : tc_raw, to_round = wide() ? to_raw & ~LBFT_S_XFLAG : to_raw;
+    const bool xft = wide() && (tc_raw & LBFT_S_XFLAG) != 0, xfo = wide() && (to_raw & LBFT_S_XFLAG) != 0;  // (see LBFT_S_XFLAG: clear = the extension words are zero)
     // (the words of a set are fetched together, before the insertions -- see handle_notification)
     if (tc_round == nf(node, NF_CUR_ROUND)) {
       const u32 xb = base + S_FIXED_WORDS + 2 * NN();
       u32 x0 = pre ? rp.tc_mask0 : ld(base + S_TC_MASK), x1 = 0, x2 = 0, x3 = 0;
-      if (1 < MW()) x1 = ld(xb);
-      if (2 < MW()) x2 = ld(xb + 1u);
-      if (3 < MW()) x3 = ld(xb + 2u);
-      for (u32 k = 0; k < MW(); k++) {
+      if (xft && 1 < MW()) x1 = ld(xb);
+      if (xft && 2 < MW()) x2 = ld(xb + 1u);
+      if (xft && 3 < MW()) x3 = ld(xb + 2u);
+      for (u32 k = 0; k < (xft ? MW() : 1u); k++) {
         if (tc_round != nf(node, NF_CUR_ROUND)) break;
         insert_timeouts_at(node, base + S_FIXED_WORDS, k == 0 ? x0 : k == 1 ? x1 : k == 2 ? x2 : x3, tc_round, 32 * k);
       }
@@ -2472,10 +2480,10 @@ LBFT_UNROLL
     if (to_round == nf(node, NF_CUR_ROUND)) {
       const u32 xb = base + S_FIXED_WORDS + 2 * NN() + (MW() - 1);
       u32 x0 = pre ? rp.to_mask0 : ld(base + S_TO_MASK), x1 = 0, x2 = 0, x3 = 0;
-      if (1 < MW()) x1 = ld(xb);
-      if (2 < MW()) x2 = ld(xb + 1u);
-      if (3 < MW()) x3 = ld(xb + 2u);
-      for (u32 k = 0; k < MW(); k++) {
+      if (xfo && 1 < MW()) x1 = ld(xb);
+      if (xfo && 2 < MW()) x2 = ld(xb + 1u);
+      if (xfo && 3 < MW()) x3 = ld(xb + 2u);
+      for (u32 k = 0; k < (xfo ? MW() : 1u); k++) {
         if (to_round != nf(node, NF_CUR_ROUND)) break;
         insert_timeouts_at(node, base + S_FIXED_WORDS + NN(), k == 0 ? x0 : k == 1 ? x1 : k == 2 ? x2 : x3, to_round, 32 * k);
       }
@@ -2537,8 +2545,8 @@ LBFT_UNROLL
     const u32 base = sfw(slot, 0), cur = nf(node, NF_CUR_ROUND);
     for (u32 k = 0; k < MW(); k++) {
       const u32 have = am_word(node, NF_TO_MASK, k);
-      if (rp.tc_round == cur) { u32 tk = k == 0 ? rp.tc_mask0 : ld(base + S_FIXED_WORDS + 2 * NN() + (k - 1)); if (tk & ~have) return false; }
-      if (rp.to_round == cur) { u32 ok = k == 0 ? rp.to_mask0 : ld(base + S_FIXED_WORDS + 2 * NN() + (MW() - 1) + (k - 1)); if (ok & ~have) return false; }
+      if ((rp.tc_round & ~LBFT_S_XFLAG) == cur) { u32 tk = k == 0 ? rp.tc_mask0 : ld(base + S_FIXED_WORDS + 2 * NN() + (k - 1)); if (tk & ~have) return false; }
+      if ((rp.to_round & ~LBFT_S_XFLAG) == cur) { u32 ok = k == 0 ? rp.to_mask0 : ld(base + S_FIXED_WORDS + 2 * NN() + (MW() - 1) + (k - 1)); if (ok & ~have) return false; }
     }
     const u32 pb = rp.prop & 0xffffu;
     if (pb) {
@@ -2579,8 +2587,10 @@ LBFT_UNROLL
     u32 htc = nf(node, NF_HTC_ROUND);
     u32 tcm = htc ? nf(node, NF_TC_MASK) : 0;
     u32 tom = nf(node, NF_TO_MASK);
-    stf(sb0, S_TC_ROUND, htc);
-    stf(sb0, S_TO_ROUND, nf(node, NF_CUR_ROUND));
+    u32 xt = 0, xo = 0;
+    for (u32 k = 1; wide() && k < MW(); k++) { xt |= htc ? am_word(node, NF_TC_MASK, k) : 0u; xo |= am_word(node, NF_TO_MASK, k); }
+    stf(sb0, S_TC_ROUND, htc | (xt ? LBFT_S_XFLAG : 0u));
+    stf(sb0, S_TO_ROUND, nf(node, NF_CUR_ROUND) | (xo ? LBFT_S_XFLAG : 0u));
     stf(sb0, S_TC_MASK, tcm);
     stf(sb0, S_TO_MASK, tom);
     u32 tc_sel = nf(node, NF_TC_SEL);
@@ -2703,7 +2713,8 @@ LBFT_UNROLL
       u32 pb = pv & 0xffffu, vote = pv >> 16;
       if (pb) { LBFT_STAT(34); insert_block(node, pb); }
       LBFT_MARK(22);
-      u32 tc_round = sn.w[S_TC_ROUND], to_round = sn.w[S_TO_ROUND];
+      const u32 tc_raw = sn.w[S_TC_ROUND], to_raw = sn.w[S_TO_ROUND];
+      u32 tc_round = wide() ? tc_raw & ~LBFT_S_XFLAG : tc_raw, to_round = wide() ? to_raw & ~LBFT_S_XFLAG : to_raw;
       // A timeout whose round is not the receiver's current round is rejected without side effects
       // (record_store.rs:390-415), and the current round only moves forward while a set is inserted: a set whose
       // round differs from the current round on entry is skipped as a whole -- which is the common case, because
@@ -2713,14 +2724,16 @@ LBFT_UNROLL
       if (tc_round == nf(node, NF_CUR_ROUND)) {
         LBFT_STAT(35);
         u32 x1 = 0, x2 = 0, x3 = 0;
-        if (wide()) { if (1 < MW()) x1 = ld(sxw(slot, 0, 1)); if (2 < MW()) x2 = ld(sxw(slot, 0, 2)); if (3 < MW()) x3 = ld(sxw(slot, 0, 3)); }
+        const bool xf = wide() && (tc_raw & LBFT_S_XFLAG) != 0;  // (clear: the extension words are zero -- not fetched, nothing to insert from them)
+        if (xf) { if (1 < MW()) x1 = ld(sxw(slot, 0, 1)); if (2 < MW()) x2 = ld(sxw(slot, 0, 2)); if (3 < MW()) x3 = ld(sxw(slot, 0, 3)); }
         insert_timeouts(node, slot, S_FIXED_WORDS, sn.w[S_TC_MASK], tc_round);
-        for (u32 k = 1; wide() && k < MW(); k++) insert_timeouts(node, slot, S_FIXED_WORDS, k == 1 ? x1 : k == 2 ? x2 : x3, tc_round, 32 * k);
+        for (u32 k = 1; xf && k < MW(); k++) insert_timeouts(node, slot, S_FIXED_WORDS, k == 1 ? x1 : k == 2 ? x2 : x3, tc_round, 32 * k);
       }
       if (to_round == nf(node, NF_CUR_ROUND)) {
         if (sn.w[S_TO_MASK]) LBFT_STAT(36);
         u32 x1 = 0, x2 = 0, x3 = 0;
-        if (wide()) { if (1 < MW()) x1 = ld(sxw(slot, 1, 1)); if (2 < MW()) x2 = ld(sxw(slot, 1, 2)); if (3 < MW()) x3 = ld(sxw(slot, 1, 3)); }
+        const bool xf = wide() && (to_raw & LBFT_S_XFLAG) != 0;
+        if (xf) { if (1 < MW()) x1 = ld(sxw(slot, 1, 1)); if (2 < MW()) x2 = ld(sxw(slot, 1, 2)); if (3 < MW()) x3 = ld(sxw(slot, 1, 3)); }
         if (small_sets()) {  // hcbr words already fetched with the notification
           for (u32 m = sn.w[S_TO_MASK] & 15u; m; m &= m - 1) {  // (one inlined copy of insert_timeout, not one per author)
             u32 a = ctz32(m);
@@ -2729,7 +2742,7 @@ LBFT_UNROLL
           }
         } else
         insert_timeouts(node, slot, S_FIXED_WORDS + NN(), sn.w[S_TO_MASK], to_round);
-        for (u32 k = 1; wide() && k < MW(); k++) insert_timeouts(node, slot, S_FIXED_WORDS + NN(), k == 1 ? x1 : k == 2 ? x2 : x3, to_round, 32 * k);
+        for (u32 k = 1; xf && k < MW(); k++) insert_timeouts(node, slot, S_FIXED_WORDS + NN(), k == 1 ? x1 : k == 2 ? x2 : x3, to_round, 32 * k);
       }
       LBFT_MARK(23);
       if (vote) { LBFT_STAT(37); insert_vote(node, sender, vote, blk_get(vote)); }

@@ -483,9 +483,14 @@ inline int load_node_image(const Params& dp, u32* hw, u32 node, const u32* weigh
       std::vector<u32> tcm(mw, 0), tom(mw, 0);
       if (st.has_tc && st.htc_round) for (auto& t : st.tc) { tcm[t.author >> 5] |= 1u << (t.author & 31u); s.st(base + S_FIXED_WORDS + (u32)t.author, (u32)t.hcbr); }
       for (auto& t : st.to) { tom[t.author >> 5] |= 1u << (t.author & 31u); s.st(base + S_FIXED_WORDS + n + (u32)t.author, (u32)t.hcbr); }
+      u32 xt = 0, xo = 0;
       for (u32 k = 0; k < mw; k++) {
         s.st(k == 0 ? base + S_TC_MASK : base + S_FIXED_WORDS + 2 * n + (k - 1), tcm[k]);
         s.st(k == 0 ? base + S_TO_MASK : base + S_FIXED_WORDS + 2 * n + (mw - 1) + (k - 1), tom[k]);
+        if (k) { xt |= tcm[k]; xo |= tom[k]; }
+      }
+      if (mw > 1) {  // (LBFT_S_XFLAG: "an extension word of the set is non-zero", as SimT::write_store_snapshot marks it)
+        s.st(base + S_TC_ROUND, (u32)st.htc_round | (xt ? LBFT_S_XFLAG : 0u)); s.st(base + S_TO_ROUND, (u32)st.cur_round | (xo ? LBFT_S_XFLAG : 0u));
       }
     }
   }
