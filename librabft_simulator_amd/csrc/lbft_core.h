@@ -762,6 +762,9 @@ struct SimT {
 #define LBFT_REQRUN 1  // (round 6) lbft_k_run2l / lbft_k_run2q: the requests at the head of a bucket are taken by the whole wavefront, a chunk at a time (coop_requests)
 #endif
   static constexpr bool REQRUN = (CLS == 5 || CLS == 7) && LBFT_REQRUN != 0;
+#ifndef LBFT_RUN_MIN
+#define LBFT_RUN_MIN 2u  // events at the head of a bucket's chunk from which the whole wavefront takes them as a run
+#endif
 #ifndef LBFT_RSPRUN
 #define LBFT_RSPRUN 1  // (round 6) lbft_k_run2l: runs of responses whose update_node is a no-op are taken by the whole wavefront too (coop_responses)
 #endif
@@ -3833,8 +3836,8 @@ LBFT_UNROLL
         if (act && qlen != 0 && !(q1() && cont != 0)) {  // (a response still going through its epochs comes first: step_begin resumes it)
           cal_open();
           const u32 in_chunk = ((sp_nx >> 6) == (cur_h >> 6) ? (sp_nx & 63u) : LBFT_CAL_CE) - (cur_h & 63u) + 1u;
-          is_req = (sp_idx & 3u) == 2u && in_chunk >= 2u && max_steps - steps >= 2u;
-          is_rsp = RSPRUN && !q1() && (sp_idx & 3u) == 1u && in_chunk >= 2u && max_steps - steps >= 2u;
+          is_req = (sp_idx & 3u) == 2u && in_chunk >= LBFT_RUN_MIN && max_steps - steps >= LBFT_RUN_MIN;
+          is_rsp = RSPRUN && !q1() && (sp_idx & 3u) == 1u && in_chunk >= LBFT_RUN_MIN && max_steps - steps >= LBFT_RUN_MIN;
         }
 #if defined(__HIP_DEVICE_COMPILE__)
         unsigned long long rq = __ballot(is_req);

@@ -59,10 +59,11 @@ PARITY_SAMPLE = {
     "c2_1024x4_lognormal": "all 1 024 instances", "c2_1024x4_uniform": "all 1 024 instances",
     "c3_65536x4": "all 65 536 instances (262 144 nodes), math_mode 0; 1 024 in every bench line",
     "c3shard_8192x4": "the first 8 192 instances of the c3 check",
-    "c4_16384x64_longtail_equivocators": "all 16 384 instances",
-    "c5_8192x100_weighted_epochs": "512 of 8 192 instances per test run; ALL 8 192 once, offline against the oracle: profiles/r05/full_size_c5_all_8192.txt",
-    "c4live_16384x64_longtail_equivocators_fixed": "2 048 of 16 384 instances per test run",
-    "c5live_8192x100_rotating_rights_epochs_fixed": "1 024 of 8 192 instances per test run; ALL 8 192 once, offline against the oracle: profiles/r05/full_size_c5live_all_8192.txt",
+    "c4_16384x64_longtail_equivocators": "all 16 384 instances in every suite run (committed oracle digests, computed on two machines) + 64 live on the oracle",
+    "c5_8192x100_weighted_epochs": "all 8 192 instances in every suite run (committed oracle digests, tests/golden/full_size_digests.npz) + 64 live on the oracle",
+    "c4live_16384x64_longtail_equivocators_fixed": "all 16 384 instances in every suite run (committed oracle digests) + 128 live on the oracle",
+    "c5live_8192x100_rotating_rights_epochs_fixed": "all 8 192 instances in every suite run (committed oracle digests) + 64 live on the oracle",
+    "c5named_8192x100_weighted_epoch_every_50_commits": "the first 1 024 of 8 192 instances in every suite run (committed oracle digests: 49 core-seconds of oracle time per instance) + 16 live",
 }
 # (round 6: every instance the oracle has a digest for in tests/golden/full_size_digests.npz is compared in every suite run -- tests/full_size_digest.py)
 # What a line measures, where that is not what its name suggests (printed with the line)

@@ -5,13 +5,13 @@
 #   bash tools/gpu_configs_profile.sh r02 "c4_16384x64_longtail_equivocators c4live_16384x64_longtail_equivocators_fixed"
 set -u
 TAG=${1:-rXX}
-PROF_CONFIGS=${2:-"c2_1024x4_lognormal c2_1024x4_uniform c3_65536x4 c3shard_8192x4 c4_16384x64_longtail_equivocators c5_8192x100_weighted_epochs c4live_16384x64_longtail_equivocators_fixed c5live_8192x100_rotating_rights_epochs_fixed"}
+PROF_CONFIGS=${2:-"c2_1024x4_lognormal c2_1024x4_uniform c3_65536x4 c3shard_8192x4 c4_16384x64_longtail_equivocators c5_8192x100_weighted_epochs c4live_16384x64_longtail_equivocators_fixed c5live_8192x100_rotating_rights_epochs_fixed c5named_8192x100_weighted_epoch_every_50_commits"}
 OUT=gpurun_out/configs_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 # (first pass: timings; the lines are rewritten with each configuration's own PMC traffic at the end)
-timeout 900 python tools/configs.py c2_1024x4_lognormal c2_1024x4_uniform c3_65536x4 c3shard_8192x4 c4_16384x64_longtail_equivocators c5_8192x100_weighted_epochs \
-  c4live_16384x64_longtail_equivocators_fixed c5live_8192x100_rotating_rights_epochs_fixed > $OUT/baseline_configs.jsonl 2> $OUT/configs.err
+timeout 1200 python tools/configs.py c2_1024x4_lognormal c2_1024x4_uniform c3_65536x4 c3shard_8192x4 c4_16384x64_longtail_equivocators c5_8192x100_weighted_epochs \
+  c4live_16384x64_longtail_equivocators_fixed c5live_8192x100_rotating_rights_epochs_fixed c5named_8192x100_weighted_epoch_every_50_commits > $OUT/baseline_configs.jsonl 2> $OUT/configs.err
 python - "$OUT" <<'PY'
 import json, sys
 for line in open(sys.argv[1] + "/baseline_configs.jsonl"):
@@ -32,7 +32,7 @@ for cfg in $PROF_CONFIGS; do
   head -3 $OUT/$cfg.kernel_stats.csv; head -30 $OUT/$cfg.pmc.json
 done
 # second pass of the lines, now with `roofline.traffic` from each configuration's own FETCH / WRITE passes
-LBFT_PMC_DIR=$OUT timeout 900 python tools/configs.py $(echo c2_1024x4_lognormal c2_1024x4_uniform c3_65536x4 c3shard_8192x4 $PROF_CONFIGS | tr " " "\n" | awk '!s[$0]++' | tr "\n" " ") > $OUT/baseline_configs_with_traffic.jsonl 2>> $OUT/configs.err
+LBFT_PMC_DIR=$OUT timeout 1200 python tools/configs.py $(echo c2_1024x4_lognormal c2_1024x4_uniform c3_65536x4 c3shard_8192x4 $PROF_CONFIGS | tr " " "\n" | awk '!s[$0]++' | tr "\n" " ") > $OUT/baseline_configs_with_traffic.jsonl 2>> $OUT/configs.err
 python - "$OUT" <<'PY'
 import json, sys
 for line in open(sys.argv[1] + "/baseline_configs_with_traffic.jsonl"):
