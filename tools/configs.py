@@ -114,7 +114,11 @@ def roofline(layout, k, kernel_ms, name=None):
     cls = layout["kernel_class"] & 255
     q1 = bool(CONFIGS.get(name, {}).get("quirks", 0) & 1) if name else bool(layout["kernel_class"] & 4096)
     node_reads = pops - (k["events"][1] if (cls != 0 and not q1) else 0)
-    ex = node_reads * s_node + k.get("node_updates", pops) * s_node + 2 * pops * s_evt + 2 * k["events"][0] * s_notif
+    # ... and a response under the reference's semantics inserts nothing: its update_node is a no-op on a settled node (the response runs prove it for 88-99.5 % of
+    # them, coop_responses), what is written back is the node's four timer words (16 B), not its row
+    upd = k.get("node_updates", pops)
+    noop_resp = min(k["events"][2], upd) if (cls != 0 and not q1) else 0
+    ex = node_reads * s_node + (upd - noop_resp) * s_node + noop_resp * 16 + 2 * pops * s_evt + 2 * k["events"][0] * s_notif
     sec = kernel_ms * 1e-3
     t = measured_traffic(name) if name else None
     # `frac` = the algorithmic bytes of what the device EXECUTES over the kernel time (as bench.py since round 4); the SURVEY 8(d) figure
@@ -160,7 +164,8 @@ def run(name, scale=1.0, reps=1, lpw=0):
                 "epochs_min_max": [int(res.epochs.min()), int(res.epochs.max())]}
     out = {"config": name, "note": NOTES.get(name), "parity": PARITY.get(name, PARITY_DEFAULT), "parity_sample": PARITY_SAMPLE.get(name), "liveness": liveness, "roofline": roofline(sim.layout(), k, best, name), "instances": m, "nodes": c["nodes"], "max_clock": c["max_clock"], "kernel_ms": best,
            "rounds_per_s": k["rounds"] / (best * 1e-3), "commits_per_s": k["commits"] / (best * 1e-3),
-           "events_per_s": sum(k["events"]) / (best * 1e-3), "events": sum(k["events"]), "rounds": k["rounds"], "commits": k["commits"],
+           "events_per_s": sum(k["events"]) / (best * 1e-3), "events": sum(k["events"]),
+           "events_by_kind": {"notify": k["events"][0], "request": k["events"][1], "response": k["events"][2], "timer": k["events"][3]}, "rounds": k["rounds"], "commits": k["commits"],
            "faulted_instances": k["faulted_instances"], "max_queue": k["max_queue"], "max_snapshots": k["max_snapshots"],
            "device_gb": sim.device_bytes() / 1e9, "layout": sim.layout()}
     try:  # diagnostic builds (LBFT_HIP_LIB=.../liblbft_hip_prof.so): share of wavefront cycles per phase of the event loop
