@@ -769,6 +769,13 @@ struct SimT {
 #define LBFT_RSPRUN 1  // (round 6) lbft_k_run2l: runs of responses whose update_node is a no-op are taken by the whole wavefront too (coop_responses)
 #endif
   static constexpr bool RSPRUN = REQRUN && CLS == 5 && LBFT_RSPRUN != 0;
+#ifndef LBFT_NTF_MIN
+#define LBFT_NTF_MIN LBFT_RUN_MIN  // events at the head of a bucket's chunk from which a notification run is attempted
+#endif
+#ifndef LBFT_NTFRUN
+#define LBFT_NTFRUN 1  // (round 6) lbft_k_run2l / lbft_k_run2q: runs of notifications that provably leave their node as it was (coop_notifications)
+#endif
+  static constexpr bool NTFRUN = REQRUN && LBFT_NTFRUN != 0;
   static constexpr bool RING = BIG || CLS == 3;
   bool coop_on;  // set by run_coop: the event loop is being run by a whole wavefront
   static constexpr u32 PB = CLS == 9 ? LBFT_POP_BATCH_QUAD : LBFT_POP_BATCH;  // slots per batch of the packed queue's scan
@@ -3373,6 +3380,190 @@ LBFT_UNROLL
     LBFT_FOR_LANES(l) if (l < cnt) LBFT_HOOK_POP(clk, 2u, node[l], 0u);  // (host analysis tools: the run's events are pops too)
     LBFT_MARK(5);  // (diagnostic builds: a response run is charged to the responses' phase)
   }
+  // ---- cooperative notification run (round 6).  56-66 % of a large network's notifications leave their node exactly as it was -- every notification carries
+  // the sender's certificates, proposal, vote and timeouts, and most receivers hold all of it already -- and they come in streaks (tests/tools/run_stats.cpp:
+  // 70-85 % of them in streaks of >= 8 of one bucket).  notification_is_inert proves it per event from the snapshot's fixed words, the node's staged words and,
+  // for the (at most four) blocks the snapshot names, the round / epoch words and the node's bit in the "known" / "QC" sets -- loads of immutable words and of
+  // bits that only this node's events set; it is conservative wherever handle_notification would have to look further (a set extension word, a timeout's
+  // highest_certified_block_round).  With update_is_noop the event then only releases its reference to the snapshot and schedules / folds the node's timer.
+  // cert: the certificate block of a notification in the given roles (data_sync.rs:125-148)
+  LBFT_HD bool cert_is_inert(u32 node, u32 b, bool as_hcc, bool as_hqc, u32 epoch) const {
+    const u32 bb = boff(bfw(b, 0));
+    const u32 r = ldf(bb, B_ROUND), qe = ldf(bb, B_EPOCH);
+    u32 kw, qw;
+    if (!wide() || node < 32) { kw = ldf(bb, B_KNOWN); qw = ldf(bb, B_QC); }
+    else { kw = ld(bxw(b, B_KNOWN, node >> 5)); qw = ld(bxw(b, B_QC, node >> 5)); }
+    const bool known = ((kw >> (node & 31u)) & 1u) != 0, hasqc = ((qw >> (node & 31u)) & 1u) != 0;
+    if (qe > epoch) return false;          // should_sync
+    if (qe < epoch) return true;           // not of this store: nothing inserted, nothing asked
+    if (known && !hasqc) return false;     // insert_qc would insert it ("already inserted" / "the certified block must be verified first" return untouched)
+    if (as_hcc && r > nf(node, NF_HC_ROUND) + 2) return false;
+    if (as_hqc && r > nf(node, NF_HQC_ROUND)) return false;
+    return true;
+  }
+  LBFT_HD bool notification_is_inert(u32 node, u32 sender, const Snap& sn) const {
+    const u32 epoch = nf(node, NF_EPOCH), n_epoch = sn.w[S_EPOCH];
+    if (n_epoch > epoch) return false;     // should_sync
+    const u32 certs = sn.w[S_CERTS], hcc = certs & 0xffffu, hqc = certs >> 16;
+    const bool c_hcc = hcc != 0 && hcc != nf(node, NF_HCC_BLK), c_hqc = hqc != 0 && hqc != nf(node, NF_HQC_BLK);
+    bool ok = true;
+    if (c_hcc) ok = cert_is_inert(node, hcc, true, c_hqc && hqc == hcc, epoch);
+    if (ok && c_hqc && !(c_hcc && hqc == hcc)) ok = cert_is_inert(node, hqc, false, true, epoch);
+    if (!ok) return false;
+    if (n_epoch != epoch) return true;     // the rest of a notification is only looked at within one epoch (data_sync.rs:149)
+    const u32 pv = sn.w[S_PROP_VOTE], pb = pv & 0xffffu, vote = pv >> 16;
+    const u32 xk = node >> 5;
+    if (pb) {  // insert_block returns at once for a block the node holds
+      const u32 kw = (!wide() || node < 32) ? ld(bfw(pb, B_KNOWN)) : ld(bxw(pb, B_KNOWN, xk));
+      if (!((kw >> (node & 31u)) & 1u)) return false;
+    }
+    const u32 cur = nf(node, NF_CUR_ROUND);
+    const u32 tc_raw = sn.w[S_TC_ROUND], to_raw = sn.w[S_TO_ROUND];
+    const u32 tc_round = wide() ? tc_raw & ~LBFT_S_XFLAG : tc_raw, to_round = wide() ? to_raw & ~LBFT_S_XFLAG : to_raw;
+    const u32 have0 = nf(node, NF_TO_MASK);
+    if (tc_round == cur && ((sn.w[S_TC_MASK] & ~have0) != 0 || (wide() && (tc_raw & LBFT_S_XFLAG) != 0))) return false;
+    if (to_round == cur && ((sn.w[S_TO_MASK] & ~have0) != 0 || (wide() && (to_raw & LBFT_S_XFLAG) != 0))) return false;
+    if (vote) {  // insert_vote: unknown block, another round, or an author already counted -> untouched
+      const u32 vb = boff(bfw(vote, 0));
+      const u32 vr = ldf(vb, B_ROUND);
+      const u32 kw = (!wide() || node < 32) ? ldf(vb, B_KNOWN) : ld(bxw(vote, B_KNOWN, xk));
+      const bool known = ((kw >> (node & 31u)) & 1u) != 0;
+      if (known && vr == cur && !am_test(node, NF_BAL0_AUTHORS, sender) && !am_test(node, NF_BAL1_AUTHORS, sender)) return false;
+    }
+    return true;
+  }
+  u32 ntf_done;  // leader lane: notifications the last coop_notifications consumed
+  u32 ntf_skip;  // leader lane: notifications behind it that were seen NOT to be inert -- they take ordinary steps without another attempt
+  // ALL networks of the wavefront at once: the wavefront's 64 lanes are split into one SEGMENT of W = 64 / lpw lanes per network (network s = lane s, its
+  // segment = lanes [s W, (s + 1) W)); lane j of a segment takes the j-th event at the head of its network's open bucket and addresses that network's column.
+  // What a run of ONE network needs from its leader lane (head and tail words, clock, stamp, free-slot count) comes by shuffle, ballots are cut down to the
+  // segment; every leader then books its own segment's result.  (One network after the other, the first form of this run, a run cost as much as an ordinary
+  // step of the whole wavefront: c5 -4 %, c4 +7 % -- profiles/r06.)  A run never appends to the calendar: an event whose timer is NOT folded into the node's
+  // pending one (1-2 % of them) ends the run like an event that is not inert and takes the ordinary step.  `want`: this lane's network has a notification
+  // run to try; `budget`: events it may still process in this launch.  The host build (one network per object) is one segment of 64 lanes.
+  LBFT_HD void coop_notifications(bool want, u32 budget) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 lane_ = lbft_lane_id();
+    const u32 W = 64u / P.lpw;                       // (lpw is a power of two <= 32 here: run_coop asks for W >= 2)
+    const u32 seg = lane_ / W, seg_sh = seg * W;     // the network this lane works for, first lane of its segment
+    const u32 lead_sh = lane_ * W;                   // (leader role) first lane of the segment that works for THIS lane's network
+    const bool leader = lane_ < P.lpw;
+#define LBFT_SEGV(x) ((u32)__shfl((int)(x), (int)seg, 64))
+#else
+    const u32 W = 64u, seg_sh = 0u, lead_sh = 0u;
+    const bool leader = true;
+#define LBFT_SEGV(x) ((u32)(x))
+#endif
+    const u64 wmask = W >= 64u ? ~0ULL : (1ULL << (W & 63u)) - 1ULL;
+    // leader side: what its segment may take
+    u32 own_avail = 0;
+    if (leader && want) {
+      own_avail = ((sp_nx >> 6) == (cur_h >> 6) ? (sp_nx & 63u) : LBFT_CAL_CE) - (cur_h & 63u) + 1u;
+      if (own_avail > budget) own_avail = budget;
+      if (own_avail > W) own_avail = W;
+      if ((i32)(sp_idx >> 2) > clock) clock = (i32)(sp_idx >> 2);
+    }
+    // worker side
+    const u32 avail = LBFT_SEGV(own_avail), l4 = LBFT_SEGV(lane4), h = LBFT_SEGV(cur_h);
+    const i32 clk = (i32)LBFT_SEGV((u32)clock);
+    const u32 stamp0 = LBFT_SEGV(stamp), sf0 = LBFT_SEGV(snap_free);
+    const u32 c = (h >> 6) - 1u, pos = h & 63u;
+    const u32 own_l4 = lane4;
+    lane4 = l4;
+    PL<u32> in, node, slot, ok, tnew, ign, dups, refs, sepoch;
+    LBFT_FOR_LANES(l) {
+      const u32 j = l - seg_sh;
+      in[l] = j < avail ? 1u : 0u;
+      node[l] = 0; slot[l] = 0; ok[l] = 0; tnew[l] = 0xffffffffu; ign[l] = 0; dups[l] = 0; refs[l] = 0; sepoch[l] = 0;
+      if (in[l]) {
+        const u32 meta = ld(chw(c, pos + j));
+        const u32 nd = meta & 0xffu, sender = (meta >> 8) & 0xffu, sl = meta >> 16;
+        node[l] = nd; slot[l] = sl;
+        begin_node(nd);
+        const Snap sn = load_snapshot(sl);
+        refs[l] = sn.refs; sepoch[l] = sn.w[S_EPOCH];
+        const i64 startup = (i64)(i32)nf(nd, NF_STARTUP);
+        i64 next;
+        const bool quiet = update_is_noop(nd, (i64)clk - startup, next);
+        i64 t_new = (i64)((u64)next + (u64)startup);  // process_node_actions (simulator.rs:296-325)
+        if (t_new < (i64)clk + 1) t_new = (i64)clk + 1;
+        i64 ig = t_new - 1;
+        if (ig > (i64)P.max_clock) ig = P.max_clock;
+        ign[l] = (u32)(i32)ig;
+        tnew[l] = t_new <= (i64)P.max_clock ? (u32)t_new : 0xffffffffu;
+        dups[l] = nf(nd, NF_TIMER_DUPS);
+        const bool folds = tnew[l] == 0xffffffffu || tnew[l] == nf(nd, NF_LAST_TIMER_T);  // (past the horizon: nothing is queued either)
+        ok[l] = (quiet && folds && notification_is_inert(nd, sender, sn)) ? 1u : 0u;
+      }
+    }
+    PL<u32> bad;
+    LBFT_FOR_LANES(l) bad[l] = (in[l] && !ok[l]) ? 1u : 0u;
+    const u64 BAD = pl_ballot(bad);
+    const u64 segbad = (BAD >> seg_sh) & wmask;
+    const u32 cnt = segbad ? ctz64(segbad) : avail;
+    LBFT_STAT(60); LBFT_STATN(61, cnt); if (!cnt) LBFT_STAT(62);
+    const u64 RUN = cnt ? (((cnt >= 64u ? ~0ULL : (1ULL << cnt) - 1ULL)) << seg_sh) : 0ULL;  // the lanes of this segment's run
+    PL<u64> MS, SS;  // lanes of the run whose events are for this lane's node / hold a reference to this lane's snapshot slot
+    LBFT_FOR_LANES(l) { MS[l] = ((RUN >> l) & 1ULL) ? RUN : 0; SS[l] = MS[l]; }
+    for (u32 b = 0; (1u << b) < NN(); b++) {
+      PL<u32> bit;
+      LBFT_FOR_LANES(l) bit[l] = (MS[l] != 0 && ((node[l] >> b) & 1u)) ? 1u : 0u;
+      const u64 B = pl_ballot(bit);
+      LBFT_FOR_LANES(l) MS[l] &= bit[l] ? B : ~B;
+    }
+    for (u32 b = 0; (1u << b) < P.scap; b++) {
+      PL<u32> bit;
+      LBFT_FOR_LANES(l) bit[l] = (SS[l] != 0 && ((slot[l] >> b) & 1u)) ? 1u : 0u;
+      const u64 B = pl_ballot(bit);
+      LBFT_FOR_LANES(l) SS[l] &= bit[l] ? B : ~B;
+    }
+    // the snapshots' references: the LAST event of a slot's group leaves the count behind (and frees the slot at zero -- in event order)
+    PL<u32> freed, fold;
+    LBFT_FOR_LANES(l) {
+      freed[l] = 0; fold[l] = 0;
+      if (MS[l] != 0) {
+        if ((SS[l] >> l) == 1ULL) {  // no later lane of the run holds this slot
+          const u32 left = refs[l] - popc64(SS[l]);
+          st(sfw(slot[l], S_EPOCH), sepoch[l] | (left << 16));
+          freed[l] = left == 0 ? 1u : 0u;
+        }
+        fold[l] = tnew[l] != 0xffffffffu ? 1u : 0u;
+        if ((MS[l] & ((1ULL << l) - 1ULL)) == 0) {  // first event of its node in the run: the node's timer words, once
+          st(nfw(node[l], NF_IGNORE_UNTIL), ign[l]);
+          if (fold[l]) {
+            const u32 last_l = 63u - (u32)clz64(MS[l]);
+            st(nfw(node[l], NF_TIMER_DUPS), dups[l] + popc64(MS[l]));
+            st(nfw(node[l], NF_DUP_STAMP), stamp0 + (last_l - seg_sh));
+          }
+        }
+      }
+    }
+    const u64 FR = pl_ballot(freed), F = pl_ballot(fold);
+    LBFT_FOR_LANES(l) if (freed[l]) st(OFFSFREE() + sf0 + popc64(FR & (wmask << seg_sh) & ((1ULL << l) - 1ULL)), slot[l]);
+    lane4 = own_l4;
+    // leader side: book the segment's result
+    if (leader && want) {
+      const u64 mybad = (BAD >> lead_sh) & wmask;
+      const u32 mycnt = mybad ? ctz64(mybad) : own_avail;
+      ntf_skip = mybad ? ctz64(~(mybad >> mycnt)) : 0u;  // (consecutive events from the cut on that were seen to need an ordinary step)
+      ntf_done = mycnt;
+      if (mycnt) {
+        snap_free += popc64((FR >> lead_sh) & wmask);
+        qlen -= mycnt;
+        ev0 += mycnt;
+#if !defined(LBFT_NO_EXEC_COUNTERS)
+        n_upd += mycnt;
+        n_fold += popc64((F >> lead_sh) & wmask);
+#endif
+        stamp += mycnt;
+        if (stamp >= (1u << 30)) fault |= F_STAMP_OVERFLOW;
+        cal_advance(mycnt);
+      }
+    }
+    LBFT_FOR_LANES(l) if (MS[l] != 0) LBFT_HOOK_POP(clk, 0u, node[l], 0u);
+#undef LBFT_SEGV
+    LBFT_MARK(3);  // (diagnostic builds: a notification run is charged to the notifications' first phase)
+  }
   u32 bulk;       // leader lane: bit 0 = a broadcast is pending, bit 1 = a query-all is pending (set by send_loop)
   u32 bulk_copy;  // leader lane: bit 0 = the hcbr words of a response snapshot are to be copied (a request under quirks bit 0), slot << 8
   u32 bulk_node;  // leader lane: the node whose actions are being processed
@@ -3739,6 +3930,17 @@ LBFT_UNROLL
           sp.have_actions = 1;
         }
       }
+#if defined(LBFT_HOST_STATS) && !defined(__HIPCC__)
+      // (tests/tools/run_stats.cpp, analysis only: how many notifications leave their node as it was -- nothing inserted, no request back, a no-op update?)
+      if (kind == 0) {
+        static thread_local unsigned streak_ = 0, streak_t_ = ~0u;
+        const bool inert_ = !sync && do_update && (cdirty & ~1u) == 0 && axdirty == 0 && a.send_to < 0 && !a.broadcast && !a.query_all;
+        LBFT_STAT(43);
+        if (streak_t_ != (unsigned)t_event || !inert_) { if (streak_ >= 4) LBFT_STATN(58, streak_); if (streak_ >= 8) LBFT_STATN(59, streak_); streak_ = 0; }
+        streak_t_ = (unsigned)t_event;
+        if (inert_) { LBFT_STAT(47); streak_++; }
+      }
+#endif
       send_loop(node, sender, sp, a);
       c.node = node; c.sender = sender; c.kind = kind; c.t_event = t_event; c.do_update = do_update;
     }
@@ -3814,7 +4016,7 @@ LBFT_UNROLL
     u32 steps = 0;
     u32 max_steps = P.max_steps ? P.max_steps : 0xffffffffu;
     bool go = leader, drained = true;
-    bulk = 0; bulk_node = 0; bulk_copy = 0;
+    bulk = 0; bulk_node = 0; bulk_copy = 0; ntf_skip = 0; ntf_done = 0;
     coop_on = true;
     for (;;) {
       if (go && steps >= max_steps) { go = false; drained = false; }
@@ -3832,12 +4034,13 @@ LBFT_UNROLL
         rng.ring_fill(room < P.ring_topup ? room : P.ring_topup);
       }
       if (REQRUN && coop()) {  // a run of >= 2 requests at the head of a network's open bucket: the whole wavefront takes it (coop_requests)
-        bool is_req = false, is_rsp = false;
+        bool is_req = false, is_rsp = false, is_ntf = false;
         if (act && qlen != 0 && !(q1() && cont != 0)) {  // (a response still going through its epochs comes first: step_begin resumes it)
           cal_open();
           const u32 in_chunk = ((sp_nx >> 6) == (cur_h >> 6) ? (sp_nx & 63u) : LBFT_CAL_CE) - (cur_h & 63u) + 1u;
           is_req = (sp_idx & 3u) == 2u && in_chunk >= LBFT_RUN_MIN && max_steps - steps >= LBFT_RUN_MIN;
           is_rsp = RSPRUN && !q1() && (sp_idx & 3u) == 1u && in_chunk >= LBFT_RUN_MIN && max_steps - steps >= LBFT_RUN_MIN;
+          is_ntf = NTFRUN && P.lpw <= 32u && (sp_idx & 3u) == 3u && in_chunk >= LBFT_NTF_MIN && max_steps - steps >= LBFT_NTF_MIN && ntf_skip == 0;
         }
 #if defined(__HIP_DEVICE_COMPILE__)
         unsigned long long rq = __ballot(is_req);
@@ -3862,6 +4065,16 @@ LBFT_UNROLL
             coop_responses(k, LBFT_UNI(max_steps - steps, k));
           }
           if (is_rsp && rsp_done) { steps += rsp_done; act = false; }  // (0: the head event's update does something -- the ordinary step takes it)
+        }
+        if (NTFRUN) {  // ... and the runs of notifications that leave their nodes as they were, of all networks at once (coop_notifications)
+#if defined(__HIP_DEVICE_COMPILE__)
+          const bool any_ntf = __ballot(is_ntf) != 0;
+#else
+          const bool any_ntf = is_ntf;
+#endif
+          if (any_ntf) coop_notifications(is_ntf, max_steps - steps);
+          if (is_ntf && ntf_done) { steps += ntf_done; act = false; }
+          else if (act && ntf_skip) ntf_skip--;  // (an event seen not to be inert takes its ordinary step)
         }
       }
       if (act) {
