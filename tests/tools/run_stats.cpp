@@ -41,13 +41,13 @@ int main(int argc, char** argv) {
          " \"request_runs\": {\"runs\": %llu, \"events\": %llu, \"share_of_requests\": %.4f, \"events_per_run\": %.2f},\n"
          " \"response_runs\": {\"runs\": %llu, \"events\": %llu, \"share_of_responses\": %.4f, \"events_per_run\": %.2f, \"ended_by_an_update_that_does_something\": %llu, \"consumed_nothing\": %llu},\n"
          " \"notification_runs\": {\"runs\": %llu, \"events\": %llu, \"share_of_notifications\": %.4f, \"events_per_run\": %.2f, \"consumed_nothing\": %llu},\n"
-         " \"responses_under_quirks_bit_0\": {\"nothing_to_insert\": %llu, \"and_update_is_a_no_op\": %llu, \"other\": %llu},\n"
+         " \"responses_under_quirks_bit_0\": {\"nothing_to_insert\": %llu, \"and_update_is_a_no_op\": %llu, \"other\": %llu, \"no_op_and_timer_folded_in_streaks_of_2_or_more\": %llu, \"such_streaks\": %llu, \"in_streaks_of_4_or_more\": %llu},\n"
          " \"notifications\": {\"ordinary_steps\": %llu, \"leaving_the_node_as_it_was\": %llu, \"of_them_in_streaks_of_4_or_more\": %llu, \"of_8_or_more\": %llu},\n"
          " \"share_of_all_events_in_runs\": %.4f, \"ordinary_steps\": {\"notify\": %llu, \"request\": %llu, \"response\": %llu, \"timer_pops\": %llu}}\n",
          rc, cfg.num_nodes, n, (long long)max_clock, cfg.quirks, (unsigned long long)c.events[0], (unsigned long long)c.events[1], (unsigned long long)c.events[2],
          (unsigned long long)c.events[3], s[30], s[31], c.events[1] ? (double)s[31] / c.events[1] : 0.0, s[30] ? (double)s[31] / s[30] : 0.0,
          s[13], s[14], c.events[2] ? (double)s[14] / c.events[2] : 0.0, s[13] ? (double)s[14] / s[13] : 0.0, s[15], s[29],
          s[60], s[61], c.events[0] ? (double)s[61] / c.events[0] : 0.0, s[60] ? (double)s[61] / s[60] : 0.0, s[62],
-         s[33], s[38], s[39], s[43], s[47], s[58], s[59], ev ? (double)(s[31] + s[14] + s[61]) / ev : 0.0, s[2], s[3], s[4], s[0]);
+         s[33], s[38], s[39], s[56], s[57], s[63], s[43], s[47], s[58], s[59], ev ? (double)(s[31] + s[14] + s[61]) / ev : 0.0, s[2], s[3], s[4], s[0]);
   return rc;
 }
