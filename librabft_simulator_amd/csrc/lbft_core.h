@@ -781,6 +781,10 @@ struct SimT {
 #define LBFT_NTFRUN 1  // (round 6) lbft_k_run2l / lbft_k_run2q: runs of notifications that provably leave their node as it was (coop_notifications)
 #endif
   static constexpr bool NTFRUN = REQRUN && LBFT_NTFRUN != 0;
+#ifndef LBFT_NTFACT
+#define LBFT_NTFACT 1  // (round 6) ... including the notifications that only add to their node's current timeouts / ballot (notification_effects)
+#endif
+  static constexpr bool NTFACT = NTFRUN && F_AX && LBFT_NTFACT != 0;
   static constexpr bool RING = BIG || CLS == 3;
   bool coop_on;  // set by run_coop: the event loop is being run by a whole wavefront
   static constexpr u32 PB = CLS == 9 ? LBFT_POP_BATCH_QUAD : LBFT_POP_BATCH;  // slots per batch of the packed queue's scan
@@ -3463,6 +3467,116 @@ LBFT_UNROLL
     }
     return true;
   }
+  // ---- notifications that change their node's current timeouts and / or ballot and nothing else (round 6, second form of the notification runs).  After the
+  // runs above, nine in ten of the notifications that still took an ordinary step did exactly this (tests/tools/run_stats.cpp): the sender's own timeout and
+  // its vote reach a receiver that holds everything else the notification carries -- insert_timeout (record_store.rs:390-415) adds an author to the current
+  // timeouts without completing a certificate, insert_vote (:292-329) adds one to a ballot without winning the election, the update that follows is a no-op.
+  // Such an event writes words of ITS node only (no block record, no message), so it can be a lane of a run like an inert one -- as long as it is the only
+  // event of its node in the run (coop_notifications cuts the run in front of a second one).  notification_effects replays the tail of handle_notification
+  // (data_sync.rs:149-169) on the node's STAGED words, in the reference's order (timeout-certificate set, current timeouts, vote; authors ascending), so that
+  // update_is_noop then sees the node as the event leaves it; nothing reaches memory here.  What the lane has to write if it stays in the run is handed back
+  // as a delta.  0 = the ordinary step must take the event (it does more, or more new timeouts than a delta carries), 1 = nothing changes, 2 = see `d`.
+  struct NtfDelta {
+    u32 acc[4];  // accepted timeouts: author | highest_certified_block_round << 8
+    u32 flags;   // bits 0-2: accepted timeouts, bit 3: the node's NF_TC_SEL, bits 4-5: 1 + ballot entry the vote went to (0: no vote), bit 6: the election is ongoing (weights count)
+    u32 to_w, bal_w;  // the new NF_TO_WEIGHT / NF_BALx_WEIGHT
+  };
+  LBFT_HD bool stage_timeouts(u32 node, u32 slot, u32 which, u32 w0, bool xf, NtfDelta& d) const {  // false: the ordinary step
+    const u32 word0 = sfw(slot, S_FIXED_WORDS + which * NN());
+    for (u32 k = 0; k < (xf ? MW() : 1u); k++) {
+      u32 m = (k == 0 ? w0 : ld(sxw(slot, which, k))) & ~am_word(node, NF_TO_MASK, k);
+      while (m) {
+        const u32 a = 32u * k + ctz32(m);
+        m &= m - 1;
+        const u32 h = ld(word0 + a);
+        if (h > nf(node, NF_HQC_ROUND)) continue;  // (insert_timeout's first test; the round is the current round, the author is new)
+        const u32 n = d.flags & 7u;
+        if (n >= 4u || h >= (1u << 24)) return false;
+        const u32 v = a | (h << 8);
+        d.acc[0] = n == 0 ? v : d.acc[0]; d.acc[1] = n == 1 ? v : d.acc[1]; d.acc[2] = n == 2 ? v : d.acc[2]; d.acc[3] = n == 3 ? v : d.acc[3];
+        d.flags++;
+        am_set(node, NF_TO_MASK, a);
+        const u32 w = nf(node, NF_TO_WEIGHT) + weight(node, a);
+        nfs(node, NF_TO_WEIGHT, w);
+        if (w >= QUORUM()) return false;  // a timeout certificate forms: the round moves
+      }
+    }
+    return true;
+  }
+  LBFT_HD u32 notification_effects(u32 node, u32 sender, u32 slot, const Snap& sn, NtfDelta& d) const {
+    d.acc[0] = d.acc[1] = d.acc[2] = d.acc[3] = 0; d.flags = 0; d.to_w = 0; d.bal_w = 0;
+    const u32 epoch = nf(node, NF_EPOCH), n_epoch = sn.w[S_EPOCH];
+    if (n_epoch > epoch) return 0;         // should_sync
+    const u32 certs = sn.w[S_CERTS], hcc = certs & 0xffffu, hqc = certs >> 16;
+    const bool c_hcc = hcc != 0 && hcc != nf(node, NF_HCC_BLK), c_hqc = hqc != 0 && hqc != nf(node, NF_HQC_BLK);
+    bool ok = true;
+    if (c_hcc) ok = cert_is_inert(node, hcc, true, c_hqc && hqc == hcc, epoch);
+    if (ok && c_hqc && !(c_hcc && hqc == hcc)) ok = cert_is_inert(node, hqc, false, true, epoch);
+    if (!ok) return 0;
+    if (n_epoch != epoch) return 1;        // the rest of a notification is only looked at within one epoch (data_sync.rs:149)
+    const u32 pv = sn.w[S_PROP_VOTE], pb = pv & 0xffffu, vote = pv >> 16;
+    const u32 xk = node >> 5;
+    if (pb) {  // insert_block returns at once for a block the node holds
+      const u32 kw = (!wide() || node < 32) ? ld(bfw(pb, B_KNOWN)) : ld(bxw(pb, B_KNOWN, xk));
+      if (!((kw >> (node & 31u)) & 1u)) return 0;
+    }
+    const u32 cur = nf(node, NF_CUR_ROUND);
+    const u32 tc_raw = sn.w[S_TC_ROUND], to_raw = sn.w[S_TO_ROUND];
+    const u32 tc_round = wide() ? tc_raw & ~LBFT_S_XFLAG : tc_raw, to_round = wide() ? to_raw & ~LBFT_S_XFLAG : to_raw;
+    if (tc_round == cur && !stage_timeouts(node, slot, 0, sn.w[S_TC_MASK], wide() && (tc_raw & LBFT_S_XFLAG) != 0, d)) return 0;
+    if (to_round == cur && !stage_timeouts(node, slot, 1, sn.w[S_TO_MASK], wide() && (to_raw & LBFT_S_XFLAG) != 0, d)) return 0;
+    if (vote) {  // insert_vote: unknown block, another round, or an author already counted -> untouched
+      const u32 vb = boff(bfw(vote, 0));
+      const u32 vr = ldf(vb, B_ROUND);
+      const u32 kw = (!wide() || node < 32) ? ldf(vb, B_KNOWN) : ld(bxw(vote, B_KNOWN, xk));
+      const bool known = ((kw >> (node & 31u)) & 1u) != 0;
+      if (known && vr == cur && !am_test(node, NF_BAL0_AUTHORS, sender) && !am_test(node, NF_BAL1_AUTHORS, sender)) {
+        const u32 b0 = nf(node, NF_BAL0_BLK), b1 = nf(node, NF_BAL1_BLK);
+        const bool ongoing = (nf(node, NF_ELECTION) & 0xffu) == 0;
+        u32 w = 0;
+        if (b0 == vote || b0 == 0) {
+          nfs(node, NF_BAL0_BLK, vote); am_set(node, NF_BAL0_AUTHORS, sender);
+          if (ongoing) { w = nf(node, NF_BAL0_WEIGHT) + weight(node, sender); nfs(node, NF_BAL0_WEIGHT, w); }
+          d.flags |= 1u << 4;
+        } else if (b1 == vote || b1 == 0) {
+          nfs(node, NF_BAL1_BLK, vote); am_set(node, NF_BAL1_AUTHORS, sender);
+          if (ongoing) { w = nf(node, NF_BAL1_WEIGHT) + weight(node, sender); nfs(node, NF_BAL1_WEIGHT, w); }
+          d.flags |= 2u << 4;
+        } else return 0;                   // (a third ballot entry: the ordinary step reports the overflow)
+        if (ongoing && w >= QUORUM()) return 0;  // the election is won: check_for_new_qc has work
+        d.flags |= ongoing ? 1u << 6 : 0u;
+        d.bal_w = w;
+      }
+    }
+    if (!(d.flags & 0x37u)) return 1;
+    d.flags |= (nf(node, NF_TC_SEL) & 1u) << 3;
+    d.to_w = nf(node, NF_TO_WEIGHT);
+    return 2;
+  }
+  // ... and the delta written to the node's rows (what end_node would write of the staged words: the set words by read-modify-write)
+  LBFT_HD void commit_notification_delta(u32 node, u32 sender, u32 vote, u32 a0, u32 a1, u32 a2, u32 a3, u32 flags, u32 to_w, u32 bal_w) const {
+    const u32 n = flags & 7u, buf = 1u - ((flags >> 3) & 1u);
+    LBFT_UNROLL
+    for (u32 j = 0; j < 4; j++) {
+      if (j < n) {
+        const u32 v = j == 0 ? a0 : j == 1 ? a1 : j == 2 ? a2 : a3;
+        const u32 a = v & 0xffu, h = v >> 8;
+        const u32 addr = (!wide() || a < 32) ? nfw(node, NF_TO_MASK) : amxw(node, NF_TO_MASK, a >> 5);
+        st(addr, ld(addr) | (1u << (a & 31u)));
+        hc_set(node, buf, a, h);
+      }
+    }
+    if (n) st(nfw(node, NF_TO_WEIGHT), to_w);
+    const u32 e = (flags >> 4) & 3u;
+    if (e) {
+      const bool e0 = e == 1u;
+      st(nfw(node, e0 ? NF_BAL0_BLK : NF_BAL1_BLK), vote);
+      const u32 f = e0 ? NF_BAL0_AUTHORS : NF_BAL1_AUTHORS;
+      const u32 addr = (!wide() || sender < 32) ? nfw(node, f) : (e0 ? amxw(node, NF_BAL0_AUTHORS, sender >> 5) : amxw(node, NF_BAL1_AUTHORS, sender >> 5));
+      st(addr, ld(addr) | (1u << (sender & 31u)));
+      if (flags & (1u << 6)) st(nfw(node, e0 ? NF_BAL0_WEIGHT : NF_BAL1_WEIGHT), bal_w);
+    }
+  }
   u32 ntf_done;  // leader lane: notifications the last coop_notifications consumed
   u32 ntf_skip;  // leader lane: notifications behind it that were seen NOT to be inert -- they take ordinary steps without another attempt
   // ALL networks of the wavefront at once: the wavefront's 64 lanes are split into one SEGMENT of W = 64 / lpw lanes per network (network s = lane s, its
@@ -3502,10 +3616,12 @@ LBFT_UNROLL
     const u32 own_l4 = lane4;
     lane4 = l4;
     PL<u32> in, node, slot, ok, tnew, ign, dups, refs, sepoch;
+    PL<u32> act, da0, da1, da2, da3, dfl, dtw, dbw;  // (NTFACT) the lane's event changes its node's timeouts / ballot: the delta it writes if it stays in the run
     LBFT_FOR_LANES(l) {
       const u32 j = l - seg_sh;
       in[l] = j < avail ? 1u : 0u;
       node[l] = 0; slot[l] = 0; ok[l] = 0; tnew[l] = 0xffffffffu; ign[l] = 0; dups[l] = 0; refs[l] = 0; sepoch[l] = 0;
+      act[l] = 0; da0[l] = 0; da1[l] = 0; da2[l] = 0; da3[l] = 0; dfl[l] = 0; dtw[l] = 0; dbw[l] = 0;
       if (in[l]) {
         const u32 meta = ld(chw(c, pos + j));
         const u32 nd = meta & 0xffu, sender = (meta >> 8) & 0xffu, sl = meta >> 16;
@@ -3513,6 +3629,12 @@ LBFT_UNROLL
         begin_node(nd);
         const Snap sn = load_snapshot(sl);
         refs[l] = sn.refs; sepoch[l] = sn.w[S_EPOCH];
+        u32 cls;  // 0: the ordinary step, 1: nothing of the node changes, 2: its timeouts / ballot do (staged: update_is_noop sees the node as the event leaves it)
+        if (NTFACT) {
+          NtfDelta d;
+          cls = notification_effects(nd, sender, sl, sn, d);
+          if (cls == 2u) { act[l] = 1u; da0[l] = d.acc[0]; da1[l] = d.acc[1]; da2[l] = d.acc[2]; da3[l] = d.acc[3]; dfl[l] = d.flags | ((sn.w[S_PROP_VOTE] >> 16) << 16) | (sender << 8); dtw[l] = d.to_w; dbw[l] = d.bal_w; }
+        } else cls = notification_is_inert(nd, sender, sn) ? 1u : 0u;
         const i64 startup = (i64)(i32)nf(nd, NF_STARTUP);
         i64 next;
         const bool quiet = update_is_noop(nd, (i64)clk - startup, next);
@@ -3524,24 +3646,44 @@ LBFT_UNROLL
         tnew[l] = t_new <= (i64)P.max_clock ? (u32)t_new : 0xffffffffu;
         dups[l] = nf(nd, NF_TIMER_DUPS);
         const bool folds = tnew[l] == 0xffffffffu || tnew[l] == nf(nd, NF_LAST_TIMER_T);  // (past the horizon: nothing is queued either)
-        ok[l] = (quiet && folds && notification_is_inert(nd, sender, sn)) ? 1u : 0u;
+        ok[l] = (quiet && folds && cls != 0u) ? 1u : 0u;
       }
     }
     PL<u32> bad;
     LBFT_FOR_LANES(l) bad[l] = (in[l] && !ok[l]) ? 1u : 0u;
     const u64 BAD = pl_ballot(bad);
     const u64 segbad = (BAD >> seg_sh) & wmask;
-    const u32 cnt = segbad ? ctz64(segbad) : avail;
-    LBFT_STAT(60); LBFT_STATN(61, cnt); if (!cnt) LBFT_STAT(62);
-    const u64 RUN = cnt ? (((cnt >= 64u ? ~0ULL : (1ULL << cnt) - 1ULL)) << seg_sh) : 0ULL;  // the lanes of this segment's run
+    u32 cnt = segbad ? ctz64(segbad) : avail;
+    u64 RUN = cnt ? (((cnt >= 64u ? ~0ULL : (1ULL << cnt) - 1ULL)) << seg_sh) : 0ULL;  // the lanes of this segment's run
     PL<u64> MS, SS;  // lanes of the run whose events are for this lane's node / hold a reference to this lane's snapshot slot
-    LBFT_FOR_LANES(l) { MS[l] = ((RUN >> l) & 1ULL) ? RUN : 0; SS[l] = MS[l]; }
+    LBFT_FOR_LANES(l) MS[l] = ((RUN >> l) & 1ULL) ? RUN : 0;
     for (u32 b = 0; (1u << b) < NN(); b++) {
       PL<u32> bit;
       LBFT_FOR_LANES(l) bit[l] = (MS[l] != 0 && ((node[l] >> b) & 1u)) ? 1u : 0u;
       const u64 B = pl_ballot(bit);
       LBFT_FOR_LANES(l) MS[l] &= bit[l] ? B : ~B;
     }
+    u64 CONF = 0;
+    if (NTFACT) {
+      // an event that changes its node must be the only event of that node in the run (the others' predicates and timers were evaluated on the node
+      // as it was): the run ends in front of a later event of a node that an event of the run changes, and in front of a changing event that is not
+      // its node's first -- that one heads the next run
+      const u64 ACT = pl_ballot(act);
+      PL<u32> conf;
+      LBFT_FOR_LANES(l) {
+        const u64 earlier = MS[l] & ((1ULL << l) - 1ULL);
+        conf[l] = (earlier != 0 && (act[l] || (earlier & ACT) != 0)) ? 1u : 0u;
+      }
+      CONF = pl_ballot(conf);
+      const u64 segconf = (CONF >> seg_sh) & wmask;
+      if (segconf) {
+        cnt = ctz64(segconf);  // (>= 1: an event has no earlier one to collide with unless the run has two)
+        RUN = ((1ULL << cnt) - 1ULL) << seg_sh;
+        LBFT_FOR_LANES(l) MS[l] = ((RUN >> l) & 1ULL) ? (MS[l] & RUN) : 0;
+      }
+    }
+    LBFT_STAT(60); LBFT_STATN(61, cnt); if (!cnt) LBFT_STAT(62);
+    LBFT_FOR_LANES(l) SS[l] = ((RUN >> l) & 1ULL) ? RUN : 0;
     for (u32 b = 0; (1u << b) < P.scap; b++) {
       PL<u32> bit;
       LBFT_FOR_LANES(l) bit[l] = (SS[l] != 0 && ((slot[l] >> b) & 1u)) ? 1u : 0u;
@@ -3559,6 +3701,7 @@ LBFT_UNROLL
           freed[l] = left == 0 ? 1u : 0u;
         }
         fold[l] = tnew[l] != 0xffffffffu ? 1u : 0u;
+        if (NTFACT && act[l]) commit_notification_delta(node[l], (dfl[l] >> 8) & 0xffu, dfl[l] >> 16, da0[l], da1[l], da2[l], da3[l], dfl[l] & 0xffu, dtw[l], dbw[l]);
         if ((MS[l] & ((1ULL << l) - 1ULL)) == 0) {  // first event of its node in the run: the node's timer words, once
           st(nfw(node[l], NF_IGNORE_UNTIL), ign[l]);
           if (fold[l]) {
@@ -3575,8 +3718,12 @@ LBFT_UNROLL
     // leader side: book the segment's result
     if (leader && want) {
       const u64 mybad = (BAD >> lead_sh) & wmask;
-      const u32 mycnt = mybad ? ctz64(mybad) : own_avail;
+      u32 mycnt = mybad ? ctz64(mybad) : own_avail;
       ntf_skip = mybad ? ctz64(~(mybad >> mycnt)) : 0u;  // (consecutive events from the cut on that were seen to need an ordinary step)
+      if (NTFACT) {
+        const u64 myconf = (CONF >> lead_sh) & wmask;
+        if (myconf) { mycnt = ctz64(myconf); ntf_skip = 0; }  // (cut in front of a collision: that event heads the next run)
+      }
       ntf_done = mycnt;
       if (mycnt) {
         snap_free += popc64((FR >> lead_sh) & wmask);
