@@ -758,6 +758,9 @@ struct SimT {
   static constexpr bool F_BX = LEAN2 ? (LBFT_LEAN_BX != 0) : (LBFT_BX != 0);
   static constexpr bool F_SPEC = LEAN2 ? (LBFT_LEAN_SPEC != 0) : (LBFT_SPEC != 0);
   static constexpr bool COOP = BIG;
+#ifndef LBFT_HCBR_BATCH
+#define LBFT_HCBR_BATCH 8  // hcbr words a lane of a large-network kernel has in flight per round trip when it copies a timeout set (copy_hcbr_to)
+#endif
 #ifndef LBFT_REQRUN
 #define LBFT_REQRUN 1  // (round 6) lbft_k_run2l / lbft_k_run2q: the requests at the head of a bucket are taken by the whole wavefront, a chunk at a time (coop_requests)
 #endif
@@ -2354,7 +2357,7 @@ LBFT_UNROLL
   // time (a load-store-load-store chain would be one memory round trip per author)
   LBFT_HD void copy_hcbr(u32 node, u32 slot, u32 mask, u32 author0, u32 buf, u32 snap_word0) const { copy_hcbr_to(node, sfw(slot, snap_word0), mask, author0, buf); }
   LBFT_HD void copy_hcbr_to(u32 node, u32 dst_word0, u32 mask, u32 author0, u32 buf) const {
-    constexpr u32 B = BIG ? 8 : 4;  // loads in flight per round trip (large networks copy dozens of words per notification)
+    constexpr u32 B = BIG ? LBFT_HCBR_BATCH : 4;  // loads in flight per round trip (large networks copy dozens of words per notification)
     while (mask) {
       u32 a[B], h[B], k = 0;
       LBFT_UNROLL
