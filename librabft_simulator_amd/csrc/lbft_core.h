@@ -3768,6 +3768,139 @@ LBFT_UNROLL
     i64 t = d > INT64_MAX - (i64)clk ? INT64_MAX : (i64)clk + d;
     return t <= (i64)P.max_clock ? (u32)t : 0xffffffffu;
   }
+  // ---- the receivers' shuffle of a bulk send, lanes = STEPS (round 6, third session).  SliceRandom::shuffle is `for i = cnt - 1 .. 1: swap(i, j_i)` with
+  // j_i = gen_range(0, i + 1) off the RNG (simulator.rs:343,370): a chain of ~1.2 cnt dependent draws and cnt dependent swaps -- on the scalar unit 50
+  // instructions per draw, a quarter of a 100-node network's time after the runs.  Both halves have a lane-parallel form that yields the SAME list:
+  //   (1) which draw serves which step.  Draw d is accepted for step x iff low32(v_d (x + 1)) <= zone(x + 1), and the step a draw is tried for is
+  //       i0 - (accepted draws before it): a fixed point over the ballot of accepted lanes, exact because lane l's step depends on lanes < l only (one more
+  //       lane of the prefix is right after every iteration; it stops at once when nothing was rejected).  The accepted draws are then moved from draw order
+  //       to step order (step s takes the (i0 - s)-th accepted draw: a select on the ballot by binary search).
+  //   (2) the list from the j_i.  Position i is final after step i and holds what position j_i held just before: follow that content back -- position p at
+  //       time t was last written by the nearest later-executed... EARLIER-executed step s > t with j_s == p, which put there what position s held before step s, and so on:
+  //       final[i] = init[e_i], e_i = the end of the chain  s1 = min{s > i : j_s == j_i},  s_{k+1} = up(s_k) = min{s > s_k : j_s == s_k}  (e_i = j_i without an s1).
+  //       Both relations are equality matches between lanes: bit-sliced ballots over the 7 bits of j; the chains are closed by pointer jumping.
+  // Steps live in two registers (step l in the first, step 64 + l in the second); position 0 counts as a step that swaps with itself.
+  LBFT_HD static u64 bits_from(u32 b) { return b >= 64u ? 0ULL : (~0ULL << b); }
+  LBFT_HD u32 step_above(u64 lo, u64 hi, u32 i) const {  // the lowest set bit above step i of the 128 steps (lo, hi); 0xff: none
+    const u64 a = i < 64u ? lo & bits_from(i + 1u) : 0ULL;
+    const u64 b = i < 64u ? hi : hi & bits_from(i - 63u);
+    return a ? ctz64(a) : b ? 64u + ctz64(b) : 0xffu;
+  }
+  LBFT_HD void coop_shuffle(u32 k, u32 l4, u32 node, u32 cnt, PL<u32>& perm0, PL<u32>& perm1) {
+    const bool is_k = LBFT_IS_LANE(k);
+    const u32 ring_row = P.off_ring, ring_mask = P.ring - 1u;
+    const bool two = cnt > 64u;
+    PL<u32> J0, J1;  // j of step l / step 64 + l
+    LBFT_FOR_LANES(l) { J0[l] = l; J1[l] = 64u + l; }
+    // (1) the draws
+    for (u32 i0 = cnt - 1u; i0 >= 1u;) {
+      u32 avail = LBFT_UNI(rng.rcnt, k);
+      if (avail == 0) {
+        if (is_k) rng.ring_fill(rng.ring_room() < 64u ? rng.ring_room() : 64u);
+        avail = LBFT_UNI(rng.rcnt, k);
+      }
+      const u32 take = avail < 64u ? avail : 64u;
+      const u32 head = LBFT_UNI(rng.rhead, k);
+      PL<u32> dhi;  // next_u32() = next_u64() >> 32 of the next `take` draws
+      LBFT_FOR_LANES(l) dhi[l] = l < take ? ldc(l4, ring_row + 2u * ((head + l) & ring_mask) + 1u) : 0u;
+      u64 AM = take >= 64u ? ~0ULL : ((1ULL << take) - 1ULL);  // first guess: every draw is accepted
+      PL<u32> jv;
+      for (;;) {
+        PL<u32> acc;
+        LBFT_FOR_LANES(l) {
+          const u32 before = popc64(AM & ((1ULL << l) - 1ULL));
+          const bool valid = l < take && before < i0;  // (the shuffle ends with step 1: later draws are not consumed)
+          const u32 range = valid ? i0 - before + 1u : 2u, zone = (range << clz32(range)) - 1u;
+          const u64 mm = (u64)dhi[l] * range;
+          acc[l] = (valid && (u32)mm <= zone) ? 1u : 0u;
+          jv[l] = (u32)(mm >> 32);
+        }
+        const u64 NM = pl_ballot(acc);
+        if (NM == AM) break;
+        AM = NM;
+      }
+      const u32 na = popc64(AM);
+      const u32 used = na == i0 ? 64u - (u32)clz64(AM) : take;  // (all steps served: the draws behind the last accepted one stay in the ring)
+      // draw order -> step order: step s = i0 - r takes the r-th accepted draw
+      for (u32 h = 0; h < (two ? 2u : 1u); h++) {
+        PL<u32> src, got;
+        LBFT_FOR_LANES(l) {
+          const u32 s = h * 64u + l;
+          u32 r = i0 - s, pos = 0;  // (wraps for s > i0: not < na)
+          if (s <= i0 && r < na) {
+            LBFT_UNROLL
+            for (u32 b = 32u; b >= 1u; b >>= 1) {
+              const u32 c = popc64(AM & (((1ULL << b) - 1ULL) << pos));
+              if (r >= c) { r -= c; pos += b; }
+            }
+          }
+          src[l] = pos;
+        }
+        pl_shfl(got, jv, src);
+        LBFT_FOR_LANES(l) {
+          const u32 s = h * 64u + l, r = i0 - s;
+          if (s <= i0 && r < na) { if (h == 0) J0[l] = got[l]; else J1[l] = got[l]; }
+        }
+      }
+      if (is_k) { rng.rhead += used; rng.rcnt -= used; rng.draws += used; }
+      i0 -= na;
+    }
+    // (2) the list
+    const u64 V0 = cnt >= 64u ? ~0ULL : ((1ULL << cnt) - 1ULL), V1 = two ? ((1ULL << (cnt - 64u)) - 1ULL) : 0ULL;  // the steps 0 .. cnt - 1
+    // (all eight masks at once: taken one relation and one register of steps at a time -- two masks live -- the kernels came out with MORE spilled registers
+    // and 1-2 % slower: profiles/r06/parallel_shuffle_ab.txt)
+    PL<u64> S0l, S0h, U0l, U0h, S1l, S1h, U1l, U1h;  // register 0 / 1 lanes: steps with the same j (S) / with j == this step (U), low and high 64 steps
+    LBFT_FOR_LANES(l) { S0l[l] = V0; S0h[l] = V1; U0l[l] = V0; U0h[l] = V1; S1l[l] = V0; S1h[l] = V1; U1l[l] = V0; U1h[l] = V1; }
+    for (u32 b = 0; b < 7u; b++) {
+      PL<u32> b0, b1;
+      LBFT_FOR_LANES(l) { b0[l] = (J0[l] >> b) & 1u; b1[l] = two ? (J1[l] >> b) & 1u : 0u; }
+      const u64 B0 = pl_ballot(b0), B1 = two ? pl_ballot(b1) : 0ULL;
+      LBFT_FOR_LANES(l) {
+        const bool i0b = ((l >> b) & 1u) != 0, i1b = (((64u + l) >> b) & 1u) != 0;
+        S0l[l] &= b0[l] ? B0 : ~B0; U0l[l] &= i0b ? B0 : ~B0;
+        if (two) {
+          S0h[l] &= b0[l] ? B1 : ~B1; U0h[l] &= i0b ? B1 : ~B1;
+          S1l[l] &= b1[l] ? B0 : ~B0; S1h[l] &= b1[l] ? B1 : ~B1;
+          U1l[l] &= i1b ? B0 : ~B0; U1h[l] &= i1b ? B1 : ~B1;
+        }
+      }
+    }
+    PL<u32> s1a, s1b, p0, p1;  // the first link of a step's chain (0xff: none); up(step), a step without one pointing at itself
+    LBFT_FOR_LANES(l) {
+      s1a[l] = step_above(S0l[l], S0h[l], l);
+      const u32 u = step_above(U0l[l], U0h[l], l);
+      p0[l] = u == 0xffu ? l : u;
+      s1b[l] = 0xffu; p1[l] = 64u + l;
+      if (two) {
+        s1b[l] = step_above(S1l[l], S1h[l], 64u + l);
+        const u32 u1 = step_above(U1l[l], U1h[l], 64u + l);
+        p1[l] = u1 == 0xffu ? 64u + l : u1;
+      }
+    }
+    for (u32 rounds = 0; (1u << rounds) < cnt; rounds++) {  // pointer jumping: p = the end of the step's up-chain
+      PL<u32> g00, g01, g10, g11;
+      pl_shfl(g00, p0, p0);
+      if (two) { pl_shfl(g01, p1, p0); pl_shfl(g10, p0, p1); pl_shfl(g11, p1, p1); }
+      LBFT_FOR_LANES(l) {
+        const u32 a = p0[l], b = p1[l];
+        p0[l] = (two && a >= 64u) ? g01[l] : g00[l];
+        if (two) p1[l] = b >= 64u ? g11[l] : g10[l];
+      }
+    }
+    {
+      PL<u32> ia, ib, e00, e01, e10, e11;
+      LBFT_FOR_LANES(l) { ia[l] = s1a[l] == 0xffu ? 0u : s1a[l]; ib[l] = s1b[l] == 0xffu ? 0u : s1b[l]; }
+      pl_shfl(e00, p0, ia);
+      if (two) { pl_shfl(e01, p1, ia); pl_shfl(e10, p0, ib); pl_shfl(e11, p1, ib); }
+      LBFT_FOR_LANES(l) {
+        const u32 ea = s1a[l] == 0xffu ? J0[l] : ((two && s1a[l] >= 64u) ? e01[l] : e00[l]);
+        perm0[l] = ea < node ? ea : ea + 1u;  // init[e]: the receivers in index order skip the sender
+        u32 eb = 64u + l;
+        if (two) eb = s1b[l] == 0xffu ? J1[l] : (s1b[l] >= 64u ? e11[l] : e10[l]);
+        perm1[l] = eb < node ? eb : eb + 1u;
+      }
+    }
+  }
   LBFT_HD void coop_bulk(u32 k, u32 which) {
     const bool is_k = LBFT_IS_LANE(k);
     const u32 l4 = LBFT_UNI(lane4, k);
@@ -3775,7 +3908,6 @@ LBFT_UNROLL
     const i32 clk = (i32)LBFT_UNI((u32)clock, k);
     const u32 cnt = NN() - 1;
     const u32 kc = which ? 2u : 3u;  // 3 - Event kind (DataSyncNotify = 0, DataSyncRequest = 1): the bucket within a time
-    const u32 ring_row = P.off_ring, ring_mask = P.ring - 1u;
     // leader: what the scalar loop decides at the start of a list
     u32 eq_k = 0, rs_k = 0;
     if (is_k) {
@@ -3792,42 +3924,8 @@ LBFT_UNROLL
     const i32 rs = (i32)LBFT_UNI(rs_k, k);
     LBFT_CMARK(6);  // leader's prework
     // ---- receivers in index order, then SliceRandom::shuffle: for i = cnt - 1 .. 1: swap(i, gen_range_u32(i + 1)) ----
-    // (the swaps run on ONE register -- entry i of the list = byte i >> 6 of lane i & 63 -- with scalar shifts and selects: entries in two registers
-    // cost the loop four uniform branches per swap, 60 instructions and 8 branches per draw; a 99-receiver shuffle was 28 % of c5's time)
-    PL<u32> permp;
-    LBFT_FOR_LANES(l) permp[l] = (l < node ? l : l + 1u) | ((64u + l < node ? 64u + l : 65u + l) << 8);
-    for (u32 i = cnt - 1; i >= 1;) {
-      u32 avail = LBFT_UNI(rng.rcnt, k);
-      if (avail == 0) {
-        if (is_k) rng.ring_fill(rng.ring_room() < 64u ? rng.ring_room() : 64u);
-        avail = LBFT_UNI(rng.rcnt, k);
-      }
-      const u32 take = avail < 64u ? avail : 64u;
-      const u32 head = LBFT_UNI(rng.rhead, k);
-      PL<u32> dhi;  // next_u32() = next_u64() >> 32 of the next `take` draws
-      LBFT_FOR_LANES(l) dhi[l] = l < take ? ldc(l4, ring_row + 2u * ((head + l) & ring_mask) + 1u) : 0u;
-      u32 used = 0;
-      while (used < take && i >= 1) {
-        u32 v = pl_read(dhi, used);
-        used++;
-        u32 range = i + 1u, zone = (range << clz32(range)) - 1u;
-        u64 mm = (u64)v * range;
-        if ((u32)mm <= zone) {
-          const u32 j = (u32)(mm >> 32);
-          const u32 li = i & 63u, si = (i >> 6) << 3, lj = j & 63u, sj = (j >> 6) << 3;
-          const u32 ra = pl_read(permp, li), rb = pl_read(permp, lj);
-          const u32 a = (ra >> si) & 0xffu, b = (rb >> sj) & 0xffu;
-          const u32 na = (ra & ~(0xffu << si)) | (b << si);
-          const u32 nb = ((lj == li ? na : rb) & ~(0xffu << sj)) | (a << sj);  // (the same lane: the second write carries the first)
-          pl_write(permp, li, na);
-          pl_write(permp, lj, nb);
-          i--;
-        }
-      }
-      if (is_k) { rng.rhead += used; rng.rcnt -= used; rng.draws += used; }
-    }
     PL<u32> perm0, perm1;  // entry i of the list: lane i of perm0 (i < 64) / lane i - 64 of perm1
-    LBFT_FOR_LANES(l) { perm0[l] = permp[l] & 0xffu; perm1[l] = (permp[l] >> 8) & 0xffu; }
+    coop_shuffle(k, l4, node, cnt, perm0, perm1);
     LBFT_MARK(16);
     // ---- one delay sample per receiver, in list order ----
     PL<u32> tm0, tm1;  // scheduled time of message j (lane j of tm0 / lane j - 64 of tm1); 0xffffffff = past the horizon

@@ -1192,7 +1192,9 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   {
     u32 ring = 0, topup = 0;
     if (n > 32 && qcal) {
-      ring = 512; topup = 4;
+      // (round 6, third session: with the runs a large network makes ~15 k loop iterations instead of 215 k, and a bulk send of a 100-node network consumes ~220 draws:
+      // a top-up of 4 per iteration left the bulk's leader lane generating them one at a time -- profiles/r06/ring_topup_after_all_runs.txt)
+      ring = 512; topup = n > 64 ? 128 : 16;
       if (const char* e = getenv("LBFT_RING")) ring = (u32)atoi(e);
       if (const char* e = getenv("LBFT_RING_TOPUP")) topup = (u32)atoi(e);
       if (ring & (ring - 1)) ring = 512;
