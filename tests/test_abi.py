@@ -137,7 +137,11 @@ def test_run_kernels_keep_their_state_in_registers(hiplib):
     # update_node's tail inside handle_response) were slower than one wavefront per SIMD
     # (round 3: 38 / 70 with SimT::retire_store compiled in -- values parked around the loop: 362 vs 365 ms and 3.03 vs 2.98 s against the
     # build without it)
-    for name, cap in (("lbft_k_run2l", 56), ("lbft_k_run2q", 96)):
+    # (round 6: 37 / 60 after the runs and the packed shuffle; 62 / 119 with the lane-parallel shuffle, whose eight 64-bit masks are live for 7 ballots --
+    # measured FASTER than the serial shuffle's 37 / 60 at the same ring top-up where the shuffle is long (c5 640 -> 613 ms, c5live 1 282 -> 1 209 ms) and
+    # within 1 % elsewhere: profiles/r06/parallel_shuffle_and_ring_topup_ab.txt.  The exact counts are pinned by tests/golden/kernel_manifest.json; these
+    # caps only catch the state itself moving to scratch: hundreds)
+    for name, cap in (("lbft_k_run2l", 72), ("lbft_k_run2q", 128)):
         lean2 = [v for k, v in kernels.items() if name in k]
         assert len(lean2) == 1 and lean2[0]["vgpr_count"] <= 256 and lean2[0]["vgpr_spill_count"] <= cap, (name, lean2)
 
