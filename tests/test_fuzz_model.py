@@ -225,8 +225,9 @@ def test_random_large_configurations_on_the_device_match_the_oracle(oracle, chun
                                      calendar_queue=bool(rng.random() < 0.8), max_steps_per_launch=int(rng.choice([0, 0, 997])),
                                      lanes_per_wavefront=int(rng.choice([0, 0, 1, 4, 32])), block_capacity=max_clock + 64,
                                      queue_capacity=max(8192, 32 * n * n),
-                                     # (a per-instance state must stay below 2^24 rows: 128 nodes x 271-word snapshots allow ~40 000 slots)
-                                     snapshot_capacity=min(36000, 6 * n * n + 16 * n) if kw.get("quirks", 0) & 1 else 128 * n)
+                                     # (a per-instance state must stay below 2^24 rows: 128 nodes x 281-word snapshots allow ~55 000 slots; a 128-node network with equal delays
+                                     # has 49 000 in flight: chunk 57 of a widened run faulted on 36 000 -- on the device and on the host build alike)
+                                     snapshot_capacity=min(52000, 6 * n * n + 16 * n) if kw.get("quirks", 0) & 1 else 128 * n)
         res = sim.loop_until(max_clock, allow_faults=True)
         assert not res.faults.any(), (kw, sorted(set(int(f) for f in res.faults)), res.counters, sim.layout())
         assert (res.commit_counts == ref["commit_counts"]).all(), kw
