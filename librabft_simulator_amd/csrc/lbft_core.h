@@ -51,7 +51,7 @@ typedef int64_t i64;
 #ifndef LBFT_SPEC
 #define LBFT_SPEC 1  // calendar queue: the entry behind the popped one is fetched ahead
 #endif
-// ... and for the two-wavefronts-per-SIMD large-network kernels (SimT<5> / SimT<7>, 256 registers), where a staged word that does not fit
+// ... and for the two-wavefronts-per-SIMD large-network kernels (SimT<K_LARGE_LEAN> / SimT<K_LARGE_EXCHANGE>, 256 registers), where a staged word that does not fit
 // is a spilled register and costs more than the round trip it saves.  What pays is decided by what else is in the register file: with
 // the trace / free-slot-mask state out of it and ONE cached block record, the staged author sets and the calendar fetch-ahead fit
 // (4 / 24 spilled registers with the response bursts of DESIGN.md section 5) -- 16 384 x 64: 386 -> 375 ms, 8 192 x 100: 2.23 -> 2.04 s, live: 3.46 -> 3.32 s, 5.80 -> 5.35 s; the
@@ -66,16 +66,16 @@ typedef int64_t i64;
 #define LBFT_LEAN_SPEC 1
 #endif
 #ifndef LBFT_LEAN_Q1
-#define LBFT_LEAN_Q1 1   // large networks with the record exchange of quirks bit 0 run on a two-wavefronts-per-SIMD kernel too (SimT<7>): possible
+#define LBFT_LEAN_Q1 1   // large networks with the record exchange of quirks bit 0 run on a two-wavefronts-per-SIMD kernel too (SimT<K_LARGE_EXCHANGE>): possible
                          // since a response's epochs are separate steps; 16 384 x 64 live: 3.46 s against 4.11 s on the full-register kernel
 #endif
 #ifndef LBFT_BLK_CACHE_LEAN2
 #define LBFT_BLK_CACHE_LEAN2 1
 #endif
 #ifndef LBFT_BLK_CACHE_LEAN5
-#define LBFT_BLK_CACHE_LEAN5 3  // lbft_k_run2l (SimT<5>): three records fit since the scalar / record accesses stopped holding a register per field
+#define LBFT_BLK_CACHE_LEAN5 3  // lbft_k_run2l (SimT<K_LARGE_LEAN>): three records fit since the scalar / record accesses stopped holding a register per field
                                 // (round 4: 22 spilled registers; c4 354.6 -> 351.6 ms, c5 1.931 -> 1.897 s; two records 386 ms / 2.12 s; the kernel with
-                                // the record exchange, SimT<7>, loses with two: 3.03 against 2.82 s)
+                                // the record exchange, SimT<K_LARGE_EXCHANGE>, loses with two: 3.03 against 2.82 s)
 #endif
 // Kernel class 0 (the headline small-network path): instance-major rows (tile width 1) instead of 64-instance word-interleaved tiles.
 // The lanes of a class-0 wavefront work on different nodes, snapshot slots and blocks of their instances, i.e. on different ROWS: in a
@@ -92,7 +92,7 @@ typedef int64_t i64;
 #define LBFT_FAST_TRUNC_EXP 1  // the delay sampler decides trunc(exp(y)) from a single-precision estimate when that is safe (SimT::trunc_exp)
 #endif
 #ifndef LBFT_C0_POPC
-#define LBFT_C0_POPC 1   // small batches of class-0 networks run lbft_k_run0s (SimT<8>): the pop's scan by all 64 lanes of the wavefront
+#define LBFT_C0_POPC 1   // small batches of class-0 networks run lbft_k_run0s (SimT<K_SMALL_WAVE_POP>): the pop's scan by all 64 lanes of the wavefront
 #endif
 #ifndef LBFT_C0_HOT_FIRST
 #define LBFT_C0_HOT_FIRST 1
@@ -101,7 +101,7 @@ typedef int64_t i64;
 #define LBFT_QUAD_PAIR 1
 #endif
 #ifndef LBFT_C0_QUAD
-#define LBFT_C0_QUAD 1   // large class-0 batches of 4-node networks with unit rights and log-normal delays run lbft_k_run0q (SimT<9>)
+#define LBFT_C0_QUAD 1   // large class-0 batches of 4-node networks with unit rights and log-normal delays run lbft_k_run0q (SimT<K_HEADLINE>)
 #endif
 // (round 4 built and measured a "light-event drain" -- requests and cancelled timers finished right after the pop, the lane popping again
 // before the heavy part of the step: -18 % wavefront-steps, +-0 time in seven variants; EXPERIMENTS.md.  The code is in the history:
@@ -242,6 +242,19 @@ struct Params {
 #define LBFT_DRAIN_VMEM() do { } while (0)
 #define LBFT_MARK(k) do { } while (0)
 #define LBFT_COUNT(k) do { } while (0)
+#endif
+// -DLBFT_RUN_COUNT (with LBFT_PHASE_TIMERS; diagnostic build liblbft_hip_runcount.so): no timers -- the accumulators [0..5] count what the cooperative
+// runs of the large-network kernels retire ON THE DEVICE (whose run segments are 64 / lpw lanes wide, not the host build's 64): events retired in
+// request / response / notification runs, and the runs of each kind (one per network and pass).  tools/configs.py prints them as `runs_device`;
+// tools/configs.py::RUN_SHARES (the roofline's "updates that write timer words only") is taken from them.
+#if defined(LBFT_RUN_COUNT) && defined(LBFT_PHASE_TIMERS) && defined(__HIPCC__)
+#undef LBFT_MARK
+#undef LBFT_DRAIN_VMEM
+#define LBFT_MARK(k) do { } while (0)
+#define LBFT_DRAIN_VMEM() do { } while (0)
+#define LBFT_RUNCNT(slot, n) do { if (n) { atomicAdd(reinterpret_cast<unsigned long long*>(&wprof[slot]), (unsigned long long)(n)); atomicAdd(reinterpret_cast<unsigned long long*>(&wprof[(slot) + 3]), 1ULL); } } while (0)
+#else
+#define LBFT_RUNCNT(slot, n) do { } while (0)
 #endif
 // -DLBFT_COOP_PROF (with LBFT_PHASE_TIMERS): phases 6-10 measure the sub-phases of coop_bulk instead of update_node's
 #if defined(LBFT_COOP_PROF)
@@ -675,6 +688,21 @@ struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at
   bool query_all;
 };
 
+// The step's specialisations by name (round-5 review: "magic class numbers"); the values are the template arguments they always were -- the kernels' names
+// (lbft_k_run0 / 0q / 0s / 0u / 1l / 2l / 2q, lbft_k_run<1>, lbft_k_run<2>) and machine code are unchanged.  sim_class() returns K_SMALL / K_MID / K_LARGE for a
+// batch; lbft_hip.hip picks the specialisation of that class (sim_quad, sim_lean, sim_lean_q1, sim_lean1, the batch's size).
+enum KernelClass : int {
+  K_SMALL = 0,           // lbft_k_run0:  n <= 16, honest nodes, lossless network, reference routing; packed queue behind the LDS front
+  K_MID = 1,             // lbft_k_run<1>: n <= 32, one mask word; every feature
+  K_LARGE = 2,           // lbft_k_run<2>: n <= 128, multi-word node / author sets; every feature
+  K_GENERIC = 3,         // everything decided at run time: init / finalize / read-back kernels, the node-level C ABI, the host model
+  K_LARGE_LEAN = 5,      // lbft_k_run2l: K_LARGE without record exchange, trace and lossy network (sim_lean) -- the cooperative runs live here ...
+  K_MID_LEAN = 6,        // lbft_k_run1l: K_MID without them (sim_lean1)
+  K_LARGE_EXCHANGE = 7,  // lbft_k_run2q: ... and here: K_LARGE_LEAN plus the record exchange of quirks bit 0 (sim_lean_q1)
+  K_SMALL_WAVE_POP = 8,  // lbft_k_run0s: K_SMALL for small batches, the pop's scan by all 64 lanes
+  K_HEADLINE = 9,        // lbft_k_run0q: K_SMALL with the headline network (4 nodes, unit rights, log-normal delays) fixed at compile time (sim_quad)
+  K_SMALL_UNIFORM = 12   // lbft_k_run0u: K_SMALL_WAVE_POP for ONE network per wavefront, wavefront-uniform code on the scalar unit
+};
 // ------------------------------------------------------------------------------------------------
 // One simulated network: `tile` is the instance's tile, `lane4` the byte offset of its column in a row.
 // ------------------------------------------------------------------------------------------------
@@ -689,10 +717,10 @@ struct Actions {  // NodeUpdateActions (interfaces.rs:12-21); should_send has at
 //      plain large-network path fits 256 registers (21 spilled) and runs two wavefronts per SIMD with half the lanes each
 template <int CLS>
 struct SimT {
-  static constexpr bool LEAN2 = CLS == 5 || CLS == 7;  // 7 = 5 plus the record exchange of quirks bit 0 (24 spilled registers; a kernel of its own: with
+  static constexpr bool LEAN2 = CLS == K_LARGE_LEAN || CLS == K_LARGE_EXCHANGE;  // 7 = 5 plus the record exchange of quirks bit 0 (24 spilled registers; a kernel of its own: with
                                                        // that code compiled in, the runs without it lose 10 %)
-  static constexpr bool BIG = CLS == 2 || LEAN2;       // multi-word node / author sets
-  static constexpr bool LEAN = LEAN2 || CLS == 6;      // 6 = class 1 without those three (22 spilled registers at 256)
+  static constexpr bool BIG = CLS == K_LARGE || LEAN2;       // multi-word node / author sets
+  static constexpr bool LEAN = LEAN2 || CLS == K_MID_LEAN;      // 6 = class 1 without those three (22 spilled registers at 256)
   // Large networks: the lanes of a wavefront cooperate on one network's broadcasts (coop_bulk); every class that may meet such a
   // batch's state (the generic class 3 reads back / steps any batch) honours its ring of pre-generated draws.
   // 64-wide tiles addressed at compile time for the small-network classes (many lanes per wavefront); the large-network
@@ -705,8 +733,8 @@ struct SimT {
   // column's slots (coop_find_cols: lane-private early stop at the queue's length kept, the scan's batches split over 64 / lpw lanes)
   // (device only: the host build of the kernel logic -- oracle/host_model.cpp, one network per object -- keeps the lane-private pop)
 #if defined(__HIP_DEVICE_COMPILE__)
-  static constexpr bool PAIR = CLS == 9 && LBFT_QUAD_PAIR != 0;
-  static constexpr bool POPC = CLS == 8 || CLS == 12 || PAIR;
+  static constexpr bool PAIR = CLS == K_HEADLINE && LBFT_QUAD_PAIR != 0;
+  static constexpr bool POPC = CLS == K_SMALL_WAVE_POP || CLS == K_SMALL_UNIFORM || PAIR;
   // 12 = class 8 for ONE network per wavefront (lbft_k_run0u), executed as WAVEFRONT-UNIFORM code: the network's index, its rows' base and
   // its LDS columns are the same in all 64 lanes (derived from the wavefront's index through readfirstlane, no lane term), every lane runs
   // the step with the same values, so the compiler's uniformity analysis places the protocol logic on the scalar unit -- SGPR state, scalar
@@ -714,7 +742,7 @@ struct SimT {
   // s_cbranch_execz + s_or per `if`; 64-bit integer work is one scalar instruction instead of two vector ones).  Loads from the (uniform)
   // row addresses stay vector loads (the rows are written in the same loop: the scalar cache is not coherent with them); stores and LDS
   // writes are issued by all lanes with the same address and value.  Only the pop's scan (coop_find) has per-lane values.
-  static constexpr bool WUNI = CLS == 12;
+  static constexpr bool WUNI = CLS == K_SMALL_UNIFORM;
 #else
   static constexpr bool PAIR = false;
   static constexpr bool POPC = false;
@@ -722,8 +750,8 @@ struct SimT {
 #endif
   // 9 = class 0 with the headline network fixed at compile time (lbft_k_run0q): 4 nodes, unit voting rights, log-normal delays, <= 64
   // snapshot slots, no layout padding -- loop bounds, the quorum, record sizes and the first row offsets become immediates (sim_quad())
-  static constexpr bool QUAD = CLS == 9;  // (the small-batch kernel gains nothing from it: 1 024 x 4 6.2 against 5.8 ms, 8 192 x 4 10.0 against 9.9 -- latency-bound)
-  static constexpr bool C0 = CLS == 0 || CLS == 8 || CLS == 9 || CLS == 12;
+  static constexpr bool QUAD = CLS == K_HEADLINE;  // (the small-batch kernel gains nothing from it: 1 024 x 4 6.2 against 5.8 ms, 8 192 x 4 10.0 against 9.9 -- latency-bound)
+  static constexpr bool C0 = CLS == K_SMALL || CLS == K_SMALL_WAVE_POP || CLS == K_HEADLINE || CLS == K_SMALL_UNIFORM;
   // (WUNI) the value an out-of-line helper returned, declared wavefront-uniform: a call's result counts as divergent, and through the
   // branches that test it so would every value of the event loop after it (all lanes passed the same arguments)
   LBFT_HD static u32 wuni(u32 v) {
@@ -738,7 +766,7 @@ struct SimT {
   LBFT_HD u32 MW() const { return QUAD ? 1u : P.mw; }
   LBFT_HD u32 NWORDS() const { return QUAD ? NF_FIXED_WORDS + 8u : P.node_words; }
   // first hcbr word of a node row (behind the set extension words of a large network; a compile-time constant in the small-network classes)
-  LBFT_HD u32 HCO() const { return BIG ? NF_FIXED_WORDS + 4u * (MW() - 1u) : CLS == 3 ? NF_FIXED_WORDS + 4u * (P.mw - 1u) : (u32)NF_FIXED_WORDS; }
+  LBFT_HD u32 HCO() const { return BIG ? NF_FIXED_WORDS + 4u * (MW() - 1u) : CLS == K_GENERIC ? NF_FIXED_WORDS + 4u * (P.mw - 1u) : (u32)NF_FIXED_WORDS; }
   LBFT_HD u32 SWORDS() const { return QUAD ? S_FIXED_WORDS + 8u : P.snap_words; }
   LBFT_HD u32 BWORDS() const { return QUAD ? (u32)B_WORDS : P.blk_words; }
   LBFT_HD u32 OFFNODE() const { return QUAD ? (u32)I_WORDS : P.off_node; }
@@ -751,8 +779,8 @@ struct SimT {
   LBFT_HD u32 QUORUM() const { return QUAD ? 3u : P.quorum; }
   LBFT_HD u32 ROT() const { return QUAD ? 0u : P.rot; }
   static constexpr bool C0I = C0 && LBFT_C0_IMAJOR != 0;
-  static constexpr bool TILE64 = (C0 && !C0I) || CLS == 1 || CLS == 6;
-  static constexpr bool HCREG = CLS == 9 && C0I && LBFT_C0_HCREG != 0;  // (lbft_k_run0q: 18.7 -> 18.1 ms; no gain in the generic class-0 kernels)
+  static constexpr bool TILE64 = (C0 && !C0I) || CLS == K_MID || CLS == K_MID_LEAN;
+  static constexpr bool HCREG = CLS == K_HEADLINE && C0I && LBFT_C0_HCREG != 0;  // (lbft_k_run0q: 18.7 -> 18.1 ms; no gain in the generic class-0 kernels)
   static constexpr bool IMAJOR = BIG || C0I;  // tile width 1 = every instance's words contiguous (P.tw == 1), addressed at compile time
   static constexpr bool F_AX = LEAN2 ? (LBFT_LEAN_AX != 0) : (LBFT_AX != 0);      // (tuning switches above)
   static constexpr bool F_BX = LEAN2 ? (LBFT_LEAN_BX != 0) : (LBFT_BX != 0);
@@ -764,18 +792,18 @@ struct SimT {
 #ifndef LBFT_REQRUN
 #define LBFT_REQRUN 1  // (round 6) lbft_k_run2l / lbft_k_run2q: the requests at the head of a bucket are taken by the whole wavefront, a chunk at a time (coop_requests)
 #endif
-  static constexpr bool REQRUN = (CLS == 5 || CLS == 7) && LBFT_REQRUN != 0;
+  static constexpr bool REQRUN = (CLS == K_LARGE_LEAN || CLS == K_LARGE_EXCHANGE) && LBFT_REQRUN != 0;
 #ifndef LBFT_RUN_MIN
 #define LBFT_RUN_MIN 2u  // events at the head of a bucket's chunk from which the whole wavefront takes them as a run
 #endif
 #ifndef LBFT_RSPRUN
 #define LBFT_RSPRUN 1  // (round 6) lbft_k_run2l: runs of responses whose update_node is a no-op are taken by the whole wavefront too (coop_responses)
 #endif
-  static constexpr bool RSPRUN = REQRUN && CLS == 5 && LBFT_RSPRUN != 0;
+  static constexpr bool RSPRUN = REQRUN && CLS == K_LARGE_LEAN && LBFT_RSPRUN != 0;
 #ifndef LBFT_RSPRUNQ
 #define LBFT_RSPRUNQ 1  // (round 6) lbft_k_run2q: the record exchange's responses that carry nothing their node lacks (response_is_inert) and whose update_node is a no-op, as runs
 #endif
-  static constexpr bool RSPRUNQ = REQRUN && CLS == 7 && LBFT_RSPRUNQ != 0;
+  static constexpr bool RSPRUNQ = REQRUN && CLS == K_LARGE_EXCHANGE && LBFT_RSPRUNQ != 0;
   LBFT_HD bool rsp_runs() const { return (RSPRUN && !q1()) || (RSPRUNQ && q1()); }
 #ifndef LBFT_NTF_MIN
 #define LBFT_NTF_MIN LBFT_RUN_MIN  // events at the head of a bucket's chunk from which a notification run is attempted
@@ -788,17 +816,17 @@ struct SimT {
 #define LBFT_NTFACT 1  // (round 6) ... including the notifications that only add to their node's current timeouts / ballot (notification_effects)
 #endif
   static constexpr bool NTFACT = NTFRUN && F_AX && LBFT_NTFACT != 0;
-  static constexpr bool RING = BIG || CLS == 3;
+  static constexpr bool RING = BIG || CLS == K_GENERIC;
   bool coop_on;  // set by run_coop: the event loop is being run by a whole wavefront
-  static constexpr u32 PB = CLS == 9 ? LBFT_POP_BATCH_QUAD : LBFT_POP_BATCH;  // slots per batch of the packed queue's scan
+  static constexpr u32 PB = CLS == K_HEADLINE ? LBFT_POP_BATCH_QUAD : LBFT_POP_BATCH;  // slots per batch of the packed queue's scan
   LBFT_HD bool coop() const { return COOP && coop_on && P.qcal != 0 && P.ring != 0 && !lossy(); }
-  LBFT_HD bool wide() const { return BIG ? true : (CLS == 3 ? NN() > 32 : false); }
+  LBFT_HD bool wide() const { return BIG ? true : (CLS == K_GENERIC ? NN() > 32 : false); }
   LBFT_HD bool heap() const { return C0 ? false : (BIG ? true : P.qheap != 0); }
   LBFT_HD bool tracing() const { return !C0 && !LEAN && P.rcap != 0; }  // round-switch trace (DataWriter); class 0 never traces
-  LBFT_HD bool q1() const { return !C0 && (!LEAN || CLS == 7) && (P.quirks & 1u) != 0; }  // requests are answered by the peer with real payloads
+  LBFT_HD bool q1() const { return !C0 && (!LEAN || CLS == K_LARGE_EXCHANGE) && (P.quirks & 1u) != 0; }  // requests are answered by the peer with real payloads
   LBFT_HD bool cal() const { return !C0 && P.qcal != 0; }
   LBFT_HD bool packed() const { return C0 ? true : (BIG ? false : NN() <= 16); }
-  LBFT_HD bool qpacked() const { return C0 ? true : (CLS == 3 ? P.qpack != 0 : false); }  // one-word queue entries
+  LBFT_HD bool qpacked() const { return C0 ? true : (CLS == K_GENERIC ? P.qpack != 0 : false); }  // one-word queue entries
   const Params& P;
   char* tile;
   u32 lane4;
@@ -829,7 +857,7 @@ struct SimT {
   u32 qstr, qsh, ql;  // column stride (lanes per wavefront, a power of two) and its log2: element k of a column is [k << qsh]
   u32 hsh;            // the same for the hcbr column (attach_hcbr)
 #if defined(__HIP_DEVICE_COMPILE__)
-  static constexpr bool QS32 = CLS == 9 && LBFT_QUAD_STRIDE32 != 0;
+  static constexpr bool QS32 = CLS == K_HEADLINE && LBFT_QUAD_STRIDE32 != 0;
 #else
   static constexpr bool QS32 = false;  // (the host model passes one plain column per network)
 #endif
@@ -931,7 +959,7 @@ struct SimT {
   // 4-node kernel did not gain from such a window (its register cache misses 3 times per run); a 64-node network misses its single
   // register record on 75 % of 117 k lookups per run, each a dependent memory round trip (round 4, host-model counters).  Write-through
   // like the register cache (blk_put updates a resident entry), rebuilt empty at every launch.
-  static constexpr bool BLW = CLS == 7;  // (compiled into lbft_k_run2q only: in lbft_k_run2l it cost 60 spilled registers and time, see lbft_hip.hip)
+  static constexpr bool BLW = CLS == K_LARGE_EXCHANGE;  // (compiled into lbft_k_run2q only: in lbft_k_run2l it cost 60 spilled registers and time, see lbft_hip.hip)
   u32* bl;       // nullptr = none
   u32 bl_n, bl_sh;
   LBFT_HD void attach_blk_window(u32* column, u32 entries, u32 stride_shift) { bl = (BLW && entries) ? column : nullptr; bl_n = entries; bl_sh = stride_shift; }
@@ -1054,7 +1082,7 @@ struct SimT {
 #define LBFT_BLK_CACHE_UNI 1  // lbft_k_run0u: its state lives in SGPRs / VGPR lanes (one v_readlane / v_writelane per access to a parked word), so every cached
                               // record is paid at every access to the state behind it -- round 5, 1 024 x 4: 3 records 7.56 ms, 2: 7.33, 1: 4.88 (lbft_k_run0s: 5.27)
 #endif
-  static constexpr u32 BCN = CLS == 9 ? LBFT_BLK_CACHE_QUAD : CLS == 12 ? LBFT_BLK_CACHE_UNI : CLS == 5 ? LBFT_BLK_CACHE_LEAN5 : LEAN2 ? LBFT_BLK_CACHE_LEAN2 : LBFT_BLK_CACHE;
+  static constexpr u32 BCN = CLS == K_HEADLINE ? LBFT_BLK_CACHE_QUAD : CLS == K_SMALL_UNIFORM ? LBFT_BLK_CACHE_UNI : CLS == K_LARGE_LEAN ? LBFT_BLK_CACHE_LEAN5 : LEAN2 ? LBFT_BLK_CACHE_LEAN2 : LBFT_BLK_CACHE;
   mutable u32 bc_id[BCN];
   mutable u32 bc_w[BCN][BC_WORDS];
   mutable u32 bc_next;  // FIFO hand (plain round-robin replacement: the second-chance bookkeeping cost more than the misses it saved, EXPERIMENTS.md)
@@ -4346,7 +4374,7 @@ LBFT_UNROLL
           rq &= rq - 1;
           coop_requests(k, LBFT_UNI(max_steps - steps, k));
         }
-        if (is_req) { steps += req_done; act = false; }
+        if (is_req) { steps += req_done; act = false; LBFT_RUNCNT(0, req_done); }
         if (rsp_runs()) {  // ... and a run of responses whose update_node is a no-op (coop_responses)
 #if defined(__HIP_DEVICE_COMPILE__)
           unsigned long long rs = __ballot(is_rsp);
@@ -4358,7 +4386,7 @@ LBFT_UNROLL
             rs &= rs - 1;
             coop_responses(k, LBFT_UNI(max_steps - steps, k));
           }
-          if (is_rsp && rsp_done) { steps += rsp_done; act = false; }  // (0: the head event's update does something -- the ordinary step takes it)
+          if (is_rsp && rsp_done) { steps += rsp_done; act = false; LBFT_RUNCNT(1, rsp_done); }  // (0: the head event's update does something -- the ordinary step takes it)
         }
         if (NTFRUN) {  // ... and the runs of notifications that leave their nodes as they were, of all networks at once (coop_notifications)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -4367,7 +4395,7 @@ LBFT_UNROLL
           const bool any_ntf = is_ntf;
 #endif
           if (any_ntf) coop_notifications(is_ntf, max_steps - steps);
-          if (is_ntf && ntf_done) { steps += ntf_done; act = false; }
+          if (is_ntf && ntf_done) { steps += ntf_done; act = false; LBFT_RUNCNT(2, ntf_done); }
           else if (act && ntf_skip) ntf_skip--;  // (an event seen not to be inert takes its ordinary step)
         }
       }
@@ -4396,26 +4424,26 @@ LBFT_UNROLL
   }
 };
 
-typedef SimT<3> Sim;
+typedef SimT<K_GENERIC> Sim;
 // The class lbft_k_run (and the host model) executes a batch with.
 inline int sim_class(const Params& p) {
-  if (p.n > 32) return 2;
+  if (p.n > 32) return K_LARGE;
   bool small = p.n <= 16 && !p.qheap && !p.equiv && !p.rcap && !p.drop_ppm && !p.part_size && !(p.quirks & 1u);
   bool fits_packed_queue = p.max_clock < (1 << LBFT_QP_TIME_BITS) && p.scap <= 256;  // one-word queue entries
-  return small && fits_packed_queue ? 0 : 1;
+  return small && fits_packed_queue ? K_SMALL : K_MID;
 }
 
-// Does a class-0 batch qualify for the kernel with the headline network fixed at compile time (SimT<9>)?
+// Does a class-0 batch qualify for the kernel with the headline network fixed at compile time (SimT<K_HEADLINE>)?
 inline bool sim_quad(const Params& p) {
-  return sim_class(p) == 0 && p.n == 4 && p.unit_weights && p.delay_model == 0 && p.scap <= 64 && p.rot == 0 && p.rarch_words == 0 &&
+  return sim_class(p) == K_SMALL && p.n == 4 && p.unit_weights && p.delay_model == 0 && p.scap <= 64 && p.rot == 0 && p.rarch_words == 0 &&
          LBFT_C0_IMAJOR && p.off_node == I_WORDS && p.node_words == NF_FIXED_WORDS + 8u && p.snap_words == S_FIXED_WORDS + 8u &&
          p.blk_words == B_WORDS;
 }
-// Does a class-2 / class-1 batch qualify for the lean kernel of its class (SimT<5> / SimT<6>)?
+// Does a class-2 / class-1 batch qualify for the lean kernel of its class (SimT<K_LARGE_LEAN> / SimT<K_MID_LEAN>)?
 inline bool sim_lean_features(const Params& p) { return (!(p.quirks & 1u) || (LBFT_LEAN_Q1 && p.n > 32)) && !p.rcap && !p.drop_ppm && !p.part_size; }
-inline bool sim_lean(const Params& p) { return sim_class(p) == 2 && sim_lean_features(p); }
-inline bool sim_lean_q1(const Params& p) { return sim_lean(p) && (p.quirks & 1u) != 0; }  // ... SimT<7> instead of SimT<5>
-inline bool sim_lean1(const Params& p) { return sim_class(p) == 1 && sim_lean_features(p); }
+inline bool sim_lean(const Params& p) { return sim_class(p) == K_LARGE && sim_lean_features(p); }
+inline bool sim_lean_q1(const Params& p) { return sim_lean(p) && (p.quirks & 1u) != 0; }  // ... SimT<K_LARGE_EXCHANGE> instead of SimT<K_LARGE_LEAN>
+inline bool sim_lean1(const Params& p) { return sim_class(p) == K_MID && sim_lean_features(p); }
 
 // Row layout for a batch; fills the offset fields of `p` and returns words per instance.  Accumulated in 64 bits: a tile is
 // addressed with 32-bit byte offsets (boff(): row << rsh, at most 8), so a layout is only usable while it stays below 2^24 rows; the
@@ -4423,7 +4451,7 @@ inline bool sim_lean1(const Params& p) { return sim_class(p) == 1 && sim_lean_fe
 #define LBFT_CAL_CE_LAYOUT 31u  // (= LBFT_CAL_CE inside SimT)
 inline u32 node_words_used(const Params& p) { return NF_FIXED_WORDS + 2 * p.n + 4 * ((p.n + 31) / 32 - 1); }
 inline u32 snap_words_used(const Params& p) { return S_FIXED_WORDS + 2 * p.n + 2 * ((p.n + 31) / 32 - 1) + ((p.quirks & 1u) ? 2 : 0); }
-inline u32 layout_tile_width(const Params& p) { return sim_class(p) == 0 ? (LBFT_C0_IMAJOR ? 1u : 64u) : sim_class(p) == 1 ? 64u : 1u; }
+inline u32 layout_tile_width(const Params& p) { return sim_class(p) == K_SMALL ? (LBFT_C0_IMAJOR ? 1u : 64u) : sim_class(p) == K_MID ? 64u : 1u; }
 inline u64 compute_layout(Params& p) {
   u64 w = I_WORDS;
   p.mw = (p.n + 31) / 32;
@@ -4438,8 +4466,8 @@ inline u64 compute_layout(Params& p) {
   p.blk_words = B_WORDS + 4 * (p.mw - 1);  // + extension words (nodes / authors >= 32) of KNOWN, QC, PEND and VOTERS
   // class 0, instance-major: notification snapshots and the block pool follow the nodes, the queue's spill rows come last -- the first
   // word of every hot region then depends on num_nodes and snapshot_capacity alone, which the kernel with the headline network fixed at
-  // compile time (SimT<9>) turns into immediates
-  const bool hot_first = LBFT_C0_IMAJOR && LBFT_C0_HOT_FIRST && sim_class(p) == 0;
+  // compile time (SimT<K_HEADLINE>) turns into immediates
+  const bool hot_first = LBFT_C0_IMAJOR && LBFT_C0_HOT_FIRST && sim_class(p) == K_SMALL;
   auto snaps_blocks = [&]() {
     p.off_snap = (u32)w; w += (u64)p.scap * p.snap_words;
     p.off_snap_ref = (u32)w; w += p.scap;
@@ -4475,7 +4503,7 @@ inline u64 compute_layout(Params& p) {
   p.off_ring = (u32)w; w += 2ULL * p.ring;
   if (align_rows) w = (w + 31) & ~(u64)31;
   p.total_words = w > 0xffffffffULL ? 0xffffffffu : (u32)w;
-  p.qpack = sim_class(p) == 0 ? 1u : 0u;
+  p.qpack = sim_class(p) == K_SMALL ? 1u : 0u;
   return w;
 }
 inline bool layout_fits(u64 total_words) { return total_words < (1ULL << 24); }

@@ -172,7 +172,7 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
     }
 #endif
   } else if constexpr (SimT<CLS>::WUNI) {
-    // ONE network per wavefront as wavefront-uniform code (SimT<12>, lbft_k_run0u; p.lpw == 1): nothing below depends on the lane -- the
+    // ONE network per wavefront as wavefront-uniform code (SimT<K_SMALL_UNIFORM>, lbft_k_run0u; p.lpw == 1): nothing below depends on the lane -- the
     // network's index, rows and LDS columns come from the wavefront's index through readfirstlane -- so all 64 lanes run the event loop
     // with the same values and the compiler keeps the protocol logic on the scalar unit (lbft_core.h, SimT::WUNI); only the pop's scan
     // (coop_find) reads per-lane slots.  Stores / LDS writes: the same address and value in every lane.
@@ -311,26 +311,26 @@ __device__ __forceinline__ void run_body(const Params& p, u32* __restrict__ stat
 // Class 0 (the headline small-network path) is compiled for two wavefronts per SIMD; classes 1 and 2 run one 8- or 16-lane
 // wavefront per SIMD and may use the whole register file (VGPRs + AGPRs).
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
-void lbft_k_run0(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(0) run_body<0>(p, state, unfinished); }
-// ... the same kernel with the headline network fixed at compile time (4 nodes, unit voting rights, log-normal delays: SimT<9>, sim_quad())
+void lbft_k_run0(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(K_SMALL) run_body<K_SMALL>(p, state, unfinished); }
+// ... the same kernel with the headline network fixed at compile time (4 nodes, unit voting rights, log-normal delays: SimT<K_HEADLINE>, sim_quad())
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
-void lbft_k_run0q(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(9) run_body<9>(p, state, unfinished); }
-// ... and for small batches (at most LBFT_POPC_MAX_LPW networks per wavefront): the pop's scan by all 64 lanes (SimT<8>)
+void lbft_k_run0q(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(K_HEADLINE) run_body<K_HEADLINE>(p, state, unfinished); }
+// ... and for small batches (at most LBFT_POPC_MAX_LPW networks per wavefront): the pop's scan by all 64 lanes (SimT<K_SMALL_WAVE_POP>)
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
-void lbft_k_run0s(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(8) run_body<8>(p, state, unfinished); }
-// ... and for ONE network per wavefront (batches of <= 2 048 networks), as wavefront-uniform code on the scalar unit (SimT<12>; round 5, measured: 256 / 1 024 / 2 048 x 4
+void lbft_k_run0s(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(K_SMALL_WAVE_POP) run_body<K_SMALL_WAVE_POP>(p, state, unfinished); }
+// ... and for ONE network per wavefront (batches of <= 2 048 networks), as wavefront-uniform code on the scalar unit (SimT<K_SMALL_UNIFORM>; round 5, measured: 256 / 1 024 / 2 048 x 4
 // networks 4.77 / 4.88 / 4.91 ms against 5.81 / 5.27 / 5.28 ms on lbft_k_run0s; LBFT_NO_UNI=1 falls back to that kernel)
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
-void lbft_k_run0u(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(12) run_body<12>(p, state, unfinished); }
+void lbft_k_run0u(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(K_SMALL_UNIFORM) run_body<K_SMALL_UNIFORM>(p, state, unfinished); }
 // Large networks without record exchange / trace / lossy network (sim_lean()): also two wavefronts per SIMD (4 spilled registers)
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
-void lbft_k_run2l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(5) run_body<5>(p, state, unfinished); }
+void lbft_k_run2l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(K_LARGE_LEAN) run_body<K_LARGE_LEAN>(p, state, unfinished); }
 // ... and with the record exchange of quirks bit 0 (sim_lean_q1(): requests answered by the peer, responses inserted): 24 spilled registers
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
-void lbft_k_run2q(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(7) run_body<7>(p, state, unfinished); }
+void lbft_k_run2q(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(K_LARGE_EXCHANGE) run_body<K_LARGE_EXCHANGE>(p, state, unfinished); }
 // ... and class 1 without them (networks of <= 32 nodes with equivocators, a heap / calendar queue, ...): 22 spilled registers
 __global__ __launch_bounds__(LBFT_RUN_BLOCK) __attribute__((amdgpu_waves_per_eu(LBFT_RUN_WAVES_PER_SIMD, LBFT_RUN_WAVES_PER_SIMD)))
-void lbft_k_run1l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(6) run_body<6>(p, state, unfinished); }
+void lbft_k_run1l(Params p, u32* __restrict__ state, u32* __restrict__ unfinished) { LBFT_DEV_ONLY(K_MID_LEAN) run_body<K_MID_LEAN>(p, state, unfinished); }
 #ifndef LBFT_BIG_WAVES_PER_SIMD
 #define LBFT_BIG_WAVES_PER_SIMD 1  // classes 1-2: wavefronts per SIMD the kernels are compiled for (1 = the whole register file;
                                    // measured with 2 -- half the lanes per wavefront, 167 spilled registers: 16384 x 64 nodes
@@ -578,7 +578,7 @@ static bool quad_eligible(const Params& p) {
 // 8.37 / 10.82 / 13.85 on lbft_k_run0; 1 024 x 4 uniform on lbft_k_run0u: 4.71 against 5.11)
 static bool small_batch_kernel(const Params& p) {
   const char* e = getenv("LBFT_NO_POPC");
-  return LBFT_C0_POPC && sim_class(p) == 0 && p.lpw <= LBFT_POPC_MAX_LPW && !quad_eligible(p) && !(e && atoi(e));
+  return LBFT_C0_POPC && sim_class(p) == K_SMALL && p.lpw <= LBFT_POPC_MAX_LPW && !quad_eligible(p) && !(e && atoi(e));
 }
 // ... and large batches of the headline network (4 nodes, unit rights, log-normal delays) lbft_k_run0q; LBFT_NO_QUAD=1: lbft_k_run0
 // LBFT_BLK_WINDOW=n: entries (a power of two, default 32; 0 = off) of the large-network kernels' LDS window of block records
@@ -1235,7 +1235,7 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
     // per SIMD, 24.4 ms at 32 = two per SIMD, 40.1 ms at 16 = two rounds; 1024 x 4 nodes: 22.9 ms at 8 lanes, 17.6 at 4,
     // 13.2 at 2, 9.4 ms at ONE network per wavefront; 8192 x 100 nodes: 9.0 s at 16 lanes, 5.9 s at 8, 7.8 s at 4 = two rounds).
     const bool lean2k = sim_lean(p) && lean2_allowed();
-    u64 resident = (lean2k || sim_class(p) == 0 || (sim_lean1(p) && lean_allowed())) ? 2048 : 1024 * LBFT_BIG_WAVES_PER_SIMD;
+    u64 resident = (lean2k || sim_class(p) == K_SMALL || (sim_lean1(p) && lean_allowed())) ? 2048 : 1024 * LBFT_BIG_WAVES_PER_SIMD;
     u64 want = (b->m + resident - 1) / resident;
     lpw = 1;
     while (lpw < want && lpw < 32) lpw <<= 1;
@@ -1257,7 +1257,7 @@ static int prepare_run(lbft_batch* b, int64_t max_clock) {
   }
   // wavefronts per workgroup of the kernel this batch runs on: 8 = both wavefront slots of a CU's four SIMDs for the kernels compiled
   // for two wavefronts per SIMD, 4 for the full-register ones
-  const bool two_wave_kernel = sim_class(p) == 0 || (sim_lean(p) && lean2_allowed()) || (sim_lean1(p) && lean_allowed());
+  const bool two_wave_kernel = sim_class(p) == K_SMALL || (sim_lean(p) && lean2_allowed()) || (sim_lean1(p) && lean_allowed());
   const u32 nwaves = two_wave_kernel ? LBFT_RUN_WAVES : LBFT_RUN_WAVES_FULL;
   b->run_waves = nwaves;
   // LDS queue slots per instance: what one CU's LDS affords when it hosts 64/lpw workgroups
@@ -1339,11 +1339,11 @@ static int launch_run(lbft_batch* b) {
   const bool leanq = lean && sim_lean_q1(p);
   const bool small0 = small_batch_kernel(p);
   const bool quad0 = quad_kernel(p);
-  const bool uni0 = cls == 0 && uni_kernel(p);
+  const bool uni0 = cls == K_SMALL && uni_kernel(p);
   const void* run_fn = leanq ? reinterpret_cast<const void*>(lbft_k_run2q) : lean ? reinterpret_cast<const void*>(lbft_k_run2l) : lean1 ? reinterpret_cast<const void*>(lbft_k_run1l) :
                        uni0 ? reinterpret_cast<const void*>(lbft_k_run0u) :
-                       (cls == 0 && small0) ? reinterpret_cast<const void*>(lbft_k_run0s) : (cls == 0 && quad0) ? reinterpret_cast<const void*>(lbft_k_run0q) : cls == 0 ? reinterpret_cast<const void*>(lbft_k_run0)
-                     : cls == 1 ? reinterpret_cast<const void*>(lbft_k_run<1>) : reinterpret_cast<const void*>(lbft_k_run<2>);
+                       (cls == K_SMALL && small0) ? reinterpret_cast<const void*>(lbft_k_run0s) : (cls == K_SMALL && quad0) ? reinterpret_cast<const void*>(lbft_k_run0q) : cls == K_SMALL ? reinterpret_cast<const void*>(lbft_k_run0)
+                     : cls == K_MID ? reinterpret_cast<const void*>(lbft_k_run<K_MID>) : reinterpret_cast<const void*>(lbft_k_run<K_LARGE>);
   HIP_TRY(hipFuncSetAttribute(run_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b->lds_bytes));
   const u32 nwaves = b->run_waves, block = 64u * nwaves;
   u32 grid_run = (u32)((b->m + (size_t)nwaves * p.lpw - 1) / ((size_t)nwaves * p.lpw));
@@ -1353,11 +1353,11 @@ static int launch_run(lbft_batch* b) {
   else if (lean) lbft_k_run2l<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (lean1) lbft_k_run1l<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   else if (uni0) lbft_k_run0u<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
-  else if (cls == 0 && small0) lbft_k_run0s<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
-  else if (cls == 0 && quad0) lbft_k_run0q<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
-  else if (cls == 0) lbft_k_run0<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
-  else if (cls == 1) lbft_k_run<1><<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
-  else lbft_k_run<2><<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  else if (cls == K_SMALL && small0) lbft_k_run0s<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  else if (cls == K_SMALL && quad0) lbft_k_run0q<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  else if (cls == K_SMALL) lbft_k_run0<<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  else if (cls == K_MID) lbft_k_run<K_MID><<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
+  else lbft_k_run<K_LARGE><<<grid_run, block, b->lds_bytes, b->stream>>>(p, b->d_state, b->d_unfinished);
   HIP_TRY(hipGetLastError());
   return LBFT_OK;
 }

@@ -29,7 +29,7 @@ struct BlockInfo { u32 base; u32 round, prev, author, prev_round, pp, pp_round, 
 
 // Every block of the instance's pool, in id order (a block's predecessor has a smaller id): the hashes the reference gives the Block,
 // the ledger State after it and its QuorumCertificate -- what identifies a record in a NodeState image.
-inline void pool_block_infos(SimT<3>& s, const Params& hp, std::vector<save_node_detail::BlockInfo>& B, u64& empty_state) {
+inline void pool_block_infos(SimT<K_GENERIC>& s, const Params& hp, std::vector<save_node_detail::BlockInfo>& B, u64& empty_state) {
   using namespace save_node_detail;
   const u32 mw = hp.mw;
   const u32 nblocks = s.ld(I_NBLOCKS);

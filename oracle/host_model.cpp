@@ -37,7 +37,7 @@ typedef struct lbft_hostmodel_caps {
   uint32_t qcap, scap, bcap, lcap;
   uint32_t ql;  // queue slots held in the emulated LDS front (0 = HBM rows only)
   uint32_t qheap;  // 1 = binary-heap event queue (the device's large-network mode)
-  uint32_t force_generic;  // 1 = run the step as the run-time-generic class SimT<3> instead of the specialised one
+  uint32_t force_generic;  // 1 = run the step as the run-time-generic class SimT<K_GENERIC> instead of the specialised one
   uint32_t rcap;           // > 0: round-switch trace (DataWriter) with this many rounds per node
   uint32_t qcal;           // 1 = calendar event queue (needs max_clock <= LBFT_CAL_MAX_CLOCK and a class >= 1 kernel)
   uint32_t ring;           // > 0 (class 2 + calendar): the cooperative event loop (run_coop / coop_bulk, 64 emulated lanes) with a ring of this many pre-generated draws
@@ -145,13 +145,13 @@ int lbft_hostmodel_run_batch(const lbft_oracle_config* cfg, const lbft_hostmodel
     for (size_t i = tid; i < n_instances; i += threads) {
       { Sim s0(p, state.data(), (u32)i); s0.init(seeds[i]); }
       // emulate the device's launch structure: the LDS front of the queue is a cache of the HBM rows
-      if (cls == 0 && LBFT_C0_QUAD && sim_quad(p)) { SimT<9> s(p, state.data(), (u32)i); run_one(s, i); }  // as the device dispatches (large batches)
-      else if (cls == 0) { SimT<0> s(p, state.data(), (u32)i); run_one(s, i); }
-      else if (cls == 1 && sim_lean1(p)) { SimT<6> s(p, state.data(), (u32)i); run_one(s, i); }  // as the device dispatches
-      else if (cls == 1) { SimT<1> s(p, state.data(), (u32)i); run_one(s, i); }
-      else if (cls == 2 && sim_lean_q1(p)) { SimT<7> s(p, state.data(), (u32)i); run_one(s, i); }  // as the device dispatches
-      else if (cls == 2 && sim_lean(p)) { SimT<5> s(p, state.data(), (u32)i); run_one(s, i); }
-      else if (cls == 2) { SimT<2> s(p, state.data(), (u32)i); run_one(s, i); }
+      if (cls == K_SMALL && LBFT_C0_QUAD && sim_quad(p)) { SimT<K_HEADLINE> s(p, state.data(), (u32)i); run_one(s, i); }  // as the device dispatches (large batches)
+      else if (cls == K_SMALL) { SimT<K_SMALL> s(p, state.data(), (u32)i); run_one(s, i); }
+      else if (cls == K_MID && sim_lean1(p)) { SimT<K_MID_LEAN> s(p, state.data(), (u32)i); run_one(s, i); }  // as the device dispatches
+      else if (cls == K_MID) { SimT<K_MID> s(p, state.data(), (u32)i); run_one(s, i); }
+      else if (cls == K_LARGE && sim_lean_q1(p)) { SimT<K_LARGE_EXCHANGE> s(p, state.data(), (u32)i); run_one(s, i); }  // as the device dispatches
+      else if (cls == K_LARGE && sim_lean(p)) { SimT<K_LARGE_LEAN> s(p, state.data(), (u32)i); run_one(s, i); }
+      else if (cls == K_LARGE) { SimT<K_LARGE> s(p, state.data(), (u32)i); run_one(s, i); }
       else { Sim s(p, state.data(), (u32)i); run_one(s, i); }
     }
   };

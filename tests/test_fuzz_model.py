@@ -111,9 +111,10 @@ def test_random_large_configurations_on_the_cooperative_loop(oracle, chunk):
             assert a["counters"][key] == b["counters"][key], (key, kw)
 
 
-# LBFT_FUZZ_GPU_CHUNKS=n widens the device run (10 configurations per chunk; the default keeps `pytest -m gpu` short)
+# LBFT_FUZZ_GPU_CHUNKS=n widens the device run (10 configurations per chunk; the default keeps `pytest -m gpu` short); LBFT_FUZZ_GPU_FIRST=k starts at chunk k
+# (other draws than an earlier widened run; likewise ..._QUAD_FIRST / ..._LARGE_FIRST below)
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_CHUNKS", "8"))))
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_FIRST", "0")), int(os.environ.get("LBFT_FUZZ_GPU_FIRST", "0")) + int(os.environ.get("LBFT_FUZZ_GPU_CHUNKS", "8"))))
 def test_random_configurations_on_the_device_match_the_oracle(oracle, chunk):
     import librabft_simulator_amd as amd
     rng = np.random.default_rng(777 + chunk)
@@ -133,7 +134,10 @@ def test_random_configurations_on_the_device_match_the_oracle(oracle, chunk):
                                      drop_per_million=kw.get("drop_per_million", 0), partition=part, quirks=kw.get("quirks", 0),
                                      rights_rotation=kw.get("rights_rotation", 0),
                                      calendar_queue=bool(rng.random() < 0.7), max_steps_per_launch=int(rng.choice([0, 0, 173])),
-                                     lanes_per_wavefront=int(rng.choice([0, 0, 1, 2, 8, 16, 32, 64])), block_capacity=max_clock + 64,
+                                     lanes_per_wavefront=int(rng.choice([0, 0, 1, 2, 8, 16, 32, 64])),
+                                     # (equivocators propose twice per round: chunk 149 -- 3 nodes, rights [1, 1, 5], the heavy node committing alone every 1.7 ticks
+                                     # and equivocating -- needs 1 204 block rows by clock 1 000; with max_clock + 64 the device raised F_BLOCK_OVERFLOW, as the host build does)
+                                     block_capacity=(2 * max_clock + 256) if kw.get("equivocate_every", 0) else max_clock + 64,
                                      queue_capacity=max(4096, 64 * n * n),
                                      # 0 = automatic (<= 64 slots for small honest networks: the register-resident free mask)
                                      snapshot_capacity=0 if (not (kw.get("quirks", 0) & 1) and rng.random() < 0.5) else max(128, 128 * n))
@@ -154,7 +158,7 @@ def test_random_configurations_on_the_device_match_the_oracle(oracle, chunk):
 # cut into pieces.  At least half of the draws must have run on that kernel -- or, one network per wavefront (batches this small then run lbft_k_run0u), on the
 # scalar-unit kernel -- (the rest: the general small-network kernels).
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_QUAD_CHUNKS", "5"))))
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_QUAD_FIRST", "0")), int(os.environ.get("LBFT_FUZZ_GPU_QUAD_FIRST", "0")) + int(os.environ.get("LBFT_FUZZ_GPU_QUAD_CHUNKS", "5"))))
 def test_random_headline_network_configurations_on_the_device_match_the_oracle(oracle, chunk):
     import librabft_simulator_amd as amd
     rng = np.random.default_rng(31337 + chunk)
@@ -206,7 +210,7 @@ def test_random_headline_network_configurations_on_the_device_match_the_oracle(o
 
 # the same for networks of 33..128 nodes: the cooperative large-network kernel (lanes per wavefront 1..32, multi-launch)
 @pytest.mark.gpu
-@pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_LARGE_CHUNKS", "4"))))
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("LBFT_FUZZ_GPU_LARGE_FIRST", "0")), int(os.environ.get("LBFT_FUZZ_GPU_LARGE_FIRST", "0")) + int(os.environ.get("LBFT_FUZZ_GPU_LARGE_CHUNKS", "4"))))
 def test_random_large_configurations_on_the_device_match_the_oracle(oracle, chunk):
     import librabft_simulator_amd as amd
     rng = np.random.default_rng(4242 + chunk)

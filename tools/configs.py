@@ -44,14 +44,17 @@ CONFIGS = {
                                                              commands_per_epoch=50, quirks=3, rights_rotation=1),
 }
 HBM_PEAK_GBS = 8000.0
-# Share of a configuration's notifications / responses that the cooperative runs retire (tests/tools/run_stats.cpp on the host build of the kernel logic, one or two
-# instances each: profiles/r06/cooperative_runs_final_c5_c4_c4live_c5live_c5named.jsonl) -- such an event writes its node's timer words, not its row (roofline()).
+# Share of a configuration's notifications / responses that the cooperative runs retire -- such an event writes its node's timer words, not its row (roofline()).
+# Since the round's last session COUNTED ON THE DEVICE, every instance of the full-size run (liblbft_hip_runcount.so = -DLBFT_PHASE_TIMERS -DLBFT_RUN_COUNT, LDS counters
+# per wavefront; tools/gpu_r06_run_counts.sh -> profiles/r06/run_counts_on_the_device.jsonl: retired events / the kind's events, same counters and commits as the
+# product library in the same call).  The host build of the kernel logic (64-lane segments, one or two instances: tests/tools/run_stats.cpp ->
+# profiles/r06/cooperative_runs_final_c5_c4_c4live_c5live_c5named.jsonl) had given 0.8283 / 0.8763, 0.9618 / 0.9952, 0.8870 / 0.8201, 0.9506 / 0.9941, 0.9678 / 0.9927.
 RUN_SHARES = {
-    "c4_16384x64_longtail_equivocators": {"notify": 0.8283, "response": 0.8763},
-    "c5_8192x100_weighted_epochs": {"notify": 0.9618, "response": 0.9952},
-    "c4live_16384x64_longtail_equivocators_fixed": {"notify": 0.8870, "response": 0.8201},
-    "c5live_8192x100_rotating_rights_epochs_fixed": {"notify": 0.9506, "response": 0.9941},
-    "c5named_8192x100_weighted_epoch_every_50_commits": {"notify": 0.9678, "response": 0.9927},
+    "c4_16384x64_longtail_equivocators": {"notify": 83467987 / 100539014, "response": 119600086 / 136261613},                   # 0.8302 / 0.8777
+    "c5_8192x100_weighted_epochs": {"notify": 540324867 / 563063241, "response": 575621584 / 578109344},                       # 0.9596 / 0.9957
+    "c4live_16384x64_longtail_equivocators_fixed": {"notify": 512370218 / 574990270, "response": 337271225 / 411852790},       # 0.8911 / 0.8189
+    "c5live_8192x100_rotating_rights_epochs_fixed": {"notify": 649765811 / 684296122, "response": 711763478 / 716057659},      # 0.9495 / 0.9940
+    "c5named_8192x100_weighted_epoch_every_50_commits": {"notify": 5392660624 / 5581414146, "response": 6508032751 / 6556394091},  # 0.9662 / 0.9926
 }
 OPT_IN = ("c5b", "c4live", "c5live", "c5named")
 # What pins each configuration's results (printed with every line): the reference itself only holds answers for 3- / 8-node
@@ -129,8 +132,8 @@ def roofline(layout, k, kernel_ms, name=None):
     noop_resp = min(k["events"][2], upd) if (cls != 0 and not q1) else 0
     # ... (third session of round 6) and so do the events the response / notification runs retire in every mode: a run's event reads its node's row (and a
     # notification its snapshot's fixed words), proves that handler + update_node leave the node as it was -- or only add to its current timeouts / ballot --
-    # and writes the four timer words (+ a delta of a few words, not counted: a lower bound).  The device has no counter for them; the shares are the
-    # workload's, measured on the host build of the kernel logic (RUN_SHARES below)
+    # and writes the four timer words (+ a delta of a few words, not counted: a lower bound).  The product kernels carry no counter for them; the shares are
+    # counted on the device by the diagnostic build of the same logic (RUN_SHARES above)
     sh = RUN_SHARES.get(name)
     noop = min(int(sh["notify"] * k["events"][0] + sh["response"] * k["events"][2]), upd) if (sh and cls != 0) else noop_resp
     ex_rows = node_reads * s_node + (upd - noop_resp) * s_node + noop_resp * 16 + 2 * pops * s_evt + 2 * k["events"][0] * s_notif  # (the model before the runs of notifications)
@@ -189,6 +192,14 @@ def run(name, scale=1.0, reps=1, lpw=0):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from sweep import COUNTS, PHASES
         pc = sim.phase_cycles()
+        if os.environ.get("LBFT_RUN_COUNT"):  # liblbft_hip_runcount.so (-DLBFT_PHASE_TIMERS -DLBFT_RUN_COUNT): what the cooperative runs retire ON THE DEVICE
+            ev = k["events"]
+            out["runs_device"] = {"retired": {"request": int(pc[0]), "response": int(pc[1]), "notify": int(pc[2])},
+                                  "runs": {"request": int(pc[3]), "response": int(pc[4]), "notify": int(pc[5])},
+                                  "share_of_kind": {"request": int(pc[0]) / max(ev[1], 1), "response": int(pc[1]) / max(ev[2], 1), "notify": int(pc[2]) / max(ev[0], 1)},
+                                  "events_per_run": {"request": int(pc[0]) / max(int(pc[3]), 1), "response": int(pc[1]) / max(int(pc[4]), 1), "notify": int(pc[2]) / max(int(pc[5]), 1)},
+                                  "wave_steps": int(pc[30])}
+            raise StopIteration
         tot = float(sum(int(pc[i]) for i in range(30) if i not in COUNTS)) or 1.0
         out["phases"] = {PHASES.get(i, str(i)): round(int(pc[i]) / tot, 4) for i in range(30) if int(pc[i]) and i not in COUNTS}
         out["cycles_per_wave_step"] = int(pc[31]) / max(int(pc[30]), 1)
