@@ -9,6 +9,7 @@ hashes) of all its nodes.  Hours of CPU time on 8 cores, minutes on the GPU box'
 
 --count NAME=K   only the first K instances of configuration NAME (prefix match) get a digest; the rest stay "not covered" (c5named: 49 core-seconds per
                  instance on the oracle)
+--first K        start at instance K (the window [K, count): several machines share one configuration, their outputs are merged afterwards)
 --merge PATH     start from an existing fixture: configurations / instances it already covers are kept, new ones added
 --device         (GPU box) also run every configuration on the HIP path and report, per configuration, how many covered instances differ
 """
@@ -51,6 +52,8 @@ def main():
     ap.add_argument("--out", default=fsd.FIXTURE)
     ap.add_argument("--device", action="store_true")
     ap.add_argument("--none", action="store_true", help="run nothing: merge the given fixtures and write the result")
+    ap.add_argument("--first", type=int, default=0, help="start at this instance (with --count NAME=K: the window [first, K) -- several machines can share a configuration)")
+    ap.add_argument("--save-every", type=int, default=8, help="write the fixture every N oracle calls (a run that may be cut off: 1)")
     ap.add_argument("--log", default=None)
     a = ap.parse_args()
     limits = {}
@@ -123,7 +126,7 @@ def main():
                 int(res.commit_counts.max()), int(ep.min()), int(ep.max())))
             del sim, res
         t0, done, bad = time.time(), 0, 0
-        for lo in range(0, want, chunk):
+        for lo in range(min(a.first, want), want, chunk):
             hi = min(want, lo + chunk)
             todo = np.nonzero(~cov[lo:hi])[0] + lo
             if len(todo):
@@ -133,7 +136,7 @@ def main():
                 done += len(todo)
             if dev is not None:
                 bad += int((dev[lo:hi] != dg[lo:hi]).sum())
-            if (lo // chunk) % 8 == 7 or hi == want:
+            if ((lo - min(a.first, want)) // chunk) % a.save_every == a.save_every - 1 or hi == want:
                 say("  %s [%d, %d) oracle %.0f s%s" % (name, 0, hi, time.time() - t0, "" if dev is None else ", device mismatches so far %d" % bad))
                 table[name] = (dg, cov)
                 save(a.out, table, meta)
