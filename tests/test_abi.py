@@ -148,7 +148,7 @@ def test_run_kernels_keep_their_state_in_registers(hiplib):
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"), reason="needs the ROCm LLVM binutils")
 def test_uniform_kernel_compiles_to_scalar_code(hiplib):
-    """lbft_k_run0u (SimT<12>: batches with one network per wavefront; round 5: 1 024 x 4 networks 4.88 ms against 5.27 on lbft_k_run0s): nothing in
+    """lbft_k_run0u (SimT<K_SMALL_UNIFORM>: batches with one network per wavefront; round 5: 1 024 x 4 networks 4.88 ms against 5.27 on lbft_k_run0s): nothing in
     its event loop depends on the lane, so that the compiler keeps the step on the scalar unit.  One source of divergence slipping in -- an
     inline-asm pin, a flat load, the return value of an out-of-line helper -- silently turns the whole loop back into masked vector code:
     the register budget tells (162 VGPRs in the product build -- most of them lanes that park scalar state --, 215+ as vector code: lbft_k_run0s)."""

@@ -132,7 +132,7 @@ def test_host_model_large_networks(oracle, name, qcal):
 
 
 def test_generic_class_equals_specialised(oracle):
-    """SimT<3> (everything decided at run time: what the init / read-back kernels instantiate) == SimT<0..2>."""
+    """SimT<K_GENERIC> (everything decided at run time: what the init / read-back kernels instantiate) == SimT<K_SMALL / K_MID / K_LARGE>."""
     for kw, m, max_clock, qheap in (LARGE["n4_heap_mode"], LARGE["n33_two_mask_words"], (dict(num_nodes=4), 64, 1000, 0)):
         cfg = oracle.make_config(math_mode=1, **kw)
         seeds = np.arange(1, m + 1, dtype=np.uint64)
