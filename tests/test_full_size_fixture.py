@@ -18,7 +18,7 @@ LIVE = {"c3_65536x4": 256, "c4_16384x64_longtail_equivocators": 8, "c4live_16384
         "c5live_8192x100_rotating_rights_epochs_fixed": 4, "c5named_8192x100_weighted_epoch_every_50_commits": 0}
 # ... and what the device tests assert about the coverage
 MIN_COVERED = {"c3_65536x4": 65536, "c4_16384x64_longtail_equivocators": 16384, "c4live_16384x64_longtail_equivocators_fixed": 16384,
-               "c5_8192x100_weighted_epochs": 8192, "c5live_8192x100_rotating_rights_epochs_fixed": 8192, "c5named_8192x100_weighted_epoch_every_50_commits": 1024}
+               "c5_8192x100_weighted_epochs": 8192, "c5live_8192x100_rotating_rights_epochs_fixed": 8192, "c5named_8192x100_weighted_epoch_every_50_commits": 3584}
 
 
 def test_fixture_covers_every_full_size_configuration():

@@ -676,7 +676,7 @@ def test_full_size_config5_as_named_8192x100_reconfiguration_every_50_commits(am
     assert _prefix_consistent(cc, hist)                      # logs agree across the epoch change
     assert (hist["proposer"][np.arange(hist.shape[2])[None, None, :] < cc[:, :, None]] < n).all()
     covered, _ = _fixture_check(name, amd, oracle, res, kw, seeds, max_clock, live=16, hist=hist)
-    assert covered >= 1024                                   # (the first 1 024 instances: 14 hours of oracle time on one core, computed on the GPU box's host)
+    assert covered >= 3584                                   # (3 584 instances since the round's last session: 49 core-seconds of oracle time each, computed on the GPU box's host and the build container)
 
 
 def test_full_batch_math_mode_0_all_262144_nodes(amd, oracle):

@@ -75,7 +75,7 @@ PARITY_SAMPLE = {
     "c5_8192x100_weighted_epochs": "all 8 192 instances in every suite run (committed oracle digests, tests/golden/full_size_digests.npz) + 64 live on the oracle",
     "c4live_16384x64_longtail_equivocators_fixed": "all 16 384 instances in every suite run (committed oracle digests) + 128 live on the oracle",
     "c5live_8192x100_rotating_rights_epochs_fixed": "all 8 192 instances in every suite run (committed oracle digests) + 64 live on the oracle",
-    "c5named_8192x100_weighted_epoch_every_50_commits": "the first 1 024 of 8 192 instances in every suite run (committed oracle digests: 49 core-seconds of oracle time per instance) + 16 live",
+    "c5named_8192x100_weighted_epoch_every_50_commits": "the first 3 584 of 8 192 instances in every suite run (committed oracle digests: 49 core-seconds of oracle time per instance, computed on the GPU box's host and on the build container) + 16 live",
 }
 # (round 6: every instance the oracle has a digest for in tests/golden/full_size_digests.npz is compared in every suite run -- tests/full_size_digest.py)
 # What a line measures, where that is not what its name suggests (printed with the line)
