@@ -32,7 +32,7 @@ for chunk in range(lo, hi):
     cfg = oracle.make_config(math_mode=1, **kw)
     a = oracle.run_batch(cfg, seeds, max_clock, threads=2, history_cap=64)
     b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=2, history_cap=64, qcap=max(8192, 32 * n * n),
-                                   scap=min(52000, 6 * n * n + 16 * n) if kw.get("quirks", 0) & 1 else 128 * n, bcap=512, lcap=512, ql=0, qheap=1, qcal=1,
+                                   scap=min(65535, 6 * n * n + 16 * n) if kw.get("quirks", 0) & 1 else 128 * n, bcap=512, lcap=512, ql=0, qheap=1, qcal=1,
                                    ring=int(rng.choice([128, 256, 512])), ring_topup=int(rng.choice([0, 4, 16])))
     ok = (all((a[k] == b[k]).all() for k in ("commit_counts", "active_rounds", "last_states", "histories")) and not b["faults"].any()
           and all(a["counters"][k] == b["counters"][k] for k in ("events", "rng_draws", "rounds", "commits", "events_scheduled")))
