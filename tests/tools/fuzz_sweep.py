@@ -55,7 +55,7 @@ for chunk in range(lo, hi, 4):
     a = oracle.run_batch(cfg, seeds, max_clock, threads=os.cpu_count(), history_cap=64)
     ring, topup = int(rng.choice([128, 256, 512])), int(rng.choice([0, 4, 16]))
     b = oracle.hostmodel_run_batch(cfg, seeds, max_clock, threads=os.cpu_count(), history_cap=64, qcap=max(8192, 32 * n * n),
-                                   scap=min(52000, 6 * n * n + 16 * n) if kw.get("quirks", 0) & 1 else 128 * n, bcap=512, lcap=512, ql=0, qheap=1, qcal=1,
+                                   scap=min(65535, 6 * n * n + 16 * n) if kw.get("quirks", 0) & 1 else 128 * n, bcap=512, lcap=512, ql=0, qheap=1, qcal=1,
                                    ring=ring, ring_topup=topup)
     ok = (all((a[k] == b[k]).all() for k in ("commit_counts", "active_rounds", "last_states", "histories")) and not b["faults"].any()
           and all(a["counters"][k] == b["counters"][k] for k in ("events", "rng_draws", "rounds", "commits", "events_scheduled")))
